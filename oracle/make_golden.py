@@ -1,0 +1,130 @@
+"""TEST INFRASTRUCTURE ONLY — generates tests/golden/*.pt by running the UNMODIFIED reference
+(/root/reference, imported under oracle/ref_stubs.py) on seeded inputs and the deterministic
+weights of oracle/weights.py.  Run in the build container (the reference does not exist on the
+GPU box):   python -m oracle.make_golden [--only NAME]
+
+Each fixture stores the case description (enough to rebuild weights+inputs from seeds) and the
+reference outputs only, so files stay small.
+"""
+import argparse
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from oracle import ref_stubs  # noqa: E402
+from oracle.pixart_oracle import OracleCfg  # noqa: E402
+from oracle.weights import make_inputs, make_state_dict  # noqa: E402
+
+GOLDEN_DIR = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+
+CASES = {
+    # name: (cfg kwargs, input kwargs)
+    "fwd_d2_sq": (dict(depth=2, input_size=16, model_max_length=20), dict(B=2, Hl=16, Wl=16, L=20, lens=[20, 7])),
+    "fwd_d2_kvconv": (dict(depth=2, input_size=16, model_max_length=20, kv_sampling="conv", kv_scale_factor=2, kv_layers=(1,), pe_interpolation=1.0),
+                      dict(B=2, Hl=16, Wl=24, L=20, lens=[13, 20])),
+    "fwd_d2_kvuniform": (dict(depth=2, input_size=16, model_max_length=20, kv_sampling="uniform", kv_scale_factor=2, kv_layers=(0, 1)),
+                         dict(B=2, Hl=16, Wl=16, L=20, lens=[20, 20])),
+    "fwd_d2_kvave": (dict(depth=2, input_size=16, model_max_length=20, kv_sampling="ave", kv_scale_factor=2, kv_layers=(0, 1)),
+                     dict(B=2, Hl=16, Wl=16, L=20, lens=[5, 20])),
+    "fwd_d2_nomask": (dict(depth=2, input_size=16, model_max_length=20, pe_interpolation=0.5), dict(B=3, Hl=8, Wl=8, L=20, lens=None)),
+    "train_d2": (dict(depth=2, input_size=16, model_max_length=20, kv_sampling="conv", kv_scale_factor=2, kv_layers=(1,)),
+                 dict(B=2, Hl=16, Wl=16, L=20, lens=[20, 9])),
+    "dpms_d2": (dict(depth=2, input_size=16, model_max_length=20), dict(B=2, Hl=16, Wl=16, L=20, lens=[20, 11])),
+    # BASELINE.json configs[0]: XL/2 256px, batch 2, 2 DPM-Solver steps, CFG 4.5, random-init, CPU
+    "cfg1_xl2_256": (dict(depth=28, input_size=32, model_max_length=300, pe_interpolation=0.5), dict(B=2, Hl=32, Wl=32, L=300, lens=[300, 77])),
+}
+
+
+def build_reference(cfg, sd):
+    ref_stubs.install()
+    from diffusion.model.nets.PixArtMS import PixArtMS
+    kvc = None
+    if cfg.kv_sampling is not None:
+        kvc = {"sampling": cfg.kv_sampling, "scale_factor": cfg.kv_scale_factor, "kv_compress_layer": list(cfg.kv_layers)}
+    m = PixArtMS(depth=cfg.depth, hidden_size=cfg.hidden_size, patch_size=cfg.patch_size, num_heads=cfg.num_heads,
+                 input_size=cfg.input_size, pe_interpolation=cfg.pe_interpolation, model_max_length=cfg.model_max_length,
+                 class_dropout_prob=0.0, qk_norm=cfg.qk_norm, kv_compress_config=kvc)
+    missing, unexpected = m.load_state_dict(sd, strict=False)
+    assert [k for k in missing if k != "pos_embed"] == [] and unexpected == [], (missing, unexpected)
+    return m
+
+
+def gen_case(name):
+    ckw, ikw = CASES[name]
+    cfg = OracleCfg(**ckw)
+    sd = make_state_dict(cfg, seed=0)
+    inp = make_inputs(seed=1, **ikw)
+    m = build_reference(cfg, sd).eval()
+    hw = torch.tensor([[inp["x"].shape[-2] * 8.0, inp["x"].shape[-1] * 8.0]] * inp["x"].shape[0])
+    data_info = {"img_hw": hw, "aspect_ratio": torch.ones(inp["x"].shape[0], 1)}
+    mask = inp["mask"] if ikw.get("lens") is not None else None
+    out = {"cfg": ckw, "inputs": ikw, "weights_seed": 0, "inputs_seed": 1}
+    t0 = time.time()
+    if name.startswith("fwd"):
+        with torch.no_grad():
+            out["y"] = m(inp["x"], inp["t"], inp["y"], mask=mask, data_info=data_info).clone()
+    elif name.startswith("train"):
+        from diffusion import IDDPM
+        m.train()
+        diff = IDDPM(str(1000), learn_sigma=True, pred_sigma=True, snr=False)
+        t = inp["t"].clone()
+        t[0] = 0  # exercise the decoder-NLL branch (gaussian_diffusion.py:741)
+        terms = diff.training_losses(m, inp["x"], t, model_kwargs=dict(y=inp["y"], mask=mask[:, None, None, :], data_info=data_info), noise=inp["noise"])
+        loss = terms["loss"].mean()
+        loss.backward()
+        out.update(t=t, loss=terms["loss"].detach().clone(), mse=terms["mse"].detach().clone(), vb=terms["vb"].detach().clone())
+        grads = {}
+        for k, p in m.named_parameters():
+            g = p.grad
+            grads[k] = {"norm": g.norm().item(), "head": g.flatten()[:16].clone(), "sum": g.double().sum().item()}
+            if g.numel() <= 8192:
+                grads[k]["full"] = g.clone()
+        out["grads"] = grads
+    elif name.startswith("dpms") or name.startswith("cfg1"):
+        from diffusion import DPMS
+        g = torch.Generator().manual_seed(7)
+        null_y = torch.randn(1, 1, ikw["L"], 4096, generator=g).repeat(inp["x"].shape[0], 1, 1, 1)
+        with torch.no_grad():
+            out["fwd"] = m(inp["x"], inp["t"], inp["y"], mask=mask, data_info=data_info).clone()
+            dpms = DPMS(m.forward_with_dpmsolver, condition=inp["y"], uncondition=null_y, cfg_scale=4.5,
+                        model_kwargs=dict(data_info=data_info, mask=mask))
+            out["sample"] = dpms.sample(inp["x"], steps=2, order=2, skip_type="time_uniform", method="multistep").clone()
+        out["null_seed"] = 7
+    out["ref_seconds"] = time.time() - t0
+    return out
+
+
+def gen_tables():
+    ref_stubs.install()
+    from diffusion.model.nets.PixArt import get_2d_sincos_pos_embed
+    from diffusion.model.nets.PixArt_blocks import TimestepEmbedder
+    out = {"pos": {}, "temb": {}}
+    for (h, w, pe, base) in [(16, 16, 0.5, 16), (8, 12, 1.0, 8), (64, 64, 2.0, 64), (32, 48, 1.0, 32)]:
+        tab = get_2d_sincos_pos_embed(1152, (h, w), pe_interpolation=pe, base_size=base)
+        out["pos"][(h, w, pe, base)] = torch.from_numpy(tab[:: max(1, (h * w) // 37)]).clone()  # strided rows, float64
+    ts = torch.tensor([0.0, 1.0, 17.5, 499.0, 999.0, 998.999])
+    out["temb"]["t"] = ts
+    out["temb"]["emb"] = TimestepEmbedder.timestep_embedding(ts, 256).clone()
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", default=None)
+    a = ap.parse_args()
+    os.makedirs(GOLDEN_DIR, exist_ok=True)
+    torch.manual_seed(0)
+    names = [a.only] if a.only else list(CASES) + ["tables"]
+    for n in names:
+        t0 = time.time()
+        obj = gen_tables() if n == "tables" else gen_case(n)
+        path = os.path.join(GOLDEN_DIR, n + ".pt")
+        torch.save(obj, path)
+        print(f"{n}: {os.path.getsize(path) / 1024:.1f} KiB in {time.time() - t0:.1f}s")
+
+
+if __name__ == "__main__":
+    main()
