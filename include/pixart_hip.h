@@ -1,0 +1,131 @@
+/* pixart_hip.h — C ABI of libpixart_hip.so: hand-written gfx950 (MI355X, CDNA4) kernels for the PixArt-Sigma
+ * denoiser hot path (PixArtMS / PixArtMSBlock forward + backward + AdamW).
+ *
+ * The reference (PixArt-alpha/PixArt-sigma) has NO native/FFI boundary: its kernels live in third-party wheels
+ * (xformers FMHA, cuBLAS/cuDNN through torch.nn).  The seam this library replaces is therefore the reference's
+ * *operator call sites*; each entry point below cites the reference lines whose math it computes
+ * (paths relative to the reference repo root).  The Python binding a maintainer adds is a ctypes stub, shown in
+ * INTEGRATION.md and implemented in pixart_sigma_amd/lib.py.
+ *
+ * Conventions
+ *   - plain C: device pointers + sizes + a hipStream_t; no torch types.  The caller owns every buffer (including
+ *     saved activations and workspaces); kernels never allocate, never synchronise, and launch only on `stream`.
+ *   - return 0 on success, negative on error; pxa_last_error() returns a thread-local message.  No global state.
+ *   - "bf16" pointers are `void*` to 16-bit bfloat16; everything else is float32 / int32.
+ *   - row-major tensors exactly as the reference lays them out: tokens (B*N, C), qkv (B, N, 3, H, 72).
+ */
+#ifndef PIXART_HIP_H
+#define PIXART_HIP_H
+
+#include <hip/hip_runtime_api.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PXA_ABI_VERSION 1
+
+const char* pxa_last_error(void);
+int pxa_abi_version(void);
+int pxa_device_info(int* cu_count, int* is_gfx950);
+
+/* ---------------------------------------------------------------------------------------------- GEMM family
+ * Replaces torch.nn.Linear forward/backward at: attn.qkv / attn.proj (PixArt_blocks.py:130,155-156),
+ * cross_attn.q_linear / kv_linear / proj (PixArt_blocks.py:47-48,54-55), mlp.fc1 / fc2 (timm Mlp, PixArtMS.py:66-67,77),
+ * y_embedder.y_proj (PixArt_blocks.py:385,406), final_layer.linear (PixArt_blocks.py:220).
+ * layout 0 (NT): C[m][n] = sum_k A[m][k]*B[n][k]   y = x W^T          A:(M,K) B:(N,K)
+ * layout 1 (NN): C[m][n] = sum_k A[m][k]*B[k][n]   dX = dY W          A:(M,K) B:(K,N)
+ * layout 2 (TN): C[m][n] = sum_k A[k][m]*B[k][n]   dW = dY^T X        A:(K,M) B:(K,N)
+ * act 0: none; 1: GELU(tanh) applied after bias (pre-activation optionally stored to out2_bf16);
+ * act 2: multiply by GELU'(aux[m][n]) (aux = saved pre-activation) — the fc1 backward input gradient. */
+typedef struct {
+  const void* A; const void* B;  /* bf16 */
+  int lda, ldb;
+  int M, N, K;
+  int layout;
+  const float* bias;             /* [N] or NULL */
+  int act;
+  const void* aux; int ldaux;    /* bf16 [M][N], act == 2 */
+  void* out_bf16; void* out2_bf16; int ld_out;
+  float* out_f32; int ld_f32;
+  int accumulate;                /* out_f32: 0 = store, 1 = atomicAdd (gradient accumulation / split-K) */
+  int split_k;                   /* >1 only with accumulate */
+} pxa_gemm_args;
+int pxa_gemm(const pxa_gemm_args* args, hipStream_t stream);
+
+/* ---------------------------------------------------------------------------------------------- adaLN-single rows
+ * x' = x + gate*u (u bf16, gate per sample; either may be NULL), optional bf16 copy of x' (cross-attn input),
+ * xn = LayerNorm(x', no affine, eps) * (1 + scale) + shift  -> bf16.
+ * Replaces nn.LayerNorm(elementwise_affine=False, eps=1e-6) + t2i_modulate + the gated residual adds
+ * (PixArtMS.py:58,64,74-77; PixArt_blocks.py:24-25,217-219).  shift/scale/gate point at sample 0; sample b is at
+ * ptr + b*mod_stride.  rows_per_batch = tokens per sample. x_out may alias x. */
+int pxa_ln_mod_fwd(const float* x, const void* u_bf16, const float* gate, const float* shift, const float* scale, int mod_stride,
+                   float* x_out, void* xn_bf16, void* xb_bf16, float* mean, float* rstd,
+                   int R, int D, int rows_per_batch, float eps, hipStream_t stream);
+/* dx_out = dx_in + dLN(dy*(1+scale));  dshift[b] += sum dy;  dscale[b] += sum dy*xhat  (atomic; caller zeroes). */
+int pxa_ln_mod_bwd(const void* dy_bf16, const float* x, const float* mean, const float* rstd, const float* scale, int mod_stride,
+                   const float* dx_in, float* dx_out, float* dshift, float* dscale, int dmod_stride,
+                   int R, int D, int rows_per_batch, hipStream_t stream);
+/* g = dx (+ add_bf16);  dx_out = g (optional);  du = gate*g (bf16; plain cast if gate NULL);  dgate[b] += sum g*u. */
+int pxa_gate_bwd(const float* dx, const void* add_bf16, const void* u_bf16, const float* gate, int mod_stride,
+                 float* dx_out, void* du_bf16, float* dgate, int dmod_stride, int R, int D, int rows_per_batch, hipStream_t stream);
+/* out[n] += sum_r dY[r][n]  — nn.Linear bias gradients. */
+int pxa_colsum_bf16(const void* dy_bf16, int ld, float* out, int R, int N, hipStream_t stream);
+
+/* ---------------------------------------------------------------------------------------------- attention
+ * softmax(q k^T * scale) v with head_dim 72; replaces xformers.ops.memory_efficient_attention at
+ * PixArt_blocks.py:153 (self-attention, optionally against KV-compressed tokens: Nk != Nq) and at
+ * PixArt_blocks.py:52-53 (cross-attention under BlockDiagonalMask.from_seqlens([N]*B, y_lens): pass kv_start/kv_len).
+ * All strides are in elements: *_bs batch, *_ts token, *_hs head.  With kv_start != NULL the K/V (and dK/dV) batch
+ * strides are ignored and sample b uses rows kv_start[b] .. kv_start[b]+kv_len[b] of the packed K/V.
+ * lse: [B][H][Nq] float, log2 domain (written by fwd, read by bwd).  delta: [B][H][Nq] float workspace (bwd).
+ * d_o has the layout of o. */
+typedef struct {
+  const void* q; const void* k; const void* v; void* o;
+  const void* d_o; void* dq; void* dk; void* dv;
+  float* lse; float* delta;
+  long q_bs, q_ts, k_bs, k_ts, v_bs, v_ts, o_bs, o_ts;
+  int q_hs, k_hs, v_hs, o_hs;
+  long dq_bs, dq_ts, dk_bs, dk_ts, dv_bs, dv_ts;
+  int dq_hs, dk_hs, dv_hs;
+  int B, H, Nq, Nk, head_dim;
+  const int* kv_start; const int* kv_len;  /* device int32 [B] or NULL */
+  int max_kv_len;                           /* host-known max(kv_len) for the varlen backward grid (0: use Nk) */
+  float scale;
+} pxa_attn_args;
+int pxa_attn_fwd(const pxa_attn_args* args, hipStream_t stream);
+int pxa_attn_bwd(const pxa_attn_args* args, hipStream_t stream);
+
+/* ---------------------------------------------------------------------------------------------- token boundary
+ * PatchEmbed conv (k=2,s=2) + bias + pos_embed -> fp32 tokens (PixArtMS.py:38-44,184); its weight/bias gradient;
+ * unpatchify 'nhwpqc->nchpwq' (PixArtMS.py:236-248) and the inverse permutation of the output gradient (bf16);
+ * packed caption-row gather = masked_select + CaptionEmbedder.token_drop (PixArtMS.py:196-204, PixArt_blocks.py:389-398). */
+int pxa_patch_embed_fwd(const float* x, const float* w, const float* bias, const float* pos, float* out,
+                        int B, int C, int Hl, int Wl, int D, hipStream_t stream);
+int pxa_patch_embed_bwd(const float* x, const float* dtok, float* dw, float* dbias, int B, int C, int Hl, int Wl, int D, hipStream_t stream);
+int pxa_unpatchify_fwd(const float* lin, float* img, int B, int h, int w, int Co, hipStream_t stream);
+int pxa_patchify_bwd(const float* dimg, void* dlin_bf16, int B, int h, int w, int Co, hipStream_t stream);
+int pxa_gather_rows_bf16(const float* src, const float* alt, const int* row_idx, const int* drop, void* out_bf16,
+                         int rows, int L, int Cw, hipStream_t stream);
+
+/* ---------------------------------------------------------------------------------------------- KV token compression
+ * AttentionKVCompress.downsample_2d 'conv' mode (PixArt_blocks.py:84-89,97-121): depthwise Conv2d(C,C,k=sr,s=sr) over
+ * the (H,W) token grid + affine LayerNorm(C, eps 1e-5); the same parameters process K and V.
+ * in: bf16 rows with token stride in_ts (e.g. the k / v slice of qkv), out: bf16 (B, (H/sr)*(W/sr), C). */
+int pxa_kv_compress_fwd(const void* in_bf16, long in_bs, long in_ts, const float* conv_w, const float* conv_b,
+                        const float* ln_w, const float* ln_b, void* out_bf16, int B, int H, int W, int C, int sr, float eps,
+                        hipStream_t stream);
+
+/* ---------------------------------------------------------------------------------------------- optimizer
+ * Global grad norm + clip coefficient (accelerator.clip_grad_norm_, train.py:182) and torch.optim.AdamW
+ * (configs/PixArt_xl2_internal.py:48) over flat fp32 buffers, refreshing the bf16 shadow weights in the same pass. */
+int pxa_sumsq_f32(const float* x, long n, float* out, hipStream_t stream);
+int pxa_clip_coef(const float* sumsq, float* out2, float max_norm, float inv_world, hipStream_t stream);
+int pxa_adamw_step(float* p, const float* g, float* m, float* v, void* p_bf16, long n, float lr, float beta1, float beta2,
+                   float eps, float weight_decay, int step, const float* gscale, hipStream_t stream);
+int pxa_cast_f32_bf16(const float* x, void* y_bf16, long n, hipStream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PIXART_HIP_H */

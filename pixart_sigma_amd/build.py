@@ -1,0 +1,87 @@
+"""Builds pixart_sigma_amd/libpixart_hip.so (gfx950 only) from csrc/*.hip with hipcc, in-tree.
+
+    python -m pixart_sigma_amd.build [--force] [--verbose]
+
+hipcc cross-compiles without a GPU, so this runs in the build container; the .so is git-ignored but travels to the
+GPU box with the repo snapshot.  Objects are cached per source hash under pixart_sigma_amd/csrc/.obj/.
+"""
+import argparse
+import hashlib
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(CSRC, ".obj")
+LIB = os.path.join(HERE, "libpixart_hip.so")
+INCLUDE = os.path.join(os.path.dirname(HERE), "include")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+
+
+def _hipcc():
+    for c in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
+        if c and (os.path.isabs(c) and os.path.exists(c) or not os.path.isabs(c)):
+            return c
+    raise RuntimeError("hipcc not found")
+
+
+def _digest(path):
+    h = hashlib.sha256()
+    for p in [path, os.path.join(CSRC, "common.h"), os.path.join(INCLUDE, "pixart_hip.h")]:
+        with open(p, "rb") as f:
+            h.update(f.read())
+    h.update(" ".join(FLAGS).encode())
+    return h.hexdigest()[:16]
+
+
+def build(force=False, verbose=False):
+    os.makedirs(OBJ, exist_ok=True)
+    srcs = sorted(f for f in os.listdir(CSRC) if f.endswith(".hip"))
+    hipcc = _hipcc()
+    objs, jobs = [], []
+    for s in srcs:
+        src = os.path.join(CSRC, s)
+        obj = os.path.join(OBJ, f"{s[:-4]}.{_digest(src)}.o")
+        objs.append(obj)
+        if force or not os.path.exists(obj):
+            jobs.append((src, obj))
+
+    def compile_one(job):
+        src, obj = job
+        cmd = [hipcc, *FLAGS, "-I", INCLUDE, "-c", src, "-o", obj]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"hipcc failed for {src}:\n{r.stdout}\n{r.stderr}")
+        if verbose and r.stderr.strip():
+            print(r.stderr)
+        return obj
+
+    if jobs:
+        with ThreadPoolExecutor(max_workers=min(8, len(jobs))) as ex:
+            list(ex.map(compile_one, jobs))
+    stale = not os.path.exists(LIB) or any(os.path.getmtime(o) > os.path.getmtime(LIB) for o in objs)
+    if jobs or stale or force:
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", LIB]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
+    # drop objects of older source versions
+    keep = set(objs)
+    for f in os.listdir(OBJ):
+        p = os.path.join(OBJ, f)
+        if p not in keep:
+            os.remove(p)
+    return LIB
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--force", action="store_true")
+    ap.add_argument("--verbose", action="store_true")
+    a = ap.parse_args()
+    print(build(a.force, a.verbose))
+    sys.exit(0)

@@ -1,0 +1,404 @@
+// Flash-style softmax attention, head_dim 72, bf16 MFMA, for the three attention shapes of the PixArt block:
+//   * self-attention over image tokens               (xformers.ops.memory_efficient_attention, PixArt_blocks.py:153)
+//   * self-attention against KV-compressed tokens    (N_q != N_kv, PixArt_blocks.py:137-139)
+//   * varlen cross-attention to packed text tokens   (BlockDiagonalMask.from_seqlens, PixArt_blocks.py:50-53)
+// All three are one kernel family driven by strides + optional per-sample (kv_start, kv_len).
+//
+// Structure ("swapped QK^T"): a wave owns 32 query columns. S^T = K Q^T is computed with
+// v_mfma_f32_32x32x16_bf16 (A = K rows from LDS, B = Q^T held in registers), so every lane holds scores of ONE
+// query -> softmax max/sum are in-lane plus a single lane^32 exchange, and P^T in accumulator layout is
+// directly the B operand of O^T = V^T P^T (the reduction index kv is permuted identically on both operands).
+// V^T fragments come from a row-major [kv][d] LDS tile through ds_read_b64_tr_b16.
+// head_dim 72 is zero-padded to 80 for the QK^T reduction (5 k-steps) and to 96 for the O^T rows (3 tiles).
+// Backward = delta pre-pass + dQ kernel (q-stationary) + dK/dV kernel (kv-stationary), both recomputing P
+// from the saved log2-sum-exp.
+#include "common.h"
+#include "../../include/pixart_hip.h"
+
+namespace {
+using namespace pxa;
+
+constexpr int DH = 72;
+constexpr int NCH = DH / 8;          // 9 16-byte chunks per head row
+constexpr int KSTEPS = 5;            // ceil(72/16)
+constexpr int S80 = 160;             // LDS row stride (bytes) of a [..][80] tile (b128 reads only)
+constexpr int S96 = 192;             // LDS row stride (bytes) of a [..][96] tile (b128 + transpose reads)
+constexpr int BKV = 64;
+
+struct AttnParams {
+  const bf16_t *Q, *K, *V, *dO;
+  bf16_t *O, *dQ, *dK, *dV;
+  float* LSE;          // [B][H][Nq], log2 domain: m*c + log2(l)
+  const float* Delta;  // [B][H][Nq]
+  long q_bs, q_ts, k_bs, k_ts, v_bs, v_ts, o_bs, o_ts;  // element strides (batch, token)
+  int q_hs, k_hs, v_hs, o_hs;                            // head strides
+  long dq_bs, dq_ts, dk_bs, dk_ts, dv_bs, dv_ts;
+  int dq_hs, dk_hs, dv_hs;
+  int B, H, Nq, Nk;
+  const int* kv_start; const int* kv_len;  // optional per-batch varlen (rows into the packed K/V)
+  float scale, scale_log2;
+};
+
+__device__ __forceinline__ void kv_range(const AttnParams& p, int b, long& kbase, long& vbase, long& dkbase, long& dvbase, int& len) {
+  if (p.kv_start) {
+    const long s = p.kv_start[b];
+    kbase = s * p.k_ts; vbase = s * p.v_ts; dkbase = s * p.dk_ts; dvbase = s * p.dv_ts; len = p.kv_len[b];
+  } else {
+    kbase = (long)b * p.k_bs; vbase = (long)b * p.v_bs; dkbase = (long)b * p.dk_bs; dvbase = (long)b * p.dv_bs; len = p.Nk;
+  }
+}
+
+// stage a [64][72] bf16 tile (rows row0..row0+63 of a strided matrix, zero beyond `nrows`) into LDS with row stride `ls`
+__device__ __forceinline__ void stage_tile(char* lds, int ls, const bf16_t* __restrict__ src, long ts, int row0, int nrows, int tid) {
+  for (int c = tid; c < BKV * NCH; c += 256) {
+    const int r = c / NCH, ch = c - r * NCH;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (row0 + r < nrows) v = *reinterpret_cast<const uint4*>(src + (long)(row0 + r) * ts + ch * 8);
+    *reinterpret_cast<uint4*>(lds + r * ls + ch * 16) = v;
+  }
+}
+__device__ __forceinline__ void zero_pad(char* lds, int ls, int tid) {  // chunks 9.. of every row
+  const int npad = ls / 16 - NCH;
+  for (int c = tid; c < BKV * npad; c += 256) {
+    const int r = c / npad, ch = NCH + (c - r * npad);
+    *reinterpret_cast<uint4*>(lds + r * ls + ch * 16) = make_uint4(0, 0, 0, 0);
+  }
+}
+// B-operand fragments of a row held in registers: X[row][ks*16 + 8*hi .. +8], zero for d >= 72 or invalid row
+__device__ __forceinline__ void load_row_frags(bf16x8 (&f)[KSTEPS], const bf16_t* __restrict__ rowptr, bool valid, int hi) {
+#pragma unroll
+  for (int ks = 0; ks < KSTEPS; ks++) {
+    const int d0 = ks * 16 + 8 * hi;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (valid && d0 < DH) v = *reinterpret_cast<const uint4*>(rowptr + d0);
+    f[ks] = __builtin_bit_cast(bf16x8, v);
+  }
+}
+// A-operand from a row-major tile: rows sub*32 + (lane&31), k = d
+__device__ __forceinline__ bf16x8 rowfrag(const char* lds, int ls, int sub, int ks, int lane) {
+  return *reinterpret_cast<const bf16x8*>(lds + (sub * 32 + (lane & 31)) * ls + (ks * 2 + (lane >> 5)) * 16);
+}
+// A-operand X^T[d = dt*32 + (lane&31)][k-slots of step u] from a row-major [row][d] tile (stride S96) via transpose reads.
+// slot j <-> row 16u + (j&3) + 8*(j>>2) + 4*hi : the same permutation the accumulator layout gives the B operand.
+__device__ __forceinline__ bf16x8 trfrag(const char* lds, int dt, int u, int lane) {
+  const int gg = lane >> 4, tt = lane & 15, hi = gg >> 1;
+  const int row = 16 * u + 4 * hi + (tt >> 2), col = dt * 32 + 16 * (gg & 1) + (tt & 3) * 4;
+  const char* p = lds + row * S96 + col * 2;
+  return concat_tr(lds_tr_read(p), lds_tr_read(p + 8 * S96));
+}
+__device__ __forceinline__ bf16x8 pack8(const f32x16& v, int off) {
+  bf16x8 r;
+#pragma unroll
+  for (int j = 0; j < 8; j++) r[j] = (bf16_t)v[off + j];
+  return r;
+}
+// store a transposed accumulator set X^T[d][q] (3 tiles) as bf16 rows X[q][0..71]
+__device__ __forceinline__ void store_rows(bf16_t* __restrict__ rowptr, const f32x16 (&acc)[3], float mul, int hi) {
+#pragma unroll
+  for (int dt = 0; dt < 3; dt++)
+#pragma unroll
+    for (int qd = 0; qd < 4; qd++) {
+      const int d0 = dt * 32 + 8 * qd + 4 * hi;
+      if (d0 < DH)
+        *reinterpret_cast<uint2*>(rowptr + d0) = pack_bf16x4(acc[dt][qd * 4] * mul, acc[dt][qd * 4 + 1] * mul, acc[dt][qd * 4 + 2] * mul, acc[dt][qd * 4 + 3] * mul);
+    }
+}
+__device__ __forceinline__ void zero3(f32x16 (&a)[3]) {
+#pragma unroll
+  for (int i = 0; i < 3; i++)
+#pragma unroll
+    for (int g = 0; g < 16; g++) a[i][g] = 0.f;
+}
+
+// ------------------------------------------------------------------------------------------------ forward
+__global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
+  __shared__ __attribute__((aligned(16))) char ldsK[BKV * S80];
+  __shared__ __attribute__((aligned(16))) char ldsV[BKV * S96];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hi = lane >> 5;
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int q = blockIdx.x * 128 + wave * 32 + (lane & 31);
+  const bool qvalid = q < p.Nq;
+  long kbase, vbase, d0_, d1_; int kvlen;
+  kv_range(p, b, kbase, vbase, d0_, d1_, kvlen);
+  const bf16_t* Kp = p.K + kbase + (long)h * p.k_hs;
+  const bf16_t* Vp = p.V + vbase + (long)h * p.v_hs;
+
+  bf16x8 qf[KSTEPS];
+  load_row_frags(qf, p.Q + (long)b * p.q_bs + (long)q * p.q_ts + (long)h * p.q_hs, qvalid, hi);
+  zero_pad(ldsK, S80, tid);
+  zero_pad(ldsV, S96, tid);
+
+  f32x16 o[3];
+  zero3(o);
+  float m = -INFINITY, l = 0.f;
+  const float c = p.scale_log2;
+
+  for (int kv0 = 0; kv0 < kvlen; kv0 += BKV) {
+    __syncthreads();
+    stage_tile(ldsK, S80, Kp, p.k_ts, kv0, kvlen, tid);
+    stage_tile(ldsV, S96, Vp, p.v_ts, kv0, kvlen, tid);
+    __syncthreads();
+    f32x16 s[2];
+#pragma unroll
+    for (int sub = 0; sub < 2; sub++) {
+#pragma unroll
+      for (int g = 0; g < 16; g++) s[sub][g] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < KSTEPS; ks++) s[sub] = mfma32(rowfrag(ldsK, S80, sub, ks, lane), qf[ks], s[sub]);
+    }
+    if (kv0 + BKV > kvlen) {
+#pragma unroll
+      for (int sub = 0; sub < 2; sub++)
+#pragma unroll
+        for (int g = 0; g < 16; g++)
+          if (kv0 + sub * 32 + (g & 3) + 8 * (g >> 2) + 4 * hi >= kvlen) s[sub][g] = -INFINITY;
+    }
+    float mt = s[0][0];
+#pragma unroll
+    for (int sub = 0; sub < 2; sub++)
+#pragma unroll
+      for (int g = 0; g < 16; g++) mt = fmaxf(mt, s[sub][g]);
+    mt = fmaxf(mt, __shfl_xor(mt, 32));
+    const float mn = fmaxf(m, mt);
+    const float alpha = __builtin_amdgcn_exp2f((m - mn) * c);
+    const float mc = mn * c;
+    m = mn;
+    float ps = 0.f;
+#pragma unroll
+    for (int sub = 0; sub < 2; sub++)
+#pragma unroll
+      for (int g = 0; g < 16; g++) {
+        const float e = __builtin_amdgcn_exp2f(s[sub][g] * c - mc);
+        s[sub][g] = e;
+        ps += e;
+      }
+    l = l * alpha + ps;
+#pragma unroll
+    for (int dt = 0; dt < 3; dt++)
+#pragma unroll
+      for (int g = 0; g < 16; g++) o[dt][g] *= alpha;
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const bf16x8 pb = pack8(s[u >> 1], 8 * (u & 1));
+#pragma unroll
+      for (int dt = 0; dt < 3; dt++) o[dt] = mfma32(trfrag(ldsV, dt, u, lane), pb, o[dt]);
+    }
+  }
+  l += __shfl_xor(l, 32);
+  if (qvalid) {
+    const float inv = l > 0.f ? 1.f / l : 0.f;
+    store_rows(p.O + (long)b * p.o_bs + (long)q * p.o_ts + (long)h * p.o_hs, o, inv, hi);
+    if (hi == 0 && p.LSE) p.LSE[((long)b * p.H + h) * p.Nq + q] = m * c + log2f(l);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ delta = rowsum(dO * O)
+__global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* __restrict__ O, const bf16_t* __restrict__ dO, float* __restrict__ delta,
+                                                         long o_bs, long o_ts, int o_hs, long do_bs, long do_ts, int do_hs, int B, int H, int Nq) {
+  const long idx = blockIdx.x * 256L + threadIdx.x;  // (b, q, h) with h fastest -> adjacent threads read adjacent 144-byte rows
+  if (idx >= (long)B * Nq * H) return;
+  const int h = idx % H;
+  const long t = idx / H;
+  const int q = t % Nq, b = t / Nq;
+  const bf16_t* po = O + b * o_bs + q * o_ts + (long)h * o_hs;
+  const bf16_t* pd = dO + b * do_bs + q * do_ts + (long)h * do_hs;
+  float acc = 0.f;
+#pragma unroll
+  for (int ch = 0; ch < NCH; ch++) {
+    float a[8], d[8];
+    unpack_bf16x8(*reinterpret_cast<const uint4*>(po + ch * 8), a);
+    unpack_bf16x8(*reinterpret_cast<const uint4*>(pd + ch * 8), d);
+#pragma unroll
+    for (int e = 0; e < 8; e++) acc += a[e] * d[e];
+  }
+  delta[((long)b * H + h) * Nq + q] = acc;
+}
+
+// ------------------------------------------------------------------------------------------------ backward: dQ
+__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnParams p) {
+  __shared__ __attribute__((aligned(16))) char ldsK[BKV * S96];
+  __shared__ __attribute__((aligned(16))) char ldsV[BKV * S80];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hi = lane >> 5;
+  const int b = blockIdx.z, h = blockIdx.y;
+  const int q = blockIdx.x * 128 + wave * 32 + (lane & 31);
+  const bool qvalid = q < p.Nq;
+  long kbase, vbase, d0_, d1_; int kvlen;
+  kv_range(p, b, kbase, vbase, d0_, d1_, kvlen);
+  const bf16_t* Kp = p.K + kbase + (long)h * p.k_hs;
+  const bf16_t* Vp = p.V + vbase + (long)h * p.v_hs;
+
+  bf16x8 qf[KSTEPS], dof[KSTEPS];
+  load_row_frags(qf, p.Q + (long)b * p.q_bs + (long)q * p.q_ts + (long)h * p.q_hs, qvalid, hi);
+  load_row_frags(dof, p.dO + (long)b * p.o_bs + (long)q * p.o_ts + (long)h * p.o_hs, qvalid, hi);
+  const long sidx = ((long)b * p.H + h) * p.Nq + q;
+  const float lse = qvalid ? p.LSE[sidx] : 0.f;
+  const float delta = qvalid ? p.Delta[sidx] : 0.f;
+  zero_pad(ldsK, S96, tid);
+  zero_pad(ldsV, S80, tid);
+
+  f32x16 dq[3];
+  zero3(dq);
+  const float c = p.scale_log2;
+  for (int kv0 = 0; kv0 < kvlen; kv0 += BKV) {
+    __syncthreads();
+    stage_tile(ldsK, S96, Kp, p.k_ts, kv0, kvlen, tid);
+    stage_tile(ldsV, S80, Vp, p.v_ts, kv0, kvlen, tid);
+    __syncthreads();
+    f32x16 s[2], dp[2];
+#pragma unroll
+    for (int sub = 0; sub < 2; sub++) {
+#pragma unroll
+      for (int g = 0; g < 16; g++) { s[sub][g] = 0.f; dp[sub][g] = 0.f; }
+#pragma unroll
+      for (int ks = 0; ks < KSTEPS; ks++) {
+        s[sub] = mfma32(rowfrag(ldsK, S96, sub, ks, lane), qf[ks], s[sub]);
+        dp[sub] = mfma32(rowfrag(ldsV, S80, sub, ks, lane), dof[ks], dp[sub]);
+      }
+    }
+#pragma unroll
+    for (int sub = 0; sub < 2; sub++)
+#pragma unroll
+      for (int g = 0; g < 16; g++) {
+        const bool kvok = kv0 + sub * 32 + (g & 3) + 8 * (g >> 2) + 4 * hi < kvlen;
+        const float pr = kvok ? __builtin_amdgcn_exp2f(s[sub][g] * c - lse) : 0.f;
+        s[sub][g] = pr * (dp[sub][g] - delta);  // dS^T (without the softmax scale, applied at the end)
+      }
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const bf16x8 db = pack8(s[u >> 1], 8 * (u & 1));
+#pragma unroll
+      for (int dt = 0; dt < 3; dt++) dq[dt] = mfma32(trfrag(ldsK, dt, u, lane), db, dq[dt]);
+    }
+  }
+  if (qvalid) store_rows(p.dQ + (long)b * p.dq_bs + (long)q * p.dq_ts + (long)h * p.dq_hs, dq, p.scale, hi);
+}
+
+// ------------------------------------------------------------------------------------------------ backward: dK, dV
+__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnParams p) {
+  __shared__ __attribute__((aligned(16))) char ldsQ[BKV * S96];
+  __shared__ __attribute__((aligned(16))) char ldsD[BKV * S96];
+  __shared__ __attribute__((aligned(16))) float ldsL[BKV];
+  __shared__ __attribute__((aligned(16))) float ldsDl[BKV];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hi = lane >> 5;
+  const int b = blockIdx.z, h = blockIdx.y;
+  long kbase, vbase, dkbase, dvbase; int kvlen;
+  kv_range(p, b, kbase, vbase, dkbase, dvbase, kvlen);
+  if ((int)(blockIdx.x * 128) >= kvlen) return;  // whole block beyond this sample's keys (uniform across the block)
+  const int kv = blockIdx.x * 128 + wave * 32 + (lane & 31);
+  const bool kvvalid = kv < kvlen;
+
+  bf16x8 kf[KSTEPS], vf[KSTEPS];
+  load_row_frags(kf, p.K + kbase + (long)kv * p.k_ts + (long)h * p.k_hs, kvvalid, hi);
+  load_row_frags(vf, p.V + vbase + (long)kv * p.v_ts + (long)h * p.v_hs, kvvalid, hi);
+  const bf16_t* Qp = p.Q + (long)b * p.q_bs + (long)h * p.q_hs;
+  const bf16_t* Dp = p.dO + (long)b * p.o_bs + (long)h * p.o_hs;
+  const float* Lp = p.LSE + ((long)b * p.H + h) * p.Nq;
+  const float* Dl = p.Delta + ((long)b * p.H + h) * p.Nq;
+  zero_pad(ldsQ, S96, tid);
+  zero_pad(ldsD, S96, tid);
+
+  f32x16 dk[3], dv[3];
+  zero3(dk);
+  zero3(dv);
+  const float c = p.scale_log2;
+  for (int q0 = 0; q0 < p.Nq; q0 += BKV) {
+    __syncthreads();
+    stage_tile(ldsQ, S96, Qp, p.q_ts, q0, p.Nq, tid);
+    stage_tile(ldsD, S96, Dp, p.o_ts, q0, p.Nq, tid);
+    if (tid < BKV) {
+      const bool ok = q0 + tid < p.Nq;
+      ldsL[tid] = ok ? Lp[q0 + tid] : INFINITY;   // +inf -> P = exp2(-inf) = 0 for rows beyond Nq
+      ldsDl[tid] = ok ? Dl[q0 + tid] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int sub = 0; sub < 2; sub++) {
+      f32x16 s, dp;
+#pragma unroll
+      for (int g = 0; g < 16; g++) { s[g] = 0.f; dp[g] = 0.f; }
+#pragma unroll
+      for (int ks = 0; ks < KSTEPS; ks++) {
+        s = mfma32(rowfrag(ldsQ, S96, sub, ks, lane), kf[ks], s);    // S[q][kv], col = kv (lane), rows = q
+        dp = mfma32(rowfrag(ldsD, S96, sub, ks, lane), vf[ks], dp);  // dP[q][kv]
+      }
+#pragma unroll
+      for (int qd = 0; qd < 4; qd++) {
+        const int ql = sub * 32 + 8 * qd + 4 * hi;
+        const float4 L4 = *reinterpret_cast<const float4*>(&ldsL[ql]);
+        const float4 D4 = *reinterpret_cast<const float4*>(&ldsDl[ql]);
+        const float Lv[4] = {L4.x, L4.y, L4.z, L4.w}, Dv[4] = {D4.x, D4.y, D4.z, D4.w};
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+          const float pr = __builtin_amdgcn_exp2f(s[qd * 4 + e] * c - Lv[e]);
+          s[qd * 4 + e] = pr;
+          dp[qd * 4 + e] = pr * (dp[qd * 4 + e] - Dv[e]);
+        }
+      }
+#pragma unroll
+      for (int uu = 0; uu < 2; uu++) {
+        const bf16x8 pb = pack8(s, 8 * uu), db = pack8(dp, 8 * uu);
+        const int u = sub * 2 + uu;
+#pragma unroll
+        for (int dt = 0; dt < 3; dt++) {
+          dv[dt] = mfma32(trfrag(ldsD, dt, u, lane), pb, dv[dt]);
+          dk[dt] = mfma32(trfrag(ldsQ, dt, u, lane), db, dk[dt]);
+        }
+      }
+    }
+  }
+  if (kvvalid) {
+    store_rows(p.dK + dkbase + (long)kv * p.dk_ts + (long)h * p.dk_hs, dk, p.scale, hi);
+    store_rows(p.dV + dvbase + (long)kv * p.dv_ts + (long)h * p.dv_hs, dv, 1.f, hi);
+  }
+}
+
+int fill(AttnParams& p, const pxa_attn_args* a) {
+  PXA_CHECK(a, "attn: null args");
+  PXA_CHECK(a->head_dim == DH, "attn: head_dim %d unsupported (PixArt XL/2 uses 72)", a->head_dim);
+  PXA_CHECK(a->B > 0 && a->H > 0 && a->Nq > 0 && a->Nk >= 0, "attn: bad shape");
+  PXA_CHECK(!a->kv_start == !a->kv_len, "attn: kv_start/kv_len must both be given");
+  p.Q = (const bf16_t*)a->q; p.K = (const bf16_t*)a->k; p.V = (const bf16_t*)a->v; p.dO = (const bf16_t*)a->d_o;
+  p.O = (bf16_t*)a->o; p.dQ = (bf16_t*)a->dq; p.dK = (bf16_t*)a->dk; p.dV = (bf16_t*)a->dv;
+  p.LSE = a->lse; p.Delta = a->delta;
+  p.q_bs = a->q_bs; p.q_ts = a->q_ts; p.q_hs = a->q_hs;
+  p.k_bs = a->k_bs; p.k_ts = a->k_ts; p.k_hs = a->k_hs;
+  p.v_bs = a->v_bs; p.v_ts = a->v_ts; p.v_hs = a->v_hs;
+  p.o_bs = a->o_bs; p.o_ts = a->o_ts; p.o_hs = a->o_hs;
+  p.dq_bs = a->dq_bs; p.dq_ts = a->dq_ts; p.dq_hs = a->dq_hs;
+  p.dk_bs = a->dk_bs; p.dk_ts = a->dk_ts; p.dk_hs = a->dk_hs;
+  p.dv_bs = a->dv_bs; p.dv_ts = a->dv_ts; p.dv_hs = a->dv_hs;
+  p.B = a->B; p.H = a->H; p.Nq = a->Nq; p.Nk = a->Nk;
+  p.kv_start = a->kv_start; p.kv_len = a->kv_len;
+  p.scale = a->scale; p.scale_log2 = a->scale * 1.4426950408889634f;
+  const long strides[] = {p.q_ts, p.k_ts, p.v_ts, p.o_ts, p.q_hs, p.k_hs, p.v_hs, p.o_hs, p.q_bs, p.k_bs, p.v_bs, p.o_bs};
+  for (long s : strides) PXA_CHECK(s % 8 == 0, "attn: strides must be multiples of 8 elements (16-byte rows)");
+  return 0;
+}
+}  // namespace
+
+extern "C" int pxa_attn_fwd(const pxa_attn_args* a, hipStream_t stream) {
+  AttnParams p;
+  if (int rc = fill(p, a)) return rc;
+  PXA_CHECK(p.Q && p.K && p.V && p.O, "pxa_attn_fwd: null tensor");
+  hipLaunchKernelGGL(attn_fwd_kernel, dim3((p.Nq + 127) / 128, p.H, p.B), dim3(256), 0, stream, p);
+  PXA_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int pxa_attn_bwd(const pxa_attn_args* a, hipStream_t stream) {
+  AttnParams p;
+  if (int rc = fill(p, a)) return rc;
+  PXA_CHECK(p.Q && p.K && p.V && p.O && p.dO && p.dQ && p.dK && p.dV && p.LSE && a->delta, "pxa_attn_bwd: null tensor");
+  for (long s : {p.dq_ts, p.dk_ts, p.dv_ts, (long)p.dq_hs, (long)p.dk_hs, (long)p.dv_hs, p.dq_bs, p.dk_bs, p.dv_bs})
+    PXA_CHECK(s % 4 == 0, "pxa_attn_bwd: gradient strides must be multiples of 4 elements");
+  const long total = (long)p.B * p.Nq * p.H;
+  hipLaunchKernelGGL(attn_delta_kernel, dim3((total + 255) / 256), dim3(256), 0, stream, p.O, p.dO, a->delta,
+                     p.o_bs, p.o_ts, p.o_hs, p.o_bs, p.o_ts, p.o_hs, p.B, p.H, p.Nq);
+  PXA_LAUNCH_CHECK();
+  hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3((p.Nq + 127) / 128, p.H, p.B), dim3(256), 0, stream, p);
+  PXA_LAUNCH_CHECK();
+  const int max_k = a->max_kv_len > 0 ? a->max_kv_len : p.Nk;
+  hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3((max_k + 127) / 128, p.H, p.B), dim3(256), 0, stream, p);
+  PXA_LAUNCH_CHECK();
+  return 0;
+}

@@ -1,0 +1,86 @@
+// Shared device helpers for the gfx950 (CDNA4, wave64) kernels of the PixArt-Sigma denoiser path.
+// Lane layouts used here were verified on MI355X by probe/probe.hip (see DESIGN.md "Verified hardware semantics"):
+//   v_mfma_f32_32x32x16_bf16:  A[i=l&31][k=8*(l>>5)+j], B[k=8*(l>>5)+j][n=l&31], j=0..7;
+//                              C: col = l&31, row = (g&3) + 8*(g>>2) + 4*(l>>5), g = 0..15
+//   ds_read_b64_tr_b16:        inside each 16-lane group, result lane t elem j = (source lane 4j + (t>>2)) elem (t&3)
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef __bf16 bf16_t;
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define PXA_WAVE 64
+#define LDS_PTR(T, p) ((__attribute__((address_space(3))) T*)(p))
+
+namespace pxa {
+
+__device__ __forceinline__ float bf2f(bf16_t v) { return (float)v; }
+__device__ __forceinline__ bf16_t f2bf(float v) { return (bf16_t)v; }  // RNE (v_cvt_pk_bf16_f32)
+
+__device__ __forceinline__ uint32_t pack_bf16x2(float a, float b) {
+  bf16x2 v; v[0] = (bf16_t)a; v[1] = (bf16_t)b;
+  return __builtin_bit_cast(uint32_t, v);
+}
+__device__ __forceinline__ uint2 pack_bf16x4(float a, float b, float c, float d) {
+  return make_uint2(pack_bf16x2(a, b), pack_bf16x2(c, d));
+}
+__device__ __forceinline__ void unpack_bf16x2(uint32_t u, float& a, float& b) {
+  a = __builtin_bit_cast(float, u << 16);
+  b = __builtin_bit_cast(float, u & 0xffff0000u);
+}
+__device__ __forceinline__ void unpack_bf16x8(const uint4& u, float (&f)[8]) {
+  unpack_bf16x2(u.x, f[0], f[1]); unpack_bf16x2(u.y, f[2], f[3]);
+  unpack_bf16x2(u.z, f[4], f[5]); unpack_bf16x2(u.w, f[6], f[7]);
+}
+
+// LDS transpose read: 4 bf16 (see layout note above). `p` must be 8-byte aligned.
+__device__ __forceinline__ s16x4 lds_tr_read(const char* p) {
+  return __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, p));
+}
+__device__ __forceinline__ bf16x8 concat_tr(s16x4 lo, s16x4 hi) {
+  typedef short s16x8 __attribute__((ext_vector_type(8)));
+  s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+  return __builtin_bit_cast(bf16x8, v);
+}
+
+__device__ __forceinline__ f32x16 mfma32(bf16x8 a, bf16x8 b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+
+// GELU(approximate="tanh") and its derivative (reference: nn.GELU(approximate="tanh"), PixArtMS.py:66)
+__device__ __forceinline__ float tanh_fast(float u) {
+  // tanh(u) = 1 - 2/(1+exp(2u)); exact limits at +-inf
+  float e = __expf(2.0f * u);
+  return 1.0f - 2.0f / (1.0f + e);
+}
+__device__ __forceinline__ float gelu_tanh(float x) {
+  const float k0 = 0.7978845608028654f, k1 = 0.044715f;
+  float u = k0 * (x + k1 * x * x * x);
+  return 0.5f * x * (1.0f + tanh_fast(u));
+}
+__device__ __forceinline__ float gelu_tanh_grad(float x) {
+  const float k0 = 0.7978845608028654f, k1 = 0.044715f;
+  float x2 = x * x;
+  float u = k0 * (x + k1 * x * x2);
+  float t = tanh_fast(u);
+  return 0.5f * (1.0f + t) + 0.5f * x * (1.0f - t * t) * k0 * (1.0f + 3.0f * k1 * x2);
+}
+
+__device__ __forceinline__ float half_wave_sum(float v) {  // reduce inside each 32-lane half
+  v += __shfl_xor(v, 16); v += __shfl_xor(v, 8); v += __shfl_xor(v, 4); v += __shfl_xor(v, 2); v += __shfl_xor(v, 1);
+  return v;
+}
+__device__ __forceinline__ float wave_sum(float v) { v = half_wave_sum(v); return v + __shfl_xor(v, 32); }
+
+}  // namespace pxa
+
+// thread-local last-error string for the C ABI (api.hip)
+void pxa_set_error(const char* fmt, ...);
+#define PXA_CHECK(cond, ...) do { if (!(cond)) { pxa_set_error(__VA_ARGS__); return -1; } } while (0)
+#define PXA_LAUNCH_CHECK() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) { pxa_set_error("%s:%d launch failed: %s", __FILE__, __LINE__, hipGetErrorString(e_)); return -2; } } while (0)

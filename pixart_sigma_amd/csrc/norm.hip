@@ -1,0 +1,264 @@
+// HBM-bound row kernels of the adaLN-single block (PixArtMS.py:71-79, PixArt_blocks.py:24-25):
+//   ln_mod_fwd : x' = x (+ gate*u) ; xn = LayerNorm_noaffine(x', eps) * (1+scale) + shift   [fused residual + LN + modulate]
+//   ln_mod_bwd : dx = dx_in + LN^T( dy*(1+scale) ) ; dshift += sum_rows dy ; dscale += sum_rows dy*xhat
+//   gate_bwd   : g = dx (+ add) ; du = gate*g ; dgate += sum_rows g*u
+//   colsum     : bias gradients  db[n] += sum_rows dY[r][n]
+// One 32-lane half-wave owns a row: D/128 float4 per lane, 512-byte coalesced segments, fp32 statistics
+// (two-pass mean / centered variance in registers), one HBM pass per tensor.
+#include "common.h"
+#include "../../include/pixart_hip.h"
+
+namespace {
+using namespace pxa;
+
+template <int NV>
+__global__ __launch_bounds__(256) void ln_mod_fwd_kernel(
+    const float* x, const bf16_t* __restrict__ u, const float* __restrict__ gate,
+    const float* __restrict__ shift, const float* __restrict__ scale, int mod_stride,
+    float* x_out, bf16_t* __restrict__ xn, bf16_t* __restrict__ xb,
+    float* __restrict__ mean_out, float* __restrict__ rstd_out, int R, int D, int rows_per_batch, float eps) {
+  const int hl = threadIdx.x & 31;
+  const int row = blockIdx.x * 8 + (threadIdx.x >> 5);
+  if (row >= R) return;
+  const int b = row / rows_per_batch;
+  const size_t base = (size_t)row * D;
+  float4 v[NV];
+#pragma unroll
+  for (int j = 0; j < NV; j++) v[j] = *reinterpret_cast<const float4*>(x + base + (hl + 32 * j) * 4);
+  if (u) {
+#pragma unroll
+    for (int j = 0; j < NV; j++) {
+      const int c = (hl + 32 * j) * 4;
+      const uint2 uu = *reinterpret_cast<const uint2*>(u + base + c);
+      float u0, u1, u2, u3;
+      unpack_bf16x2(uu.x, u0, u1); unpack_bf16x2(uu.y, u2, u3);
+      if (gate) {
+        const float4 g = *reinterpret_cast<const float4*>(gate + (size_t)b * mod_stride + c);
+        v[j].x += g.x * u0; v[j].y += g.y * u1; v[j].z += g.z * u2; v[j].w += g.w * u3;
+      } else {
+        v[j].x += u0; v[j].y += u1; v[j].z += u2; v[j].w += u3;
+      }
+    }
+  }
+  if (x_out) {
+#pragma unroll
+    for (int j = 0; j < NV; j++) *reinterpret_cast<float4*>(x_out + base + (hl + 32 * j) * 4) = v[j];
+  }
+  if (xb) {
+#pragma unroll
+    for (int j = 0; j < NV; j++) *reinterpret_cast<uint2*>(xb + base + (hl + 32 * j) * 4) = pack_bf16x4(v[j].x, v[j].y, v[j].z, v[j].w);
+  }
+  if (!xn) return;
+  float s = 0.f;
+#pragma unroll
+  for (int j = 0; j < NV; j++) s += (v[j].x + v[j].y) + (v[j].z + v[j].w);
+  const float mean = half_wave_sum(s) / D;
+  float q = 0.f;
+#pragma unroll
+  for (int j = 0; j < NV; j++) {
+    float a = v[j].x - mean, bb = v[j].y - mean, c = v[j].z - mean, d = v[j].w - mean;
+    q += (a * a + bb * bb) + (c * c + d * d);
+  }
+  const float rstd = rsqrtf(half_wave_sum(q) / D + eps);
+  if (mean_out && hl == 0) { mean_out[row] = mean; rstd_out[row] = rstd; }
+#pragma unroll
+  for (int j = 0; j < NV; j++) {
+    const int c = (hl + 32 * j) * 4;
+    const float4 sh = *reinterpret_cast<const float4*>(shift + (size_t)b * mod_stride + c);
+    const float4 sc = *reinterpret_cast<const float4*>(scale + (size_t)b * mod_stride + c);
+    float y0 = (v[j].x - mean) * rstd * (1.f + sc.x) + sh.x;
+    float y1 = (v[j].y - mean) * rstd * (1.f + sc.y) + sh.y;
+    float y2 = (v[j].z - mean) * rstd * (1.f + sc.z) + sh.z;
+    float y3 = (v[j].w - mean) * rstd * (1.f + sc.w) + sh.w;
+    *reinterpret_cast<uint2*>(xn + base + c) = pack_bf16x4(y0, y1, y2, y3);
+  }
+}
+
+constexpr int BWD_ROWS = 16;  // rows per half-wave in the reducing backward kernels
+
+template <int NV>
+__global__ __launch_bounds__(256) void ln_mod_bwd_kernel(
+    const bf16_t* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ rstd,
+    const float* __restrict__ scale, int mod_stride, const float* dx_in, float* dx_out,
+    float* __restrict__ dshift, float* __restrict__ dscale, int dmod_stride, int R, int D, int rows_per_batch) {
+  const int hl = threadIdx.x & 31;
+  const int chunk = blockIdx.x * 8 + (threadIdx.x >> 5);
+  const int r_beg = chunk * BWD_ROWS, r_end = min(R, r_beg + BWD_ROWS);
+  if (r_beg >= R) return;
+  float4 ash[NV], asc[NV];
+#pragma unroll
+  for (int j = 0; j < NV; j++) { ash[j] = make_float4(0, 0, 0, 0); asc[j] = make_float4(0, 0, 0, 0); }
+  int cur_b = r_beg / rows_per_batch;
+  auto flush = [&](int b) {
+#pragma unroll
+    for (int j = 0; j < NV; j++) {
+      const int c = (hl + 32 * j) * 4;
+      float* ps = dshift + (size_t)b * dmod_stride + c;
+      float* pc = dscale + (size_t)b * dmod_stride + c;
+      atomicAdd(ps + 0, ash[j].x); atomicAdd(ps + 1, ash[j].y); atomicAdd(ps + 2, ash[j].z); atomicAdd(ps + 3, ash[j].w);
+      atomicAdd(pc + 0, asc[j].x); atomicAdd(pc + 1, asc[j].y); atomicAdd(pc + 2, asc[j].z); atomicAdd(pc + 3, asc[j].w);
+      ash[j] = make_float4(0, 0, 0, 0); asc[j] = make_float4(0, 0, 0, 0);
+    }
+  };
+  for (int row = r_beg; row < r_end; row++) {
+    const int b = row / rows_per_batch;
+    if (b != cur_b) { flush(cur_b); cur_b = b; }
+    const size_t base = (size_t)row * D;
+    const float mu = mean[row], rs = rstd[row];
+    float4 g[NV], xh[NV];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < NV; j++) {
+      const int c = (hl + 32 * j) * 4;
+      const uint2 dd = *reinterpret_cast<const uint2*>(dy + base + c);
+      const float4 xv = *reinterpret_cast<const float4*>(x + base + c);
+      const float4 sc = *reinterpret_cast<const float4*>(scale + (size_t)b * mod_stride + c);
+      float d0, d1, d2, d3;
+      unpack_bf16x2(dd.x, d0, d1); unpack_bf16x2(dd.y, d2, d3);
+      xh[j] = make_float4((xv.x - mu) * rs, (xv.y - mu) * rs, (xv.z - mu) * rs, (xv.w - mu) * rs);
+      ash[j].x += d0; ash[j].y += d1; ash[j].z += d2; ash[j].w += d3;
+      asc[j].x += d0 * xh[j].x; asc[j].y += d1 * xh[j].y; asc[j].z += d2 * xh[j].z; asc[j].w += d3 * xh[j].w;
+      g[j] = make_float4(d0 * (1.f + sc.x), d1 * (1.f + sc.y), d2 * (1.f + sc.z), d3 * (1.f + sc.w));
+      s1 += (g[j].x + g[j].y) + (g[j].z + g[j].w);
+      s2 += (g[j].x * xh[j].x + g[j].y * xh[j].y) + (g[j].z * xh[j].z + g[j].w * xh[j].w);
+    }
+    const float c1 = half_wave_sum(s1) / D, c2 = half_wave_sum(s2) / D;
+#pragma unroll
+    for (int j = 0; j < NV; j++) {
+      const int c = (hl + 32 * j) * 4;
+      float4 o = make_float4(rs * (g[j].x - c1 - xh[j].x * c2), rs * (g[j].y - c1 - xh[j].y * c2),
+                             rs * (g[j].z - c1 - xh[j].z * c2), rs * (g[j].w - c1 - xh[j].w * c2));
+      if (dx_in) {
+        const float4 di = *reinterpret_cast<const float4*>(dx_in + base + c);
+        o.x += di.x; o.y += di.y; o.z += di.z; o.w += di.w;
+      }
+      *reinterpret_cast<float4*>(dx_out + base + c) = o;
+    }
+  }
+  flush(cur_b);
+}
+
+template <int NV>
+__global__ __launch_bounds__(256) void gate_bwd_kernel(
+    const float* dx, const bf16_t* __restrict__ add, const bf16_t* __restrict__ u, const float* __restrict__ gate,
+    int mod_stride, float* dx_out, bf16_t* __restrict__ du, float* __restrict__ dgate, int dmod_stride,
+    int R, int D, int rows_per_batch) {
+  const int hl = threadIdx.x & 31;
+  const int chunk = blockIdx.x * 8 + (threadIdx.x >> 5);
+  const int r_beg = chunk * BWD_ROWS, r_end = min(R, r_beg + BWD_ROWS);
+  if (r_beg >= R) return;
+  float4 ag[NV];
+#pragma unroll
+  for (int j = 0; j < NV; j++) ag[j] = make_float4(0, 0, 0, 0);
+  int cur_b = r_beg / rows_per_batch;
+  auto flush = [&](int b) {
+    if (!dgate) return;
+#pragma unroll
+    for (int j = 0; j < NV; j++) {
+      float* pg = dgate + (size_t)b * dmod_stride + (hl + 32 * j) * 4;
+      atomicAdd(pg + 0, ag[j].x); atomicAdd(pg + 1, ag[j].y); atomicAdd(pg + 2, ag[j].z); atomicAdd(pg + 3, ag[j].w);
+      ag[j] = make_float4(0, 0, 0, 0);
+    }
+  };
+  for (int row = r_beg; row < r_end; row++) {
+    const int b = row / rows_per_batch;
+    if (b != cur_b) { flush(cur_b); cur_b = b; }
+    const size_t base = (size_t)row * D;
+#pragma unroll
+    for (int j = 0; j < NV; j++) {
+      const int c = (hl + 32 * j) * 4;
+      float4 g = *reinterpret_cast<const float4*>(dx + base + c);
+      if (add) {
+        const uint2 aa = *reinterpret_cast<const uint2*>(add + base + c);
+        float a0, a1, a2, a3;
+        unpack_bf16x2(aa.x, a0, a1); unpack_bf16x2(aa.y, a2, a3);
+        g.x += a0; g.y += a1; g.z += a2; g.w += a3;
+      }
+      if (dx_out) *reinterpret_cast<float4*>(dx_out + base + c) = g;
+      float4 o = g;
+      if (gate) {
+        const float4 gt = *reinterpret_cast<const float4*>(gate + (size_t)b * mod_stride + c);
+        const uint2 uu = *reinterpret_cast<const uint2*>(u + base + c);
+        float u0, u1, u2, u3;
+        unpack_bf16x2(uu.x, u0, u1); unpack_bf16x2(uu.y, u2, u3);
+        ag[j].x += g.x * u0; ag[j].y += g.y * u1; ag[j].z += g.z * u2; ag[j].w += g.w * u3;
+        o = make_float4(g.x * gt.x, g.y * gt.y, g.z * gt.z, g.w * gt.w);
+      }
+      if (du) *reinterpret_cast<uint2*>(du + base + c) = pack_bf16x4(o.x, o.y, o.z, o.w);
+    }
+  }
+  flush(cur_b);
+}
+
+// db[n] += sum_r dY[r][n];  thread = 8 columns (16-byte loads), block = 128 threads x ROWS rows
+constexpr int CS_ROWS = 256;
+__global__ __launch_bounds__(128) void colsum_kernel(const bf16_t* __restrict__ dy, int ld, float* __restrict__ out, int R, int N) {
+  const int c = (blockIdx.x * 128 + threadIdx.x) * 8;
+  if (c >= N) return;
+  const int r0 = blockIdx.y * CS_ROWS, r1 = min(R, r0 + CS_ROWS);
+  float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  for (int r = r0; r < r1; r++) {
+    const uint4 v = *reinterpret_cast<const uint4*>(dy + (size_t)r * ld + c);
+    float f[8];
+    unpack_bf16x8(v, f);
+#pragma unroll
+    for (int e = 0; e < 8; e++) acc[e] += f[e];
+  }
+#pragma unroll
+  for (int e = 0; e < 8; e++) atomicAdd(out + c + e, acc[e]);
+}
+
+#define DISPATCH_NV(D, CALL)                                            \
+  switch ((D) / 128) {                                                  \
+    case 9: { constexpr int NV = 9; CALL; } break;                      \
+    case 8: { constexpr int NV = 8; CALL; } break;                      \
+    case 4: { constexpr int NV = 4; CALL; } break;                      \
+    case 2: { constexpr int NV = 2; CALL; } break;                      \
+    case 1: { constexpr int NV = 1; CALL; } break;                      \
+    default: pxa_set_error("unsupported hidden size %d (supported: 128,256,512,1024,1152)", (D)); return -1; \
+  }
+}  // namespace
+
+extern "C" int pxa_ln_mod_fwd(const float* x, const void* u_bf16, const float* gate, const float* shift, const float* scale,
+                              int mod_stride, float* x_out, void* xn_bf16, void* xb_bf16, float* mean, float* rstd,
+                              int R, int D, int rows_per_batch, float eps, hipStream_t stream) {
+  PXA_CHECK(x && R > 0 && D % 128 == 0 && rows_per_batch > 0, "pxa_ln_mod_fwd: bad args");
+  PXA_CHECK(!xn_bf16 || (shift && scale), "pxa_ln_mod_fwd: LN output needs shift/scale");
+  PXA_CHECK(!mean == !rstd, "pxa_ln_mod_fwd: mean/rstd must both be given or both null");
+  DISPATCH_NV(D, hipLaunchKernelGGL(ln_mod_fwd_kernel<NV>, dim3((R + 7) / 8), dim3(256), 0, stream, x, (const bf16_t*)u_bf16, gate, shift, scale,
+                                     mod_stride, x_out, (bf16_t*)xn_bf16, (bf16_t*)xb_bf16, mean, rstd, R, D, rows_per_batch, eps));
+  PXA_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int pxa_ln_mod_bwd(const void* dy_bf16, const float* x, const float* mean, const float* rstd, const float* scale,
+                              int mod_stride, const float* dx_in, float* dx_out, float* dshift, float* dscale, int dmod_stride,
+                              int R, int D, int rows_per_batch, hipStream_t stream) {
+  PXA_CHECK(dy_bf16 && x && mean && rstd && scale && dx_out && dshift && dscale, "pxa_ln_mod_bwd: null pointer");
+  PXA_CHECK(R > 0 && D % 128 == 0 && rows_per_batch > 0, "pxa_ln_mod_bwd: bad shape");
+  const int chunks = (R + BWD_ROWS - 1) / BWD_ROWS;
+  DISPATCH_NV(D, hipLaunchKernelGGL(ln_mod_bwd_kernel<NV>, dim3((chunks + 7) / 8), dim3(256), 0, stream, (const bf16_t*)dy_bf16, x, mean, rstd,
+                                     scale, mod_stride, dx_in, dx_out, dshift, dscale, dmod_stride, R, D, rows_per_batch));
+  PXA_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int pxa_gate_bwd(const float* dx, const void* add_bf16, const void* u_bf16, const float* gate, int mod_stride,
+                            float* dx_out, void* du_bf16, float* dgate, int dmod_stride, int R, int D, int rows_per_batch,
+                            hipStream_t stream) {
+  PXA_CHECK(dx && R > 0 && D % 128 == 0 && rows_per_batch > 0, "pxa_gate_bwd: bad args");
+  PXA_CHECK(!gate || (u_bf16 && dgate), "pxa_gate_bwd: gate needs u and dgate");
+  const int chunks = (R + BWD_ROWS - 1) / BWD_ROWS;
+  DISPATCH_NV(D, hipLaunchKernelGGL(gate_bwd_kernel<NV>, dim3((chunks + 7) / 8), dim3(256), 0, stream, dx, (const bf16_t*)add_bf16,
+                                     (const bf16_t*)u_bf16, gate, mod_stride, dx_out, (bf16_t*)du_bf16, dgate, dmod_stride, R, D, rows_per_batch));
+  PXA_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int pxa_colsum_bf16(const void* dy_bf16, int ld, float* out, int R, int N, hipStream_t stream) {
+  PXA_CHECK(dy_bf16 && out && R > 0 && N % 8 == 0 && ld % 8 == 0, "pxa_colsum_bf16: bad args");
+  dim3 grid((N / 8 + 127) / 128, (R + CS_ROWS - 1) / CS_ROWS);
+  hipLaunchKernelGGL(colsum_kernel, grid, dim3(128), 0, stream, (const bf16_t*)dy_bf16, ld, out, R, N);
+  PXA_LAUNCH_CHECK();
+  return 0;
+}

@@ -1,0 +1,106 @@
+"""ctypes binding of libpixart_hip.so (include/pixart_hip.h).  Python-side mirror of the C ABI: tensors are passed as
+raw device pointers + sizes + the current HIP stream; nothing here computes.  The product path FAILS LOUDLY if the
+library is missing or a call returns an error — there is no CPU / eager-PyTorch fallback."""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libpixart_hip.so")
+ABI_VERSION = 1
+
+c_void_p, c_int, c_long, c_float = C.c_void_p, C.c_int, C.c_long, C.c_float
+
+
+class GemmArgs(C.Structure):
+    _fields_ = [("A", c_void_p), ("B", c_void_p), ("lda", c_int), ("ldb", c_int),
+                ("M", c_int), ("N", c_int), ("K", c_int), ("layout", c_int),
+                ("bias", c_void_p), ("act", c_int), ("aux", c_void_p), ("ldaux", c_int),
+                ("out_bf16", c_void_p), ("out2_bf16", c_void_p), ("ld_out", c_int),
+                ("out_f32", c_void_p), ("ld_f32", c_int), ("accumulate", c_int), ("split_k", c_int)]
+
+
+class AttnArgs(C.Structure):
+    _fields_ = [("q", c_void_p), ("k", c_void_p), ("v", c_void_p), ("o", c_void_p),
+                ("d_o", c_void_p), ("dq", c_void_p), ("dk", c_void_p), ("dv", c_void_p),
+                ("lse", c_void_p), ("delta", c_void_p),
+                ("q_bs", c_long), ("q_ts", c_long), ("k_bs", c_long), ("k_ts", c_long),
+                ("v_bs", c_long), ("v_ts", c_long), ("o_bs", c_long), ("o_ts", c_long),
+                ("q_hs", c_int), ("k_hs", c_int), ("v_hs", c_int), ("o_hs", c_int),
+                ("dq_bs", c_long), ("dq_ts", c_long), ("dk_bs", c_long), ("dk_ts", c_long), ("dv_bs", c_long), ("dv_ts", c_long),
+                ("dq_hs", c_int), ("dk_hs", c_int), ("dv_hs", c_int),
+                ("B", c_int), ("H", c_int), ("Nq", c_int), ("Nk", c_int), ("head_dim", c_int),
+                ("kv_start", c_void_p), ("kv_len", c_void_p), ("max_kv_len", c_int), ("scale", c_float)]
+
+
+# name -> argtypes (all return int); must list every symbol include/pixart_hip.h declares
+_P, _I, _L, _F = c_void_p, c_int, c_long, c_float
+SIGNATURES = {
+    "pxa_gemm": [C.POINTER(GemmArgs), _P],
+    "pxa_ln_mod_fwd": [_P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _F, _P],
+    "pxa_ln_mod_bwd": [_P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _P],
+    "pxa_gate_bwd": [_P, _P, _P, _P, _I, _P, _P, _P, _I, _I, _I, _I, _P],
+    "pxa_colsum_bf16": [_P, _I, _P, _I, _I, _P],
+    "pxa_attn_fwd": [C.POINTER(AttnArgs), _P],
+    "pxa_attn_bwd": [C.POINTER(AttnArgs), _P],
+    "pxa_patch_embed_fwd": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "pxa_patch_embed_bwd": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P],
+    "pxa_unpatchify_fwd": [_P, _P, _I, _I, _I, _I, _P],
+    "pxa_patchify_bwd": [_P, _P, _I, _I, _I, _I, _P],
+    "pxa_gather_rows_bf16": [_P, _P, _P, _P, _P, _I, _I, _I, _P],
+    "pxa_kv_compress_fwd": [_P, _L, _L, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _P],
+    "pxa_sumsq_f32": [_P, _L, _P, _P],
+    "pxa_clip_coef": [_P, _P, _F, _F, _P],
+    "pxa_adamw_step": [_P, _P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _I, _P, _P],
+    "pxa_cast_f32_bf16": [_P, _P, _L, _P],
+}
+OTHER_SYMBOLS = ["pxa_last_error", "pxa_abi_version", "pxa_device_info"]
+
+_lib = None
+
+
+class PixartHipError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the shared library once; raises if it has not been built (python -m pixart_sigma_amd.build)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise PixartHipError(f"{LIB_PATH} is missing: build it with `python -m pixart_sigma_amd.build` "
+                             "(the PixArt-Sigma HIP path has no CPU/PyTorch fallback)")
+    lib = C.CDLL(LIB_PATH)
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.argtypes, fn.restype = argtypes, c_int
+    lib.pxa_last_error.restype = C.c_char_p
+    lib.pxa_abi_version.restype = c_int
+    lib.pxa_device_info.argtypes, lib.pxa_device_info.restype = [C.POINTER(c_int), C.POINTER(c_int)], c_int
+    if lib.pxa_abi_version() != ABI_VERSION:
+        raise PixartHipError(f"ABI mismatch: library {lib.pxa_abi_version()} vs binding {ABI_VERSION}")
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        raise PixartHipError(f"{what} failed (rc={rc}): {load().pxa_last_error().decode()}")
+
+
+def stream():
+    return c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL)."""
+    if t is None:
+        return None
+    assert t.is_cuda, "pixart_sigma_amd ops need tensors on the MI355X (no CPU fallback)"
+    return c_void_p(t.data_ptr())
+
+
+def call(name, *args):
+    check(getattr(load(), name)(*args, stream()), name)

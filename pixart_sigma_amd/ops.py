@@ -1,0 +1,188 @@
+"""Tensor-level wrappers over the C ABI (pixart_sigma_amd/lib.py).  Each function validates shapes/dtypes, allocates
+outputs with torch (device memory + stream plumbing only) and launches exactly one libpixart_hip.so entry point.
+No math happens in Python."""
+import math
+
+import torch
+
+from . import lib
+from .lib import AttnArgs, GemmArgs, call, ptr
+
+BF16, F32 = torch.bfloat16, torch.float32
+NT, NN, TN = 0, 1, 2
+ACT_NONE, ACT_GELU, ACT_GELU_GRAD = 0, 1, 2
+
+
+def _chk(t, dtype, name):
+    assert t.is_cuda and t.dtype == dtype and t.stride(-1) == 1, f"{name}: need contiguous-last-dim {dtype} CUDA tensor"
+
+
+def gemm(a, b, layout=NT, bias=None, act=ACT_NONE, aux=None, out=None, out2=None, out_f32=None, accumulate=False,
+         split_k=1, out_dtype=BF16):
+    """C = op(A) op(B) (see include/pixart_hip.h).  a, b: 2-D bf16 (row stride arbitrary multiple of 8).
+    Returns the bf16 output (or fp32 when out_dtype is float32 / out_f32 is given)."""
+    _chk(a, BF16, "A")
+    _chk(b, BF16, "B")
+    if layout == NT:
+        M, K = a.shape
+        N, K2 = b.shape
+    elif layout == NN:
+        M, K = a.shape
+        K2, N = b.shape
+    else:
+        K, M = a.shape
+        K2, N = b.shape
+    assert K == K2, f"gemm: K mismatch {K} vs {K2}"
+    g = GemmArgs()
+    g.A, g.B, g.lda, g.ldb = ptr(a), ptr(b), a.stride(0), b.stride(0)
+    g.M, g.N, g.K, g.layout = M, N, K, layout
+    if bias is not None:
+        _chk(bias, F32, "bias")
+        assert bias.numel() == N
+    g.bias, g.act = ptr(bias), act
+    if act == ACT_GELU_GRAD:
+        _chk(aux, BF16, "aux")
+        g.aux, g.ldaux = ptr(aux), aux.stride(0)
+    want_f32 = out_f32 is not None or out_dtype == F32
+    if want_f32:
+        if out_f32 is None:
+            out_f32 = torch.empty((M, N), dtype=F32, device=a.device)
+        _chk(out_f32, F32, "out_f32")
+        g.out_f32, g.ld_f32 = ptr(out_f32), out_f32.stride(0)
+    else:
+        if out is None:
+            out = torch.empty((M, N), dtype=BF16, device=a.device)
+    if out is not None:
+        _chk(out, BF16, "out")
+        g.out_bf16, g.ld_out = ptr(out), out.stride(0)
+    if out2 is not None:
+        _chk(out2, BF16, "out2")
+        assert out is not None and out2.stride(0) == out.stride(0)
+        g.out2_bf16 = ptr(out2)
+    g.accumulate, g.split_k = int(accumulate), split_k
+    call("pxa_gemm", g)
+    return out_f32 if want_f32 else out
+
+
+def ln_mod_fwd(x, shift=None, scale=None, mod_stride=0, u=None, gate=None, x_out=None, want_xn=True, want_xb=False,
+               want_stats=False, rows_per_batch=None, eps=1e-6):
+    """x' = x + gate*u; xn = LN(x')*(1+scale)+shift.  x: (R,D) fp32.  shift/scale/gate: fp32 views whose sample b
+    starts at data_ptr + b*mod_stride floats.  Returns dict(x, xn, xb, mean, rstd)."""
+    _chk(x, F32, "x")
+    R, D = x.shape
+    rpb = rows_per_batch or R
+    xn = torch.empty((R, D), dtype=BF16, device=x.device) if want_xn else None
+    xb = torch.empty((R, D), dtype=BF16, device=x.device) if want_xb else None
+    mean = torch.empty(R, dtype=F32, device=x.device) if want_stats else None
+    rstd = torch.empty(R, dtype=F32, device=x.device) if want_stats else None
+    if u is not None and x_out is None:
+        x_out = torch.empty_like(x)
+    call("pxa_ln_mod_fwd", ptr(x), ptr(u), ptr(gate), ptr(shift), ptr(scale), mod_stride, ptr(x_out), ptr(xn), ptr(xb),
+         ptr(mean), ptr(rstd), R, D, rpb, eps)
+    return {"x": x_out if x_out is not None else x, "xn": xn, "xb": xb, "mean": mean, "rstd": rstd}
+
+
+def ln_mod_bwd(dy, x, mean, rstd, scale, mod_stride, dx_in, dx_out, dshift, dscale, dmod_stride, rows_per_batch):
+    R, D = x.shape
+    call("pxa_ln_mod_bwd", ptr(dy), ptr(x), ptr(mean), ptr(rstd), ptr(scale), mod_stride, ptr(dx_in), ptr(dx_out),
+         ptr(dshift), ptr(dscale), dmod_stride, R, D, rows_per_batch)
+    return dx_out
+
+
+def gate_bwd(dx, add=None, u=None, gate=None, mod_stride=0, dx_out=None, du=None, dgate=None, dmod_stride=0, rows_per_batch=None):
+    R, D = dx.shape
+    call("pxa_gate_bwd", ptr(dx), ptr(add), ptr(u), ptr(gate), mod_stride, ptr(dx_out), ptr(du), ptr(dgate), dmod_stride,
+         R, D, rows_per_batch or R)
+
+
+def colsum(dy, out):
+    """out[n] += sum_r dy[r][n]  (bf16 in, fp32 accumulate)."""
+    R, N = dy.shape
+    call("pxa_colsum_bf16", ptr(dy), dy.stride(0), ptr(out), R, N)
+    return out
+
+
+def _attn_args(q, k, v, o, B, H, Nq, Nk, strides, kv_start=None, kv_len=None, max_kv_len=0, scale=None, head_dim=72):
+    a = AttnArgs()
+    a.q, a.k, a.v, a.o = ptr(q), ptr(k), ptr(v), ptr(o)
+    (a.q_bs, a.q_ts, a.q_hs), (a.k_bs, a.k_ts, a.k_hs), (a.v_bs, a.v_ts, a.v_hs), (a.o_bs, a.o_ts, a.o_hs) = strides
+    a.B, a.H, a.Nq, a.Nk, a.head_dim = B, H, Nq, Nk, head_dim
+    a.kv_start, a.kv_len, a.max_kv_len = ptr(kv_start), ptr(kv_len), max_kv_len
+    a.scale = scale if scale is not None else head_dim ** -0.5
+    return a
+
+
+def attention_fwd(q, k, v, o, lse, B, H, Nq, Nk, strides, **kw):
+    """q/k/v/o: bf16 tensors (any view); strides = ((q_bs,q_ts,q_hs),(k..),(v..),(o..)) in elements."""
+    a = _attn_args(q, k, v, o, B, H, Nq, Nk, strides, **kw)
+    a.lse = ptr(lse)
+    call("pxa_attn_fwd", a)
+    return o
+
+
+def attention_bwd(q, k, v, o, d_o, lse, delta, dq, dk, dv, B, H, Nq, Nk, strides, dstrides, **kw):
+    a = _attn_args(q, k, v, o, B, H, Nq, Nk, strides, **kw)
+    a.lse, a.delta, a.d_o, a.dq, a.dk, a.dv = ptr(lse), ptr(delta), ptr(d_o), ptr(dq), ptr(dk), ptr(dv)
+    (a.dq_bs, a.dq_ts, a.dq_hs), (a.dk_bs, a.dk_ts, a.dk_hs), (a.dv_bs, a.dv_ts, a.dv_hs) = dstrides
+    call("pxa_attn_bwd", a)
+
+
+def patch_embed_fwd(x, w, bias, pos, out=None):
+    B, Cc, Hl, Wl = x.shape
+    D = w.shape[0]
+    if out is None:
+        out = torch.empty((B * (Hl // 2) * (Wl // 2), D), dtype=F32, device=x.device)
+    call("pxa_patch_embed_fwd", ptr(x), ptr(w), ptr(bias), ptr(pos), ptr(out), B, Cc, Hl, Wl, D)
+    return out
+
+
+def patch_embed_bwd(x, dtok, dw, dbias):
+    B, Cc, Hl, Wl = x.shape
+    call("pxa_patch_embed_bwd", ptr(x), ptr(dtok), ptr(dw), ptr(dbias), B, Cc, Hl, Wl, dw.shape[0])
+
+
+def unpatchify_fwd(lin, B, h, w, Co):
+    img = torch.empty((B, Co, 2 * h, 2 * w), dtype=F32, device=lin.device)
+    call("pxa_unpatchify_fwd", ptr(lin), ptr(img), B, h, w, Co)
+    return img
+
+
+def patchify_bwd(dimg, h, w):
+    B, Co = dimg.shape[0], dimg.shape[1]
+    dlin = torch.empty((B * h * w, 4 * Co), dtype=BF16, device=dimg.device)
+    call("pxa_patchify_bwd", ptr(dimg), ptr(dlin), B, h, w, Co)
+    return dlin
+
+
+def gather_rows_bf16(src, row_idx, L, alt=None, drop=None):
+    """src: (B*L, Cw) fp32 rows; row_idx int32 (rows,) -> (rows, Cw) bf16."""
+    Cw = src.shape[-1]
+    rows = row_idx.numel()
+    out = torch.empty((rows, Cw), dtype=BF16, device=src.device)
+    call("pxa_gather_rows_bf16", ptr(src), ptr(alt), ptr(row_idx), ptr(drop), ptr(out), rows, L, Cw)
+    return out
+
+
+def kv_compress_fwd(inp, in_bs, in_ts, conv_w, conv_b, ln_w, ln_b, B, H, W, Cc, sr, eps=1e-5):
+    out = torch.empty((B, (H // sr) * (W // sr), Cc), dtype=BF16, device=inp.device)
+    call("pxa_kv_compress_fwd", ptr(inp), in_bs, in_ts, ptr(conv_w), ptr(conv_b), ptr(ln_w), ptr(ln_b), ptr(out), B, H, W, Cc, sr, eps)
+    return out
+
+
+def sumsq(x, out):
+    call("pxa_sumsq_f32", ptr(x), x.numel(), ptr(out))
+
+
+def clip_coef(sumsq_t, out2, max_norm, inv_world=1.0):
+    call("pxa_clip_coef", ptr(sumsq_t), ptr(out2), float(max_norm), float(inv_world))
+
+
+def adamw_step(p, g, m, v, p_bf16, lr, beta1, beta2, eps, weight_decay, step, gscale=None):
+    call("pxa_adamw_step", ptr(p), ptr(g), ptr(m), ptr(v), ptr(p_bf16), p.numel(), lr, beta1, beta2, eps, weight_decay, step, ptr(gscale))
+
+
+def cast_bf16(x, out=None):
+    if out is None:
+        out = torch.empty(x.shape, dtype=BF16, device=x.device)
+    call("pxa_cast_f32_bf16", ptr(x), ptr(out), x.numel())
+    return out

@@ -1,0 +1,329 @@
+"""Per-kernel parity of the HIP C-ABI entry points (through pixart_sigma_amd.ops -> ctypes -> libpixart_hip.so)
+against plain PyTorch fp32 references of the same op evaluated on the same bf16-rounded inputs.
+Tolerances: bf16 outputs carry one bf16 rounding (~1.6e-3 rel-L2 RMS) -> 4e-3; fp32 outputs -> 2e-5 unless stated."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from conftest import rel_l2  # noqa: E402
+
+BF16_TOL = 4e-3
+
+
+@pytest.fixture(scope="module")
+def ops():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from pixart_sigma_amd import ops as o
+    return o
+
+
+def rnd(*shape, scale=1.0, seed=0, dtype=torch.float32):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(dtype).cuda()
+
+
+def bf(x):
+    return x.to(torch.bfloat16)
+
+
+# ------------------------------------------------------------------------------------------------ GEMM
+@pytest.mark.parametrize("M,N,K", [(256, 256, 128), (300, 1152, 1152), (130, 32, 72), (64, 3456, 256), (1000, 4608, 1152)])
+def test_gemm_nt_bias(ops, M, N, K):
+    a, w, b = bf(rnd(M, K, seed=1)), bf(rnd(N, K, scale=K ** -0.5, seed=2)), rnd(N, seed=3)
+    ref = a.float() @ w.float().t() + b
+    out = ops.gemm(a, w, ops.NT, bias=b)
+    assert rel_l2(out.float(), ref) < BF16_TOL
+    outf = ops.gemm(a, w, ops.NT, bias=b, out_dtype=torch.float32)
+    assert rel_l2(outf, ref) < 2e-5
+
+
+def test_gemm_gelu_dual_output(ops):
+    M, N, K = 520, 4608, 1152
+    a, w, b = bf(rnd(M, K, seed=1)), bf(rnd(N, K, scale=K ** -0.5, seed=2)), rnd(N, seed=3)
+    pre = a.float() @ w.float().t() + b
+    out2 = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
+    out = ops.gemm(a, w, ops.NT, bias=b, act=ops.ACT_GELU, out2=out2)
+    assert rel_l2(out2.float(), pre) < BF16_TOL
+    assert rel_l2(out.float(), F.gelu(pre, approximate="tanh")) < BF16_TOL
+
+
+def test_gemm_nn_gelu_grad(ops):
+    M, N, K = 333, 1152, 4608  # dX = dY W ; W stored (K=out_features, N=in_features)
+    dy, w = bf(rnd(M, K, seed=1)), bf(rnd(K, N, scale=K ** -0.5, seed=2))
+    ref = dy.float() @ w.float()
+    out = ops.gemm(dy, w, ops.NN)
+    assert rel_l2(out.float(), ref) < BF16_TOL
+    pre = bf(rnd(M, N, seed=5))
+    x = pre.float().clone().requires_grad_(True)
+    F.gelu(x, approximate="tanh").backward(torch.ones_like(x))
+    out = ops.gemm(dy, w, ops.NN, act=ops.ACT_GELU_GRAD, aux=pre)
+    assert rel_l2(out.float(), ref * x.grad) < BF16_TOL
+
+
+@pytest.mark.parametrize("K,split", [(512, 1), (1000, 3), (4096, 8)])
+def test_gemm_tn_splitk_accumulate(ops, K, split):
+    M, N = 1152, 3456  # dW[M][N] = sum_k A[k][M] B[k][N]
+    a, b = bf(rnd(K, M, seed=1)), bf(rnd(K, N, seed=2))
+    ref = a.float().t() @ b.float()
+    out = torch.zeros(M, N, device="cuda")
+    ops.gemm(a, b, ops.TN, out_f32=out, accumulate=True, split_k=split)
+    assert rel_l2(out, ref) < 2e-5
+    ops.gemm(a, b, ops.TN, out_f32=out, accumulate=True, split_k=split)  # accumulates
+    assert rel_l2(out, 2 * ref) < 2e-5
+
+
+def test_gemm_strided_views(ops):
+    """operands that are column slices of wider tensors (k/v halves of kv, q/k/v thirds of dqkv)."""
+    M, K = 200, 1152
+    big = bf(rnd(M, 3 * K, seed=1))
+    w = bf(rnd(1152, K, scale=K ** -0.5, seed=2))
+    a = big[:, K:2 * K]
+    assert rel_l2(ops.gemm(a, w, ops.NT).float(), a.float() @ w.float().t()) < BF16_TOL
+
+
+# ------------------------------------------------------------------------------------------------ adaLN rows
+def _mod(B, D, seed):
+    return rnd(B, 6, D, scale=0.3, seed=seed)
+
+
+def test_ln_mod_fwd_variants(ops):
+    B, N, D = 3, 50, 1152
+    R = B * N
+    x, u, mod = rnd(R, D, seed=1), bf(rnd(R, D, seed=2)), _mod(B, D, 3)
+    shift, scale, gate = mod[:, 0], mod[:, 1], mod[:, 2]
+    rep = lambda t: t.repeat_interleave(N, 0)
+    # plain LN + modulate
+    r = ops.ln_mod_fwd(x, shift, scale, 6 * D, rows_per_batch=N, want_stats=True)
+    ref = F.layer_norm(x, (D,), eps=1e-6) * (1 + rep(scale)) + rep(shift)
+    assert rel_l2(r["xn"].float(), ref) < BF16_TOL
+    assert rel_l2(r["mean"], x.mean(1)) < 1e-4 and rel_l2(r["rstd"], (x.var(1, unbiased=False) + 1e-6).rsqrt()) < 1e-5
+    # gated residual + LN, bf16 copy
+    r = ops.ln_mod_fwd(x, shift, scale, 6 * D, u=u, gate=gate, rows_per_batch=N, want_xb=True)
+    xr = x + rep(gate) * u.float()
+    assert rel_l2(r["x"], xr) < 1e-6
+    assert rel_l2(r["xb"].float(), xr) < BF16_TOL
+    assert rel_l2(r["xn"].float(), F.layer_norm(xr, (D,), eps=1e-6) * (1 + rep(scale)) + rep(shift)) < BF16_TOL
+    # ungated residual, no LN, in place
+    x2 = x.clone()
+    r = ops.ln_mod_fwd(x2, u=u, x_out=x2, want_xn=False, want_xb=True, rows_per_batch=N)
+    assert rel_l2(x2, x + u.float()) < 1e-6 and r["xn"] is None
+
+
+def test_ln_mod_bwd(ops):
+    B, N, D = 2, 40, 1152  # 40 rows/sample: chunks of 16 rows straddle the sample boundary
+    R = B * N
+    x, mod, dy, dxin = rnd(R, D, seed=1), _mod(B, D, 2), bf(rnd(R, D, seed=3)), rnd(R, D, seed=4)
+    shift, scale = mod[:, 0], mod[:, 1]
+    st = ops.ln_mod_fwd(x, shift, scale, 6 * D, rows_per_batch=N, want_stats=True)
+    xr = x.clone().requires_grad_(True)
+    sh, sc = shift.clone().requires_grad_(True), scale.clone().requires_grad_(True)
+    y = F.layer_norm(xr, (D,), eps=1e-6) * (1 + sc.repeat_interleave(N, 0)) + sh.repeat_interleave(N, 0)
+    y.backward(dy.float())
+    dmod = torch.zeros(B, 6, D, device="cuda")
+    dx = torch.empty_like(x)
+    ops.ln_mod_bwd(dy, x, st["mean"], st["rstd"], scale, 6 * D, dxin, dx, dmod[:, 0], dmod[:, 1], 6 * D, N)
+    assert rel_l2(dx, xr.grad + dxin) < 1e-5
+    assert rel_l2(dmod[:, 0], sh.grad) < 1e-5 and rel_l2(dmod[:, 1], sc.grad) < 1e-5
+    assert dmod[:, 2:].abs().max() == 0
+
+
+def test_gate_bwd_and_colsum(ops):
+    B, N, D = 2, 40, 1152
+    R = B * N
+    dx, add, u, mod = rnd(R, D, seed=1), bf(rnd(R, D, seed=2)), bf(rnd(R, D, seed=3)), _mod(B, D, 4)
+    gate = mod[:, 2]
+    g = dx + add.float()
+    dgate = torch.zeros(B, 6, D, device="cuda")
+    dxo, du = torch.empty_like(dx), torch.empty(R, D, dtype=torch.bfloat16, device="cuda")
+    ops.gate_bwd(dx, add=add, u=u, gate=gate, mod_stride=6 * D, dx_out=dxo, du=du, dgate=dgate[:, 2], dmod_stride=6 * D, rows_per_batch=N)
+    assert rel_l2(dxo, g) < 1e-6
+    assert rel_l2(du.float(), g * gate.repeat_interleave(N, 0)) < BF16_TOL
+    assert rel_l2(dgate[:, 2], (g * u.float()).view(B, N, D).sum(1)) < 1e-5
+    du2 = torch.empty(R, D, dtype=torch.bfloat16, device="cuda")
+    ops.gate_bwd(dx, du=du2, rows_per_batch=N)  # plain cast
+    assert rel_l2(du2.float(), dx) < BF16_TOL
+    dy = bf(rnd(777, 3456, seed=5))
+    out = torch.ones(3456, device="cuda")
+    ops.colsum(dy, out)
+    assert rel_l2(out, 1 + dy.float().sum(0)) < 1e-5
+
+
+# ------------------------------------------------------------------------------------------------ attention
+def _attn_ref(q, k, v):
+    """q (B,Nq,H,72), k/v (B,Nk,H,72) fp32 -> o, with autograd."""
+    s = torch.einsum("bqhd,bkhd->bhqk", q, k) * 72 ** -0.5
+    return torch.einsum("bhqk,bkhd->bqhd", s.softmax(-1), v)
+
+
+@pytest.mark.parametrize("B,H,Nq,Nk", [(2, 16, 256, 256), (1, 4, 200, 200), (2, 3, 130, 77), (1, 2, 64, 1024)])
+def test_attention_fwd_bwd_dense(ops, B, H, Nq, Nk):
+    C = H * 72
+    q, k, v = (bf(rnd(B, n, C, seed=s)) for n, s in ((Nq, 1), (Nk, 2), (Nk, 3)))
+    do = bf(rnd(B, Nq, C, seed=4))
+    o = torch.empty(B, Nq, C, dtype=torch.bfloat16, device="cuda")
+    lse = torch.empty(B, H, Nq, device="cuda")
+    st = ((Nq * C, C, 72), (Nk * C, C, 72), (Nk * C, C, 72), (Nq * C, C, 72))
+    ops.attention_fwd(q, k, v, o, lse, B, H, Nq, Nk, st)
+    qr, kr, vr = (t.float().view(B, -1, H, 72).requires_grad_(True) for t in (q, k, v))
+    oref = _attn_ref(qr, kr, vr)
+    assert rel_l2(o.float().view(B, Nq, H, 72), oref) < BF16_TOL
+    sref = torch.einsum("bqhd,bkhd->bhqk", qr, kr) * 72 ** -0.5
+    assert rel_l2(lse, torch.logsumexp(sref, -1) / math.log(2)) < 1e-4
+    oref.backward(do.float().view(B, Nq, H, 72))
+    dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+    delta = torch.empty(B, H, Nq, device="cuda")
+    ops.attention_bwd(q, k, v, o, do, lse, delta, dq, dk, dv, B, H, Nq, Nk, st, (st[0], st[1], st[2]))
+    assert rel_l2(dv.float().view_as(vr), vr.grad) < 2 * BF16_TOL
+    assert rel_l2(dq.float().view_as(qr), qr.grad) < 2 * BF16_TOL
+    assert rel_l2(dk.float().view_as(kr), kr.grad) < 2 * BF16_TOL
+
+
+def test_attention_qkv_packed_layout(ops):
+    """q/k/v read from, and dq/dk/dv written into, the (B,N,3,H,72) layout of the qkv GEMM (PixArt_blocks.py:130-131)."""
+    B, H, N = 2, 16, 192
+    C = H * 72
+    qkv = bf(rnd(B, N, 3 * C, seed=1))
+    q, k, v = qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:]
+    o = torch.empty(B, N, C, dtype=torch.bfloat16, device="cuda")
+    lse = torch.empty(B, H, N, device="cuda")
+    s3 = (N * 3 * C, 3 * C, 72)
+    st = (s3, s3, s3, (N * C, C, 72))
+    ops.attention_fwd(q, k, v, o, lse, B, H, N, N, st)
+    qr, kr, vr = (t.float().reshape(B, N, H, 72).requires_grad_(True) for t in (q, k, v))
+    oref = _attn_ref(qr, kr, vr)
+    assert rel_l2(o.float().view(B, N, H, 72), oref) < BF16_TOL
+    do = bf(rnd(B, N, C, seed=2))
+    oref.backward(do.float().view(B, N, H, 72))
+    dqkv = torch.zeros_like(qkv)
+    delta = torch.empty(B, H, N, device="cuda")
+    ops.attention_bwd(q, k, v, o, do, lse, delta, dqkv[..., :C], dqkv[..., C:2 * C], dqkv[..., 2 * C:], B, H, N, N, st, (s3, s3, s3))
+    ref = torch.cat([qr.grad.reshape(B, N, C), kr.grad.reshape(B, N, C), vr.grad.reshape(B, N, C)], -1)
+    assert rel_l2(dqkv.float(), ref) < 2 * BF16_TOL
+
+
+def test_attention_varlen_cross(ops):
+    """BlockDiagonalMask.from_seqlens([N]*B, y_lens): sample b attends only to its own packed text rows."""
+    B, H, N, lens = 3, 16, 160, [300, 7, 64]
+    C = H * 72
+    tot = sum(lens)
+    q = bf(rnd(B, N, C, seed=1))
+    kv = bf(rnd(tot, 2 * C, seed=2))
+    do = bf(rnd(B, N, C, seed=3))
+    starts = [0, lens[0], lens[0] + lens[1]]
+    kv_start = torch.tensor(starts, dtype=torch.int32, device="cuda")
+    kv_len = torch.tensor(lens, dtype=torch.int32, device="cuda")
+    o = torch.empty(B, N, C, dtype=torch.bfloat16, device="cuda")
+    lse = torch.empty(B, H, N, device="cuda")
+    st = ((N * C, C, 72), (0, 2 * C, 72), (0, 2 * C, 72), (N * C, C, 72))
+    ops.attention_fwd(q, kv[:, :C], kv[:, C:], o, lse, B, H, N, max(lens), st, kv_start=kv_start, kv_len=kv_len, max_kv_len=max(lens))
+    qr = q.float().view(B, N, H, 72).requires_grad_(True)
+    kvr = kv.float().view(tot, 2, H, 72).requires_grad_(True)
+    outs = [_attn_ref(qr[b:b + 1], kvr[s:s + n, 0][None], kvr[s:s + n, 1][None]) for b, (s, n) in enumerate(zip(starts, lens))]
+    oref = torch.cat(outs, 0)
+    assert rel_l2(o.float().view(B, N, H, 72), oref) < BF16_TOL
+    oref.backward(do.float().view(B, N, H, 72))
+    dq, dkv = torch.empty_like(q), torch.zeros_like(kv)
+    delta = torch.empty(B, H, N, device="cuda")
+    ops.attention_bwd(q, kv[:, :C], kv[:, C:], o, do, lse, delta, dq, dkv[:, :C], dkv[:, C:], B, H, N, max(lens), st,
+                      ((N * C, C, 72), (0, 2 * C, 72), (0, 2 * C, 72)), kv_start=kv_start, kv_len=kv_len, max_kv_len=max(lens))
+    assert rel_l2(dq.float().view_as(qr), qr.grad) < 2 * BF16_TOL
+    assert rel_l2(dkv.float().view(tot, 2, H, 72), kvr.grad) < 2 * BF16_TOL
+
+
+def test_attention_online_softmax_rescale(ops):
+    """A key far above the running max arriving in a late tile forces the rescale branch (guide rule 26)."""
+    B, H, N = 1, 1, 256
+    q, k, v = bf(rnd(B, N, 72, seed=1)), bf(rnd(B, N, 72, seed=2)), bf(rnd(B, N, 72, seed=3))
+    k[0, 200] = q[0, 5] * 6  # spike for query 5 in the 4th kv tile
+    o = torch.empty_like(q)
+    lse = torch.empty(B, H, N, device="cuda")
+    st = ((N * 72, 72, 72),) * 4
+    ops.attention_fwd(q, k, v, o, lse, B, H, N, N, st)
+    oref = _attn_ref(q.float().view(B, N, 1, 72), k.float().view(B, N, 1, 72), v.float().view(B, N, 1, 72))
+    assert rel_l2(o.float().view(B, N, 1, 72), oref) < BF16_TOL
+    assert (o.float().view(B, N, 72)[0, 5] - oref[0, 5, 0]).abs().max() < 0.03
+
+
+# ------------------------------------------------------------------------------------------------ token boundary
+def test_patch_embed_fwd_bwd(ops):
+    B, Hl, Wl, D = 2, 16, 24, 1152
+    x, w, b = rnd(B, 4, Hl, Wl, seed=1), rnd(D, 4, 2, 2, scale=0.2, seed=2), rnd(D, seed=3)
+    N = (Hl // 2) * (Wl // 2)
+    pos = rnd(N, D, seed=4)
+    out = ops.patch_embed_fwd(x, w, b, pos)
+    wr, br = w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    ref = F.conv2d(x, wr, br, stride=2).flatten(2).transpose(1, 2) + pos
+    assert rel_l2(out.view(B, N, D), ref) < 1e-6
+    dtok = rnd(B * N, D, seed=5)
+    ref.backward(dtok.view(B, N, D))
+    dw, db = torch.zeros_like(w), torch.zeros_like(b)
+    ops.patch_embed_bwd(x, dtok, dw, db)
+    assert rel_l2(dw, wr.grad) < 1e-5 and rel_l2(db, br.grad) < 1e-5
+
+
+def test_unpatchify_and_inverse(ops):
+    B, h, w, Co = 2, 8, 12, 8
+    lin = rnd(B * h * w, 4 * Co, seed=1)
+    img = ops.unpatchify_fwd(lin, B, h, w, Co)
+    ref = torch.einsum("nhwpqc->nchpwq", lin.view(B, h, w, 2, 2, Co)).reshape(B, Co, 2 * h, 2 * w)
+    assert torch.equal(img, ref)
+    back = ops.patchify_bwd(img, h, w)
+    assert torch.equal(back, lin.to(torch.bfloat16))
+
+
+def test_gather_rows(ops):
+    B, L, Cw = 3, 20, 4096
+    y, alt = rnd(B * L, Cw, seed=1), rnd(L, Cw, seed=2)
+    mask = torch.zeros(B, L, dtype=torch.bool)
+    mask[0, :20] = mask[1, :3] = mask[2, 5:9] = True
+    idx = mask.flatten().nonzero().flatten().to(torch.int32).cuda()
+    drop = torch.tensor([0, 1, 0], dtype=torch.int32, device="cuda")
+    out = ops.gather_rows_bf16(y, idx, L, alt=alt, drop=drop)
+    ref = torch.where(drop.bool()[:, None, None], alt[None], y.view(B, L, Cw)).reshape(B * L, Cw)[idx.long()]
+    assert torch.equal(out, ref.to(torch.bfloat16))
+
+
+def test_kv_compress_fwd(ops):
+    B, H, W, C, sr = 2, 8, 12, 1152, 2
+    qkv = bf(rnd(B, H * W, 3 * C, seed=1))
+    cw, cb = 0.25 + rnd(C, 1, sr, sr, scale=0.05, seed=2), rnd(C, scale=0.05, seed=3)
+    lw, lb = 1 + rnd(C, scale=0.05, seed=4), rnd(C, scale=0.05, seed=5)
+    k = qkv[..., C:2 * C]
+    out = ops.kv_compress_fwd(k, H * W * 3 * C, 3 * C, cw, cb, lw, lb, B, H, W, C, sr)
+    t = k.float().reshape(B, H, W, C).permute(0, 3, 1, 2)
+    t = F.conv2d(t, cw, cb, stride=sr, groups=C).reshape(B, C, -1).permute(0, 2, 1)
+    ref = F.layer_norm(t, (C,), lw, lb, eps=1e-5)
+    assert rel_l2(out.float(), ref) < BF16_TOL
+
+
+# ------------------------------------------------------------------------------------------------ optimizer
+def test_adamw_matches_torch(ops):
+    n = 1 << 16
+    p0, g1, g2 = rnd(n, seed=1), rnd(n, scale=0.1, seed=2), rnd(n, scale=0.1, seed=3)
+    pr = p0.clone().requires_grad_(True)
+    opt = torch.optim.AdamW([pr], lr=2e-5, weight_decay=3e-2, eps=1e-10)
+    p, m, v = p0.clone(), torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
+    pb = torch.empty(n, dtype=torch.bfloat16, device="cuda")
+    for step, g in enumerate((g1, g2), 1):
+        pr.grad = g.clone()
+        opt.step()
+        ops.adamw_step(p, g, m, v, pb, 2e-5, 0.9, 0.999, 1e-10, 3e-2, step)
+    assert rel_l2(p, pr.detach()) < 1e-6
+    assert torch.equal(pb, p.to(torch.bfloat16))
+
+
+def test_grad_norm_and_clip(ops):
+    g = rnd(100003, seed=1)
+    s = torch.zeros(1, device="cuda")
+    ops.sumsq(g[:100000], s)
+    assert abs(s.item() - g[:100000].double().pow(2).sum().item()) / s.item() < 1e-5
+    out = torch.empty(2, device="cuda")
+    ops.clip_coef(s, out, 0.01, 0.5)
+    norm = math.sqrt(s.item()) * 0.5
+    assert abs(out[1].item() - norm) / norm < 1e-5
+    assert abs(out[0].item() - min(1.0, 0.01 / (norm + 1e-6)) * 0.5) < 1e-7
