@@ -1,0 +1,220 @@
+#!/usr/bin/env python
+"""Headline benchmark: denoising TRAINING steps/sec (fwd + bwd + grad-clip + AdamW) of PixArt-Sigma-XL/2 at 1024px,
+batch 16 per GPU, data-parallel over N GPUs of one node (BASELINE.json `metric`, configs[2]).
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+One JSON line on rank 0.  A "step" = q_sample -> PixArtMS.forward -> IDDPM loss (MSE + VB) -> backward (gradient all-reduce
+overlapped) -> global-norm clip -> AdamW, on synthetic latents / caption features already resident in HBM, random-init
+weights with the zero-init tensors re-randomised.  `value` is whole-job steps/s x nothing: every
+rank does one step of batch 16, so steps/s of the job = 1 / (max-over-ranks step time) and images/s = 16 N x that.
+
+Extra objects: `roofline` (MFMA bound; algorithmic FLOPs of SURVEY.md section 8d / time; the dominant kernel measured live with
+events on the launch stream) and `cpu_baseline` (oracle/ = CPU port of the reference, timed on the host cores on a
+bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+D, H, DFF, DEPTH, LTXT = 1152, 16, 4608, 28, 300
+MFMA_PEAK = 2.5e15   # dense bf16, MI355X (MI355X_MICROARCH.md)
+
+
+def fwd_flops_per_sample(N, L=LTXT, n_kv=None):
+    """SURVEY.md section 8(d) algorithmic FLOPs (2mnk per GEMM; softmax/LN/GELU excluded)."""
+    n_kv = N if n_kv is None else n_kv
+    D2 = D * D
+    per_layer = 28 * N * D2 + 4 * L * D2 + 4 * N * n_kv * D + 4 * N * L * D
+    embed = 2 * N * 16 * D + 2 * 256 * D + 2 * D2 + 12 * D2 + 2 * L * 4096 * D + 2 * L * D2 + 2 * N * D * 32
+    return DEPTH * per_layer + embed
+
+
+def timed(fn, iters, warm=2):
+    for _ in range(warm):
+        fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    e1.synchronize()
+    return e0.elapsed_time(e1) / iters * 1e-3
+
+
+def kernel_rooflines(B, N):
+    """Live per-kernel measurements (events on the stream the kernels are launched on = torch's current stream)."""
+    from pixart_sigma_amd import ops
+    dev = "cuda"
+    R = B * N
+    x = torch.randn(R, D, device=dev).to(torch.bfloat16)
+    w1 = (torch.randn(DFF, D, device=dev) * D ** -0.5).to(torch.bfloat16)
+    b1 = torch.zeros(DFF, device=dev)
+    out, out2 = torch.empty(R, DFF, dtype=torch.bfloat16, device=dev), torch.empty(R, DFF, dtype=torch.bfloat16, device=dev)
+    res = {}
+    t = timed(lambda: ops.gemm(x, w1, ops.NT, bias=b1, act=ops.ACT_GELU, out=out, out2=out2), 10)
+    res["gemm_nt_fc1_gelu"] = dict(flops=2.0 * R * DFF * D, seconds=t)
+    dy = torch.randn(R, DFF, device=dev).to(torch.bfloat16)
+    dxo = torch.empty(R, D, dtype=torch.bfloat16, device=dev)
+    t = timed(lambda: ops.gemm(dy, w1, ops.NN, out=dxo), 10)
+    res["gemm_nn_fc1_dx"] = dict(flops=2.0 * R * DFF * D, seconds=t)
+    dw = torch.zeros(DFF, D, device=dev)
+    t = timed(lambda: ops.gemm(dy, x, ops.TN, out_f32=dw, accumulate=True, split_k=2), 5)
+    res["gemm_tn_fc1_dw"] = dict(flops=2.0 * R * DFF * D, seconds=t)
+    qkv = torch.randn(R, 3 * D, device=dev).to(torch.bfloat16)
+    a = torch.empty(R, D, dtype=torch.bfloat16, device=dev)
+    lse = torch.empty(B, H, N, device=dev)
+    s3 = (N * 3 * D, 3 * D, 72)
+    st = (s3, s3, s3, (N * D, D, 72))
+    t = timed(lambda: ops.attention_fwd(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], a, lse, B, H, N, N, st), 5)
+    res["attn_fwd_self"] = dict(flops=4.0 * B * N * N * D, seconds=t)
+    da, dqkv, delta = torch.randn(R, D, device=dev).to(torch.bfloat16), torch.empty_like(qkv), torch.empty(B, H, N, device=dev)
+    t = timed(lambda: ops.attention_bwd(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], a, da, lse, delta, dqkv[:, :D], dqkv[:, D:2 * D],
+                                        dqkv[:, 2 * D:], B, H, N, N, st, (s3, s3, s3)), 3)
+    res["attn_bwd_self"] = dict(flops=10.0 * B * N * N * D, seconds=t)
+    for k, v in res.items():
+        v["tflops"] = v["flops"] / v["seconds"] / 1e12
+        v["frac"] = v["flops"] / v["seconds"] / MFMA_PEAK
+    return res
+
+
+def cpu_baseline(budget_px=256):
+    """oracle/ (CPU port of the reference path) fwd+bwd of the full-depth XL/2 on the host cores, bounded sample:
+    one sample at `budget_px` resolution, scaled to the benchmark step by algorithmic FLOPs.  Threads are capped at 32:
+    on the 256-thread GPU host an uncapped torch pool ran this op mix ~40x slower (measured round 1)."""
+    from oracle import pixart_oracle as po
+    from oracle.weights import make_inputs, make_state_dict
+    cores = min(os.cpu_count() or 1, 32)
+    torch.set_num_threads(cores)
+    lat = budget_px // 8
+    cfg = po.OracleCfg(depth=DEPTH, input_size=lat, model_max_length=LTXT, pe_interpolation=budget_px / 512)
+    sd = make_state_dict(cfg, seed=0)
+    sd = {k: (v.requires_grad_(True) if k != "y_embedder.y_embedding" else v) for k, v in sd.items()}
+    inp = make_inputs(B=1, Hl=lat, Wl=lat, L=LTXT, seed=1)
+    diff = po.GaussianDiffusionOracle()
+    t0 = time.time()
+    terms = diff.training_losses(lambda xt, t: po.forward(sd, cfg, xt, t, inp["y"], inp["mask"]), inp["x"], inp["t"], inp["noise"])
+    terms["loss"].mean().backward()
+    dt = time.time() - t0
+    n = (lat // 2) ** 2
+    return dt, 3 * fwd_flops_per_sample(n), cores, f"oracle (CPU port of the reference path, fp32) fwd+bwd XL/2 {budget_px}px batch 1: {dt:.1f} s"
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=16, help="per-GPU batch (BASELINE: 16)")
+    ap.add_argument("--image-size", type=int, default=1024)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-roofline", action="store_true")
+    ap.add_argument("--grad-checkpoint", action="store_true")
+    a = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {a.gpus}"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from pixart_sigma_amd import IDDPM, PixArtMS_XL_2
+    from pixart_sigma_amd.dp import FusedAdamW
+    from pixart_sigma_amd.model.utils import set_grad_checkpoint
+
+    lat = a.image_size // 8
+    N = (lat // 2) ** 2
+    B = a.batch
+    torch.manual_seed(0)     # identical init on every rank (DDP broadcast equivalent)
+    model = PixArtMS_XL_2(input_size=lat, pe_interpolation=a.image_size / 512, model_max_length=LTXT, class_dropout_prob=0.0)
+    with torch.no_grad():    # re-randomise the zero-init tensors so no branch is numerically dead
+        for blk in model.blocks:
+            blk.cross_attn.proj.weight.normal_(std=0.02)
+        model.final_layer.linear.weight.normal_(std=0.02)
+    model = model.to(dev).train()
+    if a.grad_checkpoint:
+        set_grad_checkpoint(model)
+    model.prepare(dev)
+    opt = FusedAdamW(model, lr=2e-5, weight_decay=3e-2, eps=1e-10, max_grad_norm=0.01)
+    diff = IDDPM(str(1000), learn_sigma=True, pred_sigma=True, snr=False)
+
+    g = torch.Generator(device="cpu").manual_seed(1234 + rank)
+    x0 = torch.randn(B, 4, lat, lat, generator=g).to(dev)
+    noise = torch.randn(B, 4, lat, lat, generator=g).to(dev)
+    y = torch.randn(B, 1, LTXT, 4096, generator=g).to(dev)
+    t = torch.randint(0, 1000, (B,), generator=g).to(dev)
+    mask = torch.ones(B, LTXT, dtype=torch.int64)            # host-side mask: no device sync for y_lens
+
+    def step():
+        opt.zero_grad()
+        terms = diff.training_losses(model, x0, t, model_kwargs=dict(y=y, mask=mask, data_info=None), noise=noise)
+        loss = terms["loss"].mean()
+        loss.backward()
+        opt.step()
+        return loss
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        loss = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = tt.item()
+    sec_per_step = dt / a.steps
+    loss_v = float(loss.item())
+
+    if rank == 0:
+        flops_step = 3 * fwd_flops_per_sample(N) * B          # per GPU, fwd + bwd, no recompute, no optimizer
+        out = {
+            "metric": "denoising steps/sec (fwd+bwd) PixArt-Sigma-XL/2 1024px bs16 @1/2/4/8 GPU",
+            "value": 1.0 / sec_per_step, "unit": "steps/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": sec_per_step * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": f"PixArt-Sigma-XL/2 {a.image_size}px training step (fwd+bwd+clip+AdamW), batch {B}/GPU, L=300 text tokens, "
+                                   f"DP={world} RCCL all-reduce", "model": "PixArtMS_XL_2", "global_batch": B * world, "seq_len": N,
+                       "parallelism": f"dp{world}", "grad_checkpoint": bool(a.grad_checkpoint)},
+            "images_per_s": B * world / sec_per_step, "final_loss": loss_v,
+            "step_tflops_per_gpu": flops_step / sec_per_step / 1e12,
+        }
+        roof = {"bound": "mfma", "achieved": flops_step / sec_per_step / 1e12, "peak": MFMA_PEAK / 1e12, "unit": "TFLOP/s",
+                "frac": flops_step / sec_per_step / MFMA_PEAK, "traffic": None, "scope": "whole training step (algorithmic FLOPs / wall time)"}
+        if not a.no_kernel_roofline and a.image_size == 1024:
+            ks = kernel_rooflines(B, N)
+            dom = max(ks, key=lambda k: ks[k]["seconds"] * {"gemm_nt_fc1_gelu": 1, "gemm_nn_fc1_dx": 1, "gemm_tn_fc1_dw": 1, "attn_fwd_self": 1, "attn_bwd_self": 1}[k])
+            roof["kernels"] = {k: {"TFLOP/s": round(v["tflops"], 1), "frac": round(v["frac"], 4), "ms": round(v["seconds"] * 1e3, 3)} for k, v in ks.items()}
+            roof["dominant_kernel"] = dom
+        out["roofline"] = roof
+        if not a.no_cpu_baseline:
+            cdt, cflops, cores, desc = cpu_baseline()
+            out["cpu_baseline"] = {"value": 1.0 / (cdt * flops_step / cflops), "unit": "steps/s", "cores": cores, "kind": "port",
+                                   "sample": desc + f"; scaled by algorithmic FLOPs x{flops_step / cflops:.1f} to the {a.image_size}px batch-{B} step"}
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

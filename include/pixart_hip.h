@@ -57,9 +57,9 @@ int pxa_gemm(const pxa_gemm_args* args, hipStream_t stream);
  * x' = x + gate*u (u bf16, gate per sample; either may be NULL), optional bf16 copy of x' (cross-attn input),
  * xn = LayerNorm(x', no affine, eps) * (1 + scale) + shift  -> bf16.
  * Replaces nn.LayerNorm(elementwise_affine=False, eps=1e-6) + t2i_modulate + the gated residual adds
- * (PixArtMS.py:58,64,74-77; PixArt_blocks.py:24-25,217-219).  shift/scale/gate point at sample 0; sample b is at
- * ptr + b*mod_stride.  rows_per_batch = tokens per sample. x_out may alias x. */
-int pxa_ln_mod_fwd(const float* x, const void* u_bf16, const float* gate, const float* shift, const float* scale, int mod_stride,
+ * (PixArtMS.py:58,64,74-77; PixArt_blocks.py:24-25,217-219).  shift/scale (gate) point at sample 0; sample b is at
+ * ptr + b*mod_stride (b*gate_stride).  rows_per_batch = tokens per sample. x_out may alias x. */
+int pxa_ln_mod_fwd(const float* x, const void* u_bf16, const float* gate, int gate_stride, const float* shift, const float* scale, int mod_stride,
                    float* x_out, void* xn_bf16, void* xb_bf16, float* mean, float* rstd,
                    int R, int D, int rows_per_batch, float eps, hipStream_t stream);
 /* dx_out = dx_in + dLN(dy*(1+scale));  dshift[b] += sum dy;  dscale[b] += sum dy*xhat  (atomic; caller zeroes). */

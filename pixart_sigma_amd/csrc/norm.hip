@@ -14,7 +14,7 @@ using namespace pxa;
 template <int NV>
 __global__ __launch_bounds__(256) void ln_mod_fwd_kernel(
     const float* x, const bf16_t* __restrict__ u, const float* __restrict__ gate,
-    const float* __restrict__ shift, const float* __restrict__ scale, int mod_stride,
+    const float* __restrict__ shift, const float* __restrict__ scale, int mod_stride, int gate_stride,
     float* x_out, bf16_t* __restrict__ xn, bf16_t* __restrict__ xb,
     float* __restrict__ mean_out, float* __restrict__ rstd_out, int R, int D, int rows_per_batch, float eps) {
   const int hl = threadIdx.x & 31;
@@ -33,7 +33,7 @@ __global__ __launch_bounds__(256) void ln_mod_fwd_kernel(
       float u0, u1, u2, u3;
       unpack_bf16x2(uu.x, u0, u1); unpack_bf16x2(uu.y, u2, u3);
       if (gate) {
-        const float4 g = *reinterpret_cast<const float4*>(gate + (size_t)b * mod_stride + c);
+        const float4 g = *reinterpret_cast<const float4*>(gate + (size_t)b * gate_stride + c);
         v[j].x += g.x * u0; v[j].y += g.y * u1; v[j].z += g.z * u2; v[j].w += g.w * u3;
       } else {
         v[j].x += u0; v[j].y += u1; v[j].z += u2; v[j].w += u3;
@@ -219,14 +219,14 @@ __global__ __launch_bounds__(128) void colsum_kernel(const bf16_t* __restrict__ 
   }
 }  // namespace
 
-extern "C" int pxa_ln_mod_fwd(const float* x, const void* u_bf16, const float* gate, const float* shift, const float* scale,
+extern "C" int pxa_ln_mod_fwd(const float* x, const void* u_bf16, const float* gate, int gate_stride, const float* shift, const float* scale,
                               int mod_stride, float* x_out, void* xn_bf16, void* xb_bf16, float* mean, float* rstd,
                               int R, int D, int rows_per_batch, float eps, hipStream_t stream) {
   PXA_CHECK(x && R > 0 && D % 128 == 0 && rows_per_batch > 0, "pxa_ln_mod_fwd: bad args");
   PXA_CHECK(!xn_bf16 || (shift && scale), "pxa_ln_mod_fwd: LN output needs shift/scale");
   PXA_CHECK(!mean == !rstd, "pxa_ln_mod_fwd: mean/rstd must both be given or both null");
   DISPATCH_NV(D, hipLaunchKernelGGL(ln_mod_fwd_kernel<NV>, dim3((R + 7) / 8), dim3(256), 0, stream, x, (const bf16_t*)u_bf16, gate, shift, scale,
-                                     mod_stride, x_out, (bf16_t*)xn_bf16, (bf16_t*)xb_bf16, mean, rstd, R, D, rows_per_batch, eps));
+                                     mod_stride, gate_stride, x_out, (bf16_t*)xn_bf16, (bf16_t*)xb_bf16, mean, rstd, R, D, rows_per_batch, eps));
   PXA_LAUNCH_CHECK();
   return 0;
 }

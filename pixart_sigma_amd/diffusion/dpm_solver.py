@@ -1,0 +1,108 @@
+"""DPM-Solver++(2M) sampling loop around the denoiser — the caller of the hot path at inference (reference
+diffusion/dpm_solver.py:6-36 and diffusion/model/dpm_solver.py:5-169,172-336,435-453,551-596,805-862,1181-1241).
+
+Same public surface (DPMS(...).sample(...)), restricted to what scripts/inference.py uses: discrete linear-beta VP
+schedule, model_type='noise', classifier-free guidance, algorithm 'dpmsolver++', method='multistep', order<=2,
+skip_type='time_uniform'.  All schedule scalars (alpha_t, sigma_t, lambda_t per step) are computed once on the host in
+float32 (the reference re-derives them every step on the device through a sort/gather interpolate_fn, :1285-1324), so the
+loop issues only the model call and two fused elementwise updates per step and never synchronises.
+"""
+import numpy as np
+import torch
+
+
+class NoiseScheduleVP:
+    def __init__(self, schedule="discrete", betas=None, dtype=torch.float32):
+        assert schedule == "discrete" and betas is not None
+        log_alphas = 0.5 * torch.log(1 - betas).cumsum(dim=0)
+        self.T = 1.0
+        self.log_alpha_array = log_alphas.to(dtype)                       # no clipping needed for the linear schedule (:71-81)
+        self.total_N = self.log_alpha_array.shape[0]
+        self.t_array = torch.linspace(0.0, 1.0, self.total_N + 1)[1:].to(dtype)
+
+    def marginal_log_mean_coeff(self, t):
+        """Piecewise-linear interpolation of log(alpha) over t_i = (i+1)/N, linear extrapolation outside (interpolate_fn)."""
+        t = torch.as_tensor(t, dtype=self.t_array.dtype).reshape(-1)
+        xp, yp = self.t_array, self.log_alpha_array
+        idx = torch.searchsorted(xp, t.contiguous()).clamp(1, self.total_N - 1)
+        x0, x1, y0, y1 = xp[idx - 1], xp[idx], yp[idx - 1], yp[idx]
+        return y0 + (t - x0) * (y1 - y0) / (x1 - x0)
+
+    def marginal_alpha(self, t):
+        return torch.exp(self.marginal_log_mean_coeff(t))
+
+    def marginal_std(self, t):
+        return torch.sqrt(1.0 - torch.exp(2.0 * self.marginal_log_mean_coeff(t)))
+
+    def marginal_lambda(self, t):
+        la = self.marginal_log_mean_coeff(t)
+        return la - 0.5 * torch.log(1.0 - torch.exp(2.0 * la))
+
+
+class DPM_Solver:
+    def __init__(self, model, noise_schedule, condition, uncondition, cfg_scale, model_kwargs):
+        self.model, self.ns = model, noise_schedule
+        self.condition, self.uncondition, self.cfg_scale = condition, uncondition, cfg_scale
+        self.model_kwargs = model_kwargs
+
+    def _eps(self, x, t_cont):
+        """model_wrapper.model_fn, :311-332: one 2B forward for classifier-free guidance."""
+        B = x.shape[0]
+        t_in = torch.full((B,), (t_cont - 1.0 / self.ns.total_N) * 1000.0, device=x.device, dtype=torch.float32)   # :280
+        if self.cfg_scale == 1.0 or self.uncondition is None:
+            return self.model(x, t_in, self.condition, **self.model_kwargs)
+        out = self.model(torch.cat([x] * 2), torch.cat([t_in] * 2), torch.cat([self.uncondition, self.condition]), **self.model_kwargs)
+        e_u, e_c = out.chunk(2)
+        return e_u + self.cfg_scale * (e_c - e_u)
+
+    def sample(self, x, steps=20, t_start=None, t_end=None, order=2, skip_type="time_uniform", method="multistep",
+               lower_order_final=True, solver_type="dpmsolver", **unused):
+        assert method == "multistep" and skip_type == "time_uniform" and solver_type == "dpmsolver" and order in (1, 2)
+        assert steps >= order
+        ns = self.ns
+        t_0 = 1.0 / ns.total_N if t_end is None else t_end
+        t_T = ns.T if t_start is None else t_start
+        ts = torch.linspace(t_T, t_0, steps + 1)                          # float32, as get_time_steps (:466)
+        lam, sig, alp = ns.marginal_lambda(ts), ns.marginal_std(ts), ns.marginal_alpha(ts)
+        tl = [float(v) for v in ts]
+
+        def x0_pred(x, i):                                                # data_prediction_fn, :435-444
+            return (x - float(sig[i]) * self._eps(x, tl[i])) / float(alp[i])
+
+        def first(x, i_s, i_t, m_s):                                      # :573-582
+            h = lam[i_t] - lam[i_s]
+            return float(sig[i_t] / sig[i_s]) * x - float(alp[i_t] * torch.expm1(-h)) * m_s
+
+        def second(x, i1, i0, i_t, m1, m0):                               # :822-841
+            h0, h = lam[i0] - lam[i1], lam[i_t] - lam[i0]
+            r0 = h0 / h
+            c = float(alp[i_t] * torch.expm1(-h))
+            D1 = float(1.0 / r0) * (m0 - m1)
+            return float(sig[i_t] / sig[i0]) * x - c * m0 - 0.5 * c * D1
+
+        with torch.no_grad():
+            idx_prev, m_prev = [0], [x0_pred(x, 0)]
+            for step in range(1, order):                                  # :1205-1213
+                x = first(x, idx_prev[-1], step, m_prev[-1])
+                idx_prev.append(step)
+                m_prev.append(x0_pred(x, step))
+            for step in range(order, steps + 1):                          # :1215-1241
+                so = min(order, steps + 1 - step) if lower_order_final else order
+                if so == 1:
+                    x = first(x, idx_prev[-1], step, m_prev[-1])
+                else:
+                    x = second(x, idx_prev[-2], idx_prev[-1], step, m_prev[-2], m_prev[-1])
+                for i in range(order - 1):
+                    idx_prev[i], m_prev[i] = idx_prev[i + 1], m_prev[i + 1]
+                idx_prev[-1] = step
+                if step < steps:
+                    m_prev[-1] = x0_pred(x, step)
+        return x
+
+
+def DPMS(model, condition, uncondition, cfg_scale, model_type="noise", noise_schedule="linear", guidance_type="classifier-free",
+         model_kwargs={}, diffusion_steps=1000):
+    """Same signature as reference diffusion/dpm_solver.py:6."""
+    assert model_type == "noise" and guidance_type == "classifier-free" and noise_schedule == "linear"
+    betas = torch.tensor(np.linspace(0.0001 * 1000 / diffusion_steps, 0.02 * 1000 / diffusion_steps, diffusion_steps, dtype=np.float64))
+    return DPM_Solver(model, NoiseScheduleVP("discrete", betas=betas), condition, uncondition, cfg_scale, dict(model_kwargs))

@@ -1,0 +1,345 @@
+"""Host-side orchestration of the PixArt-Sigma denoiser on the HIP kernels: which kernel runs when, which
+activations are kept for backward, where weight gradients land.  Pure sequencing — all arithmetic is in
+libpixart_hip.so (ops.py -> C ABI).  Mirrors the dataflow of PixArtMS.forward / PixArtMSBlock.forward
+(reference diffusion/model/nets/PixArtMS.py:71-79,165-211) with these fusions:
+
+  block l:  x_in  = x2[l-1] + gate_mlp[l-1]*u3[l-1] ; xn1 = LN(x_in)(1+scale_msa)+shift_msa      (ln_mod_fwd, 1 pass)
+            qkv   = xn1 Wqkv^T + b                                                                (gemm NT)
+            a     = softmax(q k^T/sqrt(72)) v          [k,v optionally KV-compressed]             (attn_fwd)
+            u1    = a Wproj^T + b                                                                 (gemm NT)
+            x1    = x_in + gate_msa*u1 ; x1b = bf16(x1)                                           (ln_mod_fwd, no LN)
+            qc    = x1b Wq^T + b ; kvc = y Wkv^T + b ; c = varlen-attn(qc, kvc) ; u2 = c Wcp^T+b  (gemm, attn_fwd, gemm)
+            x2    = x1 + u2 ; xn2 = LN(x2)(1+scale_mlp)+shift_mlp                                 (ln_mod_fwd)
+            h     = gelu(xn2 W1^T + b)  (pre-activation kept) ; u3 = h W2^T + b                   (gemm+GELU, gemm)
+  final:    x3 = x2 + gate_mlp*u3 ; LN+modulate ; Linear(D,32) ; unpatchify
+
+The residual stream, LayerNorm statistics, softmax and all accumulators are fp32; GEMM / attention operands and the
+stored branch activations are bf16 (DESIGN.md "Numerics").  Backward is hand-sequenced (no autograd inside): weight
+gradients are accumulated straight into the flat fp32 gradient buffer (ParamStore.grad).
+"""
+import math
+
+import numpy as np
+import torch
+
+from . import ops
+from .ops import BF16, F32, NN, NT, TN
+
+
+def sincos_pos_embed(embed_dim, h, w, pe_interpolation, base_size):
+    """Host float64 table, same arithmetic as the reference's get_2d_sincos_pos_embed (PixArt.py:258-307):
+    float32 grid coordinates, float64 omega/sin/cos, w (column) coordinate in the first half.  Cached per geometry
+    on the device instead of being rebuilt in numpy on every forward (PixArtMS.py:177-182)."""
+    grid_h = np.arange(h, dtype=np.float32) / (h / base_size) / pe_interpolation
+    grid_w = np.arange(w, dtype=np.float32) / (w / base_size) / pe_interpolation
+    gw, gh = np.meshgrid(grid_w, grid_h)
+    quarter = embed_dim // 4
+    omega = np.arange(quarter, dtype=np.float64)
+    omega /= embed_dim / 4.0
+    omega = 1.0 / 10000 ** omega
+
+    def enc(pos):
+        out = np.einsum("m,d->md", pos.reshape(-1), omega)
+        return np.concatenate([np.sin(out), np.cos(out)], axis=1)
+    return np.concatenate([enc(gw), enc(gh)], axis=1)
+
+
+class ParamStore:
+    """All model parameters in ONE flat fp32 buffer (master), ONE flat fp32 gradient buffer and ONE flat bf16 shadow
+    (the GEMM operands), sharing offsets.  nn.Parameters are re-pointed to views of the master so optimizers, state
+    dicts and the data-parallel all-reduce see ordinary tensors, while the fused AdamW / grad-norm / all-reduce kernels
+    work on contiguous ranges.  Order = forward order (embedders, block 0..L-1, final layer) so a block's gradients are a
+    contiguous bucket that completes at a known point of the hand-sequenced backward."""
+    ALIGN = 64
+
+    def __init__(self, named_params, device, group_of=None):
+        """group_of: optional name -> group label; consecutive parameters with one label form a bucket (store.groups)."""
+        self.names, self.offset, self.shape, self.numel = [], {}, {}, {}
+        self.groups = {}
+        off = 0
+        for name, p in named_params:
+            self.names.append(name)
+            self.offset[name], self.shape[name], self.numel[name] = off, tuple(p.shape), p.numel()
+            end = off + (p.numel() + self.ALIGN - 1) // self.ALIGN * self.ALIGN
+            if group_of is not None:
+                gname = group_of(name)
+                if gname in self.groups:
+                    assert self.groups[gname][1] == off, f"group {gname} is not contiguous at {name}"
+                    self.groups[gname] = (self.groups[gname][0], end)
+                else:
+                    self.groups[gname] = (off, end)
+            off = end
+        self.total = off
+        self.device = device
+        self.master = torch.zeros(off, dtype=F32, device=device)
+        self.grad = torch.zeros(off, dtype=F32, device=device)
+        self.shadow = torch.zeros(off, dtype=BF16, device=device)
+        self.params = dict(named_params)
+        self._versions = None
+        for name, p in named_params:
+            v = self.view(self.master, name)
+            v.copy_(p.data)
+            p.data = v
+            p.grad = self.view(self.grad, name)
+
+    def view(self, flat, name):
+        o = self.offset[name]
+        return flat[o:o + self.numel[name]].view(self.shape[name])
+
+    def w(self, name):   # bf16 shadow weight (2-D)
+        return self.view(self.shadow, name)
+
+    def f(self, name):   # fp32 master (bias / table)
+        return self.view(self.master, name)
+
+    def g(self, name):   # fp32 gradient accumulator
+        return self.view(self.grad, name)
+
+    def range_of(self, prefix):
+        """[start, end) element range of all parameters whose name starts with prefix (contiguous by construction)."""
+        idx = [i for i, n in enumerate(self.names) if n.startswith(prefix)]
+        assert idx and idx == list(range(idx[0], idx[-1] + 1)), prefix
+        last = self.names[idx[-1]]
+        end = self.offset[last] + (self.numel[last] + self.ALIGN - 1) // self.ALIGN * self.ALIGN
+        return self.offset[self.names[idx[0]]], end
+
+    def owns(self, p, name):
+        return p.data_ptr() == self.master.data_ptr() + 4 * self.offset[name] and p.device == self.master.device
+
+    def refresh_shadow(self, force=False):
+        """Re-cast master -> bf16 shadow if any parameter was modified by torch ops since the last cast (the fused AdamW
+        kernel refreshes the shadow itself and does not bump versions)."""
+        vers = tuple(p._version for p in self.params.values())
+        if force or vers != self._versions:
+            ops.cast_bf16(self.master, self.shadow)
+            self._versions = vers
+
+    def attach_grads(self):
+        """Make every p.grad the view of the flat buffer; returns True if the buffer had to be (re)zeroed."""
+        missing = [n for n, p in self.params.items() if p.grad is None or p.grad.data_ptr() != self.grad.data_ptr() + 4 * self.offset[n]]
+        if not missing:
+            return False
+        if len(missing) == len(self.params):
+            self.grad.zero_()
+        for n in missing:
+            p = self.params[n]
+            v = self.view(self.grad, n)
+            if len(missing) != len(self.params):
+                v.zero_()
+                if p.grad is not None:
+                    v.copy_(p.grad)
+            p.grad = v
+        return True
+
+
+def _splitk(M, N, K):
+    tiles = ((M + 127) // 128) * ((N + 127) // 128)
+    return max(1, min((640 + tiles - 1) // tiles, max(1, K // 512)))
+
+
+class Engine:
+    """Forward/backward sequencing for one PixArtMS instance."""
+
+    def __init__(self, store, cfg):
+        self.S, self.cfg = store, cfg
+        self._pos_cache = {}
+        self.grad_ready_hook = None   # callable(prefix) fired when a parameter group's gradients are complete
+
+    # ------------------------------------------------------------------ helpers
+    def pos_table(self, h, w):
+        key = (h, w)
+        if key not in self._pos_cache:
+            c = self.cfg
+            tab = sincos_pos_embed(c["hidden_size"], h, w, c["pe_interpolation"], c["base_size"])
+            self._pos_cache[key] = torch.from_numpy(tab).to(F32).to(self.S.device).contiguous()
+        return self._pos_cache[key]
+
+    def _lin(self, x, name, **kw):
+        return ops.gemm(x, self.S.w(name + ".weight"), NT, bias=self.S.f(name + ".bias"), **kw)
+
+    def _lin_bwd(self, dy, x, name, need_dx=True, dx_kw=None):
+        """dW += dy^T x ; db += colsum(dy) ; returns dx = dy W (bf16) if need_dx."""
+        S = self.S
+        M, N = S.shape[name + ".weight"]
+        ops.gemm(dy, x, TN, out_f32=S.g(name + ".weight"), accumulate=True, split_k=_splitk(M, N, dy.shape[0]))
+        ops.colsum(dy, S.g(name + ".bias"))
+        if need_dx:
+            return ops.gemm(dy, S.w(name + ".weight"), NN, **(dx_kw or {}))
+        return None
+
+    # ------------------------------------------------------------------ caption branch
+    def caption_fwd(self, y, row_idx, L, drop, y_null):
+        """y (B*L, 4096) fp32 -> packed y_emb (Ltot, D) bf16  (CaptionEmbedder, PixArt_blocks.py:400-407 after masked_select).
+        y_null: the y_embedding buffer substituted for dropped samples (token_drop)."""
+        S = self.S
+        yb = ops.gather_rows_bf16(y, row_idx, L, alt=y_null if drop is not None else None, drop=drop)
+        hpre = torch.empty((yb.shape[0], S.shape["y_embedder.y_proj.fc1.weight"][0]), dtype=BF16, device=y.device)
+        h = self._lin(yb, "y_embedder.y_proj.fc1", act=ops.ACT_GELU, out2=hpre)
+        ye = self._lin(h, "y_embedder.y_proj.fc2")
+        return ye, (yb, hpre, h)
+
+    def caption_bwd(self, dye_f32, saved):
+        yb, hpre, h = saved
+        dye = torch.empty(dye_f32.shape, dtype=BF16, device=dye_f32.device)
+        ops.gate_bwd(dye_f32, du=dye, rows_per_batch=dye_f32.shape[0])
+        dh = self._lin_bwd(dye, h, "y_embedder.y_proj.fc2", dx_kw=dict(act=ops.ACT_GELU_GRAD, aux=hpre))
+        self._lin_bwd(dh, yb, "y_embedder.y_proj.fc1", need_dx=False)
+
+    # ------------------------------------------------------------------ block
+    def block_fwd(self, l, x_prev, u_prev, gate_prev, ctx):
+        """Returns (x2, u3, saved).  x_prev/u_prev/gate_prev: residual, pending gated branch of the previous block."""
+        S, c = self.S, self.cfg
+        B, N, D, H = ctx["B"], ctx["N"], c["hidden_size"], c["num_heads"]
+        p = f"blocks.{l}."
+        mod = ctx["mod"][l]                                   # (B, 6, D) fp32 view
+        sm, scm, gm, sl, scl, gl = (mod[:, i] for i in range(6))
+        st = 6 * D
+        r = ops.ln_mod_fwd(x_prev, sm, scm, st, u=u_prev, gate=gate_prev, gate_stride=st, rows_per_batch=N, want_stats=True)
+        x_in, xn1, mean1, rstd1 = r["x"], r["xn"], r["mean"], r["rstd"]
+        qkv = self._lin(xn1, p + "attn.qkv")
+        sr = c["kv_scale_factor"] if l in c["kv_layers"] else 1
+        a = torch.empty((B * N, D), dtype=BF16, device=qkv.device)
+        lse = torch.empty((B, H, N), dtype=F32, device=qkv.device)
+        s3 = (N * 3 * D, 3 * D, 72)
+        kc = vc = None
+        if sr > 1:
+            hh, ww = ctx["hw"]
+            if c["kv_sampling"] == "conv":
+                cw, cb = S.f(p + "attn.sr.weight"), S.f(p + "attn.sr.bias")
+                lw, lb = S.f(p + "attn.norm.weight"), S.f(p + "attn.norm.bias")
+                kc = ops.kv_compress_fwd(qkv[:, D:2 * D], N * 3 * D, 3 * D, cw, cb, lw, lb, B, hh, ww, D, sr)
+                vc = ops.kv_compress_fwd(qkv[:, 2 * D:], N * 3 * D, 3 * D, cw, cb, lw, lb, B, hh, ww, D, sr)
+                Nk = kc.shape[1]
+                sk = (Nk * D, D, 72)
+                ops.attention_fwd(qkv[:, :D], kc, vc, a, lse, B, H, N, Nk, (s3, sk, sk, (N * D, D, 72)))
+            elif c["kv_sampling"] == "uniform_every":
+                Nk = (N + sr - 1) // sr
+                sk = (N * 3 * D, 3 * D * sr, 72)
+                ops.attention_fwd(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], a, lse, B, H, N, Nk, (s3, sk, sk, (N * D, D, 72)))
+            else:
+                raise NotImplementedError(f"kv sampling mode {c['kv_sampling']!r} (conv and uniform_every are implemented)")
+        else:
+            ops.attention_fwd(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], a, lse, B, H, N, N, (s3, s3, s3, (N * D, D, 72)))
+        u1 = self._lin(a, p + "attn.proj")
+        r = ops.ln_mod_fwd(x_in, u=u1, gate=gm, gate_stride=st, want_xn=False, want_xb=True, rows_per_batch=N)
+        x1, x1b = r["x"], r["xb"]
+        qc = self._lin(x1b, p + "cross_attn.q_linear")
+        ye = ctx["ye"]
+        kvc = self._lin(ye, p + "cross_attn.kv_linear")
+        cr = torch.empty((B * N, D), dtype=BF16, device=qkv.device)
+        lse_c = torch.empty((B, H, N), dtype=F32, device=qkv.device)
+        sc_str = ((N * D, D, 72), (0, 2 * D, 72), (0, 2 * D, 72), (N * D, D, 72))
+        ops.attention_fwd(qc, kvc[:, :D], kvc[:, D:], cr, lse_c, B, H, N, ctx["max_len"], sc_str,
+                          kv_start=ctx["kv_start"], kv_len=ctx["kv_len"], max_kv_len=ctx["max_len"])
+        u2 = self._lin(cr, p + "cross_attn.proj")
+        r = ops.ln_mod_fwd(x1, sl, scl, st, u=u2, x_out=x1, rows_per_batch=N, want_stats=True)
+        x2, xn2, mean2, rstd2 = r["x"], r["xn"], r["mean"], r["rstd"]
+        hpre = torch.empty((B * N, S.shape[p + "mlp.fc1.weight"][0]), dtype=BF16, device=qkv.device)
+        h = self._lin(xn2, p + "mlp.fc1", act=ops.ACT_GELU, out2=hpre)
+        u3 = self._lin(h, p + "mlp.fc2")
+        saved = dict(x_in=x_in, mean1=mean1, rstd1=rstd1, xn1=xn1, qkv=qkv, a=a, lse=lse, u1=u1, x1b=x1b, qc=qc, kvc=kvc,
+                     cr=cr, lse_c=lse_c, x2=x2, mean2=mean2, rstd2=rstd2, xn2=xn2, hpre=hpre, h=h, u3=u3, kc=kc, vc=vc, sr=sr)
+        return x2, u3, gl, saved
+
+    def block_bwd(self, l, G, sv, ctx):
+        """G: fp32 (R, D) gradient w.r.t. this block's output residual x3 = x2 + gate_mlp*u3; overwritten with the
+        gradient w.r.t. x_in.  Accumulates parameter gradients, d(mod) and d(y_emb)."""
+        S, c = self.S, self.cfg
+        B, N, D, H = ctx["B"], ctx["N"], c["hidden_size"], c["num_heads"]
+        R = B * N
+        p = f"blocks.{l}."
+        mod, dmod = ctx["mod"][l], ctx["dmod"][l]
+        st = 6 * D
+        dev = G.device
+        if sv["sr"] > 1:
+            raise NotImplementedError("backward through KV-compressed attention layers is not implemented yet (DESIGN.md: next)")
+        # ---- MLP branch: x3 = x2 + gate_mlp * u3
+        du = torch.empty((R, D), dtype=BF16, device=dev)
+        ops.gate_bwd(G, u=sv["u3"], gate=mod[:, 5], mod_stride=st, du=du, dgate=dmod[:, 5], dmod_stride=st, rows_per_batch=N)
+        dh = self._lin_bwd(du, sv["h"], p + "mlp.fc2", dx_kw=dict(act=ops.ACT_GELU_GRAD, aux=sv["hpre"]))
+        dxn = self._lin_bwd(dh, sv["xn2"], p + "mlp.fc1")
+        del dh
+        ops.ln_mod_bwd(dxn, sv["x2"], sv["mean2"], sv["rstd2"], mod[:, 4], st, G, G, dmod[:, 3], dmod[:, 4], st, N)
+        # ---- cross attention: x2 = x1 + u2 (no gate, no norm)
+        ops.gate_bwd(G, du=du, rows_per_batch=N)
+        dc = self._lin_bwd(du, sv["cr"], p + "cross_attn.proj")
+        dqc = torch.empty((R, D), dtype=BF16, device=dev)
+        dkvc = torch.empty_like(sv["kvc"])
+        delta = torch.empty((B, H, N), dtype=F32, device=dev)
+        sc_str = ((N * D, D, 72), (0, 2 * D, 72), (0, 2 * D, 72), (N * D, D, 72))
+        ops.attention_bwd(sv["qc"], sv["kvc"][:, :D], sv["kvc"][:, D:], sv["cr"], dc, sv["lse_c"], delta, dqc, dkvc[:, :D], dkvc[:, D:],
+                          B, H, N, ctx["max_len"], sc_str, ((N * D, D, 72), (0, 2 * D, 72), (0, 2 * D, 72)),
+                          kv_start=ctx["kv_start"], kv_len=ctx["kv_len"], max_kv_len=ctx["max_len"])
+        gq = self._lin_bwd(dqc, sv["x1b"], p + "cross_attn.q_linear")
+        self._lin_bwd(dkvc, ctx["ye"], p + "cross_attn.kv_linear", dx_kw=dict(out_f32=ctx["dye"], accumulate=True))
+        # ---- self attention: x1 = x_in + gate_msa * u1 ; G1 = G + gq
+        ops.gate_bwd(G, add=gq, u=sv["u1"], gate=mod[:, 2], mod_stride=st, dx_out=G, du=du, dgate=dmod[:, 2], dmod_stride=st, rows_per_batch=N)
+        da = self._lin_bwd(du, sv["a"], p + "attn.proj")
+        qkv = sv["qkv"]
+        dqkv = torch.empty_like(qkv)
+        s3 = (N * 3 * D, 3 * D, 72)
+        ops.attention_bwd(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], sv["a"], da, sv["lse"], delta, dqkv[:, :D], dqkv[:, D:2 * D], dqkv[:, 2 * D:],
+                          B, H, N, N, (s3, s3, s3, (N * D, D, 72)), (s3, s3, s3))
+        dxn = self._lin_bwd(dqkv, sv["xn1"], p + "attn.qkv")
+        ops.ln_mod_bwd(dxn, sv["x_in"], sv["mean1"], sv["rstd1"], mod[:, 1], st, G, G, dmod[:, 0], dmod[:, 1], st, N)
+        if self.grad_ready_hook:
+            self.grad_ready_hook(f"blocks.{l}")
+        return G
+
+    # ------------------------------------------------------------------ whole core
+    def forward(self, x, y, mod, fin_mod, row_idx, lens, drop, save, y_null=None):
+        """x (B,4,Hl,Wl) fp32, y (B*L,4096) fp32, mod (L,B,6,D) fp32, fin_mod (B,2,D) fp32 -> (out (B,2C,Hl,Wl), saved)."""
+        S, c = self.S, self.cfg
+        B, _, Hl, Wl = x.shape
+        h, w = Hl // 2, Wl // 2
+        N, D, depth = h * w, c["hidden_size"], c["depth"]
+        dev = x.device
+        kv_len = torch.tensor(lens, dtype=torch.int32, device=dev)
+        starts = np.concatenate([[0], np.cumsum(lens)[:-1]]).astype(np.int32)
+        ctx = dict(B=B, N=N, hw=(h, w), mod=mod, kv_len=kv_len, kv_start=torch.from_numpy(starts).to(dev), max_len=int(max(lens)))
+        L = y.shape[0] // B
+        ye, cap_saved = self.caption_fwd(y, row_idx, L, drop, y_null)
+        ctx["ye"] = ye
+        xt = ops.patch_embed_fwd(x, S.f("x_embedder.proj.weight"), S.f("x_embedder.proj.bias"), self.pos_table(h, w))
+        x_prev, u_prev, gate_prev = xt, None, None
+        blocks = []
+        for l in range(depth):
+            x_prev, u_prev, gate_prev, sv = self.block_fwd(l, x_prev, u_prev, gate_prev, ctx)
+            blocks.append(sv if save == "all" else (dict(x_in=sv["x_in"]) if save == "ckpt" else None))
+        r = ops.ln_mod_fwd(x_prev, fin_mod[:, 0], fin_mod[:, 1], 2 * D, u=u_prev, gate=gate_prev, gate_stride=6 * D, rows_per_batch=N, want_stats=True)
+        lin = ops.gemm(r["xn"], S.w("final_layer.linear.weight"), NT, bias=S.f("final_layer.linear.bias"), out_dtype=F32)
+        out = ops.unpatchify_fwd(lin, B, h, w, c["out_channels"])
+        saved = None
+        if save:
+            saved = dict(ctx=ctx, blocks=blocks, cap=cap_saved, x=x, x3=r["x"], meanf=r["mean"], rstdf=r["rstd"], xnf=r["xn"], fin_mod=fin_mod, mode=save)
+        return out, saved
+
+    def backward(self, dout, saved):
+        """dout (B,2C,Hl,Wl) fp32 -> (dmod (L,B,6,D), dfin (B,2,D)); parameter gradients go to the flat buffer."""
+        S, c = self.S, self.cfg
+        ctx = saved["ctx"]
+        B, N, D, depth = ctx["B"], ctx["N"], c["hidden_size"], c["depth"]
+        h, w = ctx["hw"]
+        dev = dout.device
+        ctx["dmod"] = torch.zeros_like(ctx["mod"])
+        dfin = torch.zeros_like(saved["fin_mod"])
+        ctx["dye"] = torch.zeros(ctx["ye"].shape, dtype=F32, device=dev)
+        dlin = ops.patchify_bwd(dout.contiguous(), h, w)
+        dxn = self._lin_bwd(dlin, saved["xnf"], "final_layer.linear")
+        G = torch.empty((B * N, D), dtype=F32, device=dev)
+        ops.ln_mod_bwd(dxn, saved["x3"], saved["meanf"], saved["rstdf"], saved["fin_mod"][:, 1], 2 * D, None, G, dfin[:, 0], dfin[:, 1], 2 * D, N)
+        if self.grad_ready_hook:
+            self.grad_ready_hook("final")
+        for l in reversed(range(depth)):
+            sv = saved["blocks"][l]
+            if saved["mode"] == "ckpt":   # recompute this block's activations from its saved input (auto_grad_checkpoint semantics)
+                sv = self._recompute(l, sv, ctx)
+            G = self.block_bwd(l, G, sv, ctx)
+            saved["blocks"][l] = None
+        ops.patch_embed_bwd(saved["x"], G, S.g("x_embedder.proj.weight"), S.g("x_embedder.proj.bias"))
+        self.caption_bwd(ctx["dye"], saved["cap"])
+        return ctx["dmod"], dfin
+
+    def _recompute(self, l, sv, ctx):
+        """Re-run block l forward from its saved input x_in (x_in already includes the previous block's gated MLP branch)."""
+        return self.block_fwd(l, sv["x_in"], None, None, ctx)[3]

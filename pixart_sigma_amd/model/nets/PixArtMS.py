@@ -1,0 +1,410 @@
+"""PixArtMS / PixArtMSBlock / PixArtMS_XL_2 with the reference's constructor and forward signatures and state-dict keys
+(reference diffusion/model/nets/PixArtMS.py:49-79,85-293; PixArt.py:63-143; PixArt_blocks.py), running on the gfx950
+HIP kernels through pixart_sigma_amd.engine.  nn.Linear / nn.Conv2d / nn.LayerNorm submodules below are *parameter
+containers only* (they give the reference's state_dict names and init); their forward is never called on the hot path.
+
+What stays in PyTorch (fp32, autograd): the per-sample conditioning vectors — sinusoidal timestep features,
+t_embedder MLP, t_block, and the (scale_shift_table + t) broadcasts — i.e. O(B*D) work, <1e-5 of the step FLOPs.
+"""
+import math
+
+import torch
+import torch.nn as nn
+
+from ...engine import Engine, ParamStore
+from ..builder import MODELS
+from ..utils import to_2tuple
+
+F32 = torch.float32
+
+
+# ----------------------------------------------------------------------------- parameter containers
+class _Mlp(nn.Module):  # timm Mlp surface: fc1, act, fc2 (PixArtMS.py:66-67; PixArt_blocks.py:385)
+    def __init__(self, in_features, hidden_features, out_features=None):
+        super().__init__()
+        self.fc1 = nn.Linear(in_features, hidden_features)
+        self.fc2 = nn.Linear(hidden_features, out_features or in_features)
+
+
+class PatchEmbed(nn.Module):  # PixArtMS.py:22-46
+    def __init__(self, patch_size=16, in_chans=3, embed_dim=768, norm_layer=None, flatten=True, bias=True):
+        super().__init__()
+        self.patch_size = to_2tuple(patch_size)
+        self.flatten = flatten
+        self.proj = nn.Conv2d(in_chans, embed_dim, kernel_size=self.patch_size, stride=self.patch_size, bias=bias)
+
+
+class TimestepEmbedder(nn.Module):
+    """PixArt_blocks.py:267-309.  Runs in torch fp32 (tiny); t is NOT rounded to the model dtype first (the reference's
+    `timestep.to(self.dtype)` quantises t under fp16/bf16 — deliberate deviation)."""
+
+    def __init__(self, hidden_size, frequency_embedding_size=256):
+        super().__init__()
+        self.mlp = nn.Sequential(nn.Linear(frequency_embedding_size, hidden_size, bias=True), nn.SiLU(),
+                                 nn.Linear(hidden_size, hidden_size, bias=True))
+        self.frequency_embedding_size = frequency_embedding_size
+
+    @staticmethod
+    def timestep_embedding(t, dim, max_period=10000):
+        half = dim // 2
+        freqs = torch.exp(-math.log(max_period) * torch.arange(start=0, end=half, dtype=torch.float32, device=t.device) / half)
+        args = t[:, None].float() * freqs[None]
+        embedding = torch.cat([torch.cos(args), torch.sin(args)], dim=-1)
+        if dim % 2:
+            embedding = torch.cat([embedding, torch.zeros_like(embedding[:, :1])], dim=-1)
+        return embedding
+
+    def forward(self, t):
+        return self.mlp(self.timestep_embedding(t, self.frequency_embedding_size).to(self.mlp[0].weight.dtype))
+
+
+class SizeEmbedder(TimestepEmbedder):
+    """PixArt_blocks.py:312-344 (alpha-1024 micro-conditioning)."""
+
+    def __init__(self, hidden_size, frequency_embedding_size=256):
+        super().__init__(hidden_size=hidden_size, frequency_embedding_size=frequency_embedding_size)
+        self.outdim = hidden_size
+
+    def forward(self, s, bs):
+        if s.ndim == 1:
+            s = s[:, None]
+        assert s.ndim == 2
+        if s.shape[0] != bs:
+            s = s.repeat(bs // s.shape[0], 1)
+            assert s.shape[0] == bs
+        b, dims = s.shape
+        s_emb = self.mlp(self.timestep_embedding(s.reshape(-1), self.frequency_embedding_size).to(self.mlp[0].weight.dtype))
+        return s_emb.reshape(b, dims * self.outdim)
+
+
+class CaptionEmbedder(nn.Module):  # PixArt_blocks.py:378-407
+    def __init__(self, in_channels, hidden_size, uncond_prob, act_layer=None, token_num=120):
+        super().__init__()
+        self.y_proj = _Mlp(in_channels, hidden_size, hidden_size)
+        self.register_buffer("y_embedding", torch.randn(token_num, in_channels) / in_channels ** 0.5)
+        self.uncond_prob = uncond_prob
+
+
+class AttentionKVCompress(nn.Module):  # PixArt_blocks.py:61-95
+    def __init__(self, dim, num_heads=8, qkv_bias=True, sampling="conv", sr_ratio=1, qk_norm=False, **block_kwargs):
+        super().__init__()
+        assert dim % num_heads == 0
+        self.num_heads, self.scale = num_heads, (dim // num_heads) ** -0.5
+        self.qkv = nn.Linear(dim, dim * 3, bias=qkv_bias)
+        self.proj = nn.Linear(dim, dim)
+        self.sampling, self.sr_ratio = sampling, sr_ratio
+        if sr_ratio > 1 and sampling == "conv":
+            self.sr = nn.Conv2d(dim, dim, groups=dim, kernel_size=sr_ratio, stride=sr_ratio)
+            self.sr.weight.data.fill_(1 / sr_ratio ** 2)
+            self.sr.bias.data.zero_()
+            self.norm = nn.LayerNorm(dim)
+        if qk_norm:
+            raise NotImplementedError("qk_norm=True is not implemented on the HIP path (off in every reference config)")
+
+
+class MultiHeadCrossAttention(nn.Module):  # PixArt_blocks.py:28-41
+    def __init__(self, d_model, num_heads, attn_drop=0.0, proj_drop=0.0, **block_kwargs):
+        super().__init__()
+        assert d_model % num_heads == 0, "d_model must be divisible by num_heads"
+        self.d_model, self.num_heads, self.head_dim = d_model, num_heads, d_model // num_heads
+        self.q_linear = nn.Linear(d_model, d_model)
+        self.kv_linear = nn.Linear(d_model, d_model * 2)
+        self.proj = nn.Linear(d_model, d_model)
+
+
+class T2IFinalLayer(nn.Module):  # PixArt_blocks.py:205-221
+    def __init__(self, hidden_size, patch_size, out_channels):
+        super().__init__()
+        self.linear = nn.Linear(hidden_size, patch_size * patch_size * out_channels, bias=True)
+        self.scale_shift_table = nn.Parameter(torch.randn(2, hidden_size) / hidden_size ** 0.5)
+        self.out_channels = out_channels
+
+
+# ----------------------------------------------------------------------------- autograd bridge
+class _CoreFn(torch.autograd.Function):
+    """The whole token path (patch-embed -> 28 blocks -> final layer -> unpatchify) as one autograd node: forward and
+    backward are the hand-sequenced HIP kernel schedules of engine.Engine.  Differentiable inputs: the modulation tensors.
+    Parameter gradients are accumulated by the kernels directly into the flat gradient buffer (p.grad are views of it)."""
+
+    @staticmethod
+    def forward(ctx, model, x, y2d, mod, fin, row_idx, lens, drop, _anchor):
+        eng = model._engine
+        need = mod.requires_grad or _anchor is not None   # grad mode is off inside Function.forward; the caller decided
+        save = ("ckpt" if getattr(model, "grad_checkpointing", False) else "all") if need else None
+        out, saved = eng.forward(x, y2d, mod.detach(), fin.detach(), row_idx, lens, drop, save,
+                                 y_null=model.y_embedder.y_embedding.to(device=x.device, dtype=F32).contiguous())
+        ctx.model, ctx.saved = model, saved
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        model, saved = ctx.model, ctx.saved
+        ctx.saved = None
+        model._store.attach_grads()
+        dmod, dfin = model._engine.backward(dout.to(F32), saved)
+        return None, None, None, dmod, dfin, None, None, None, None
+
+
+class _BlockFn(torch.autograd.Function):
+    """One PixArtMSBlock as an autograd node (drop-in use of a block outside PixArtMS.forward)."""
+
+    @staticmethod
+    def forward(ctx, block, x, y, t, lens, HW):
+        eng = block._engine_for_standalone()
+        B, N, D = x.shape
+        dev = x.device
+        import numpy as np
+        from ... import ops
+        starts = np.concatenate([[0], np.cumsum(lens)[:-1]]).astype(np.int32)
+        mod = (block.scale_shift_table.detach()[None] + t.detach().reshape(B, 6, D)).contiguous()[None]
+        c = dict(B=B, N=N, hw=HW, mod=mod, kv_len=torch.tensor(lens, dtype=torch.int32, device=dev),
+                 kv_start=torch.from_numpy(starts).to(dev), max_len=int(max(lens)),
+                 ye=y.detach().reshape(-1, D).to(torch.bfloat16).contiguous())
+        x2, u3, gl, sv = eng.block_fwd(0, x.detach().reshape(B * N, D).to(F32).contiguous(), None, None, c)
+        r = ops.ln_mod_fwd(x2, u=u3, gate=gl, gate_stride=6 * D, want_xn=False, rows_per_batch=N)
+        ctx.block, ctx.c, ctx.sv, ctx.shape = block, c, sv, (B, N, D)
+        return r["x"].view(B, N, D)
+
+    @staticmethod
+    def backward(ctx, dout):
+        block, c, sv = ctx.block, ctx.c, ctx.sv
+        B, N, D = ctx.shape
+        eng = block._engine_for_standalone()
+        eng.S.attach_grads()
+        c["dmod"] = torch.zeros_like(c["mod"])
+        c["dye"] = torch.zeros(c["ye"].shape, dtype=F32, device=dout.device)
+        G = eng.block_bwd(0, dout.to(F32).reshape(B * N, D).contiguous().clone(), sv, c)
+        dmod = c["dmod"][0]                                   # (B,6,D): d(table + t)
+        block.scale_shift_table.grad.add_(dmod.sum(0))
+        return None, G.view(B, N, D), c["dye"].view(1, -1, D), dmod.reshape(B, 6 * D), None, None
+
+
+# ----------------------------------------------------------------------------- modules
+class PixArtMSBlock(nn.Module):
+    """A PixArt block with adaLN-single conditioning (PixArtMS.py:49-79)."""
+
+    def __init__(self, hidden_size, num_heads, mlp_ratio=4.0, drop_path=0.0, input_size=None, sampling=None, sr_ratio=1,
+                 qk_norm=False, **block_kwargs):
+        super().__init__()
+        assert drop_path == 0.0, "stochastic depth is 0 in every PixArt config; not implemented on the HIP path"
+        self.hidden_size, self.num_heads = hidden_size, num_heads
+        self.attn = AttentionKVCompress(hidden_size, num_heads=num_heads, qkv_bias=True, sampling=sampling, sr_ratio=sr_ratio,
+                                        qk_norm=qk_norm, **block_kwargs)
+        self.cross_attn = MultiHeadCrossAttention(hidden_size, num_heads, **block_kwargs)
+        self.mlp = _Mlp(hidden_size, int(hidden_size * mlp_ratio))
+        self.scale_shift_table = nn.Parameter(torch.randn(6, hidden_size) / hidden_size ** 0.5)
+        self._standalone = None
+
+    def _engine_for_standalone(self):
+        dev = self.scale_shift_table.device
+        if self._standalone is None or self._standalone.S.device != dev:
+            named = [("blocks.0." + n, p) for n, p in self.named_parameters()]
+            store = ParamStore(named, dev)
+            a = self.attn
+            cfg = dict(hidden_size=self.hidden_size, num_heads=self.num_heads, depth=1, kv_sampling=a.sampling,
+                       kv_scale_factor=a.sr_ratio, kv_layers=(0,) if a.sr_ratio > 1 else ())
+            self._standalone = Engine(store, cfg)
+        self._standalone.S.refresh_shadow()
+        return self._standalone
+
+    def forward(self, x, y, t, mask=None, HW=None, **kwargs):
+        """x (B,N,C) ; y packed text (1, sum(lens), C) ; t = t0 (B, 6C) ; mask = list of per-sample text lengths
+        (what PixArtMS.forward passes as y_lens) ; HW = token grid."""
+        B, N, C = x.shape
+        lens = [int(v) for v in mask] if mask is not None else [y.shape[1] // B] * B
+        if HW is None:
+            HW = (int(N ** 0.5), int(N ** 0.5))
+        return _BlockFn.apply(self, x, y, t, lens, tuple(HW))
+
+
+@MODELS.register_module()
+class PixArtMS(nn.Module):
+    """Diffusion model with a Transformer backbone (PixArtMS.py:85-285; parent ctor PixArt.py:63-143)."""
+
+    def __init__(self, input_size=32, patch_size=2, in_channels=4, hidden_size=1152, depth=28, num_heads=16, mlp_ratio=4.0,
+                 class_dropout_prob=0.1, learn_sigma=True, pred_sigma=True, drop_path: float = 0.0, caption_channels=4096,
+                 pe_interpolation=1.0, config=None, model_max_length=120, micro_condition=False, qk_norm=False,
+                 kv_compress_config=None, **kwargs):
+        super().__init__()
+        assert patch_size == 2 and in_channels == 4, "HIP patch-embed kernel is specialised for the PixArt latent (C=4, p=2)"
+        assert hidden_size // num_heads == 72, "HIP attention kernels are specialised for head_dim 72 (XL/2)"
+        self.pred_sigma = pred_sigma
+        self.in_channels = in_channels
+        self.out_channels = in_channels * 2 if pred_sigma else in_channels
+        self.patch_size = patch_size
+        self.num_heads = num_heads
+        self.pe_interpolation = pe_interpolation
+        self.depth = depth
+        self.hidden_size = hidden_size
+        self.base_size = input_size // self.patch_size
+        self.h = self.w = 0
+        self.register_buffer("pos_embed", torch.zeros(1, (input_size // patch_size) ** 2, hidden_size))  # state-dict compat (dropped on load)
+        self.x_embedder = PatchEmbed(patch_size, in_channels, hidden_size, bias=True)
+        self.t_embedder = TimestepEmbedder(hidden_size)
+        self.t_block = nn.Sequential(nn.SiLU(), nn.Linear(hidden_size, 6 * hidden_size, bias=True))
+        self.y_embedder = CaptionEmbedder(in_channels=caption_channels, hidden_size=hidden_size, uncond_prob=class_dropout_prob,
+                                          token_num=model_max_length)
+        self.micro_conditioning = micro_condition
+        if self.micro_conditioning:
+            self.csize_embedder = SizeEmbedder(hidden_size // 3)
+            self.ar_embedder = SizeEmbedder(hidden_size // 3)
+        if kv_compress_config is None:
+            kv_compress_config = {"sampling": None, "scale_factor": 1, "kv_compress_layer": []}
+        self.kv_compress_config = kv_compress_config
+        self.blocks = nn.ModuleList([
+            PixArtMSBlock(hidden_size, num_heads, mlp_ratio=mlp_ratio, drop_path=0.0,
+                          input_size=(input_size // patch_size, input_size // patch_size),
+                          sampling=kv_compress_config["sampling"],
+                          sr_ratio=int(kv_compress_config["scale_factor"]) if i in kv_compress_config["kv_compress_layer"] else 1,
+                          qk_norm=qk_norm)
+            for i in range(depth)])
+        self.final_layer = T2IFinalLayer(hidden_size, patch_size, self.out_channels)
+        self._store = self._engine = None
+        self._anchor = None
+        self.initialize()
+
+    # ---- reference init scheme (PixArtMS.py:250-285)
+    def initialize(self):
+        def _basic_init(module):
+            if isinstance(module, nn.Linear):
+                torch.nn.init.xavier_uniform_(module.weight)
+                if module.bias is not None:
+                    nn.init.constant_(module.bias, 0)
+        self.apply(_basic_init)
+        w = self.x_embedder.proj.weight.data
+        nn.init.xavier_uniform_(w.view([w.shape[0], -1]))
+        nn.init.normal_(self.t_embedder.mlp[0].weight, std=0.02)
+        nn.init.normal_(self.t_embedder.mlp[2].weight, std=0.02)
+        nn.init.normal_(self.t_block[1].weight, std=0.02)
+        if self.micro_conditioning:
+            for e in (self.csize_embedder, self.ar_embedder):
+                nn.init.normal_(e.mlp[0].weight, std=0.02)
+                nn.init.normal_(e.mlp[2].weight, std=0.02)
+        nn.init.normal_(self.y_embedder.y_proj.fc1.weight, std=0.02)
+        nn.init.normal_(self.y_embedder.y_proj.fc2.weight, std=0.02)
+        for block in self.blocks:
+            nn.init.constant_(block.cross_attn.proj.weight, 0)
+            nn.init.constant_(block.cross_attn.proj.bias, 0)
+        nn.init.constant_(self.final_layer.linear.weight, 0)
+        nn.init.constant_(self.final_layer.linear.bias, 0)
+
+    @property
+    def dtype(self):
+        return next(self.parameters()).dtype
+
+    def load_state_dict(self, state_dict, strict=True, **kw):
+        sd = {k: v for k, v in state_dict.items() if k != "pos_embed"}   # checkpoint.py:54-57 drops it too
+        res = super().load_state_dict(sd, strict=False, **kw)
+        missing = [k for k in res.missing_keys if k != "pos_embed"]
+        if strict and (missing or res.unexpected_keys):
+            raise RuntimeError(f"load_state_dict: missing {missing}, unexpected {res.unexpected_keys}")
+        return res
+
+    # ---- engine plumbing
+    def _ordered_named_params(self):
+        """Flat order = gradient buckets in forward order: 'cond' (embedders + every scale_shift_table: the parameters whose
+        gradients PyTorch autograd finishes after the token path), blocks.0 .. blocks.L-1, 'final'."""
+        named = dict(self.named_parameters())
+        groups = ["x_embedder.", "t_embedder.", "t_block.", "y_embedder.", "csize_embedder.", "ar_embedder."]
+        order = [n for g in groups for n in named if n.startswith(g)]
+        order += [n for n in named if n.endswith("scale_shift_table")]
+        for i in range(self.depth):
+            order += [n for n in named if n.startswith(f"blocks.{i}.") and not n.endswith("scale_shift_table")]
+        order += [n for n in named if n.startswith("final_layer.") and not n.endswith("scale_shift_table")]
+        assert len(order) == len(named) == len(set(order))
+        return [(n, named[n]) for n in order]
+
+    @staticmethod
+    def _group_of(name):
+        if name.endswith("scale_shift_table") or not (name.startswith("blocks.") or name.startswith("final_layer.")):
+            return "cond"
+        return "final" if name.startswith("final_layer.") else ".".join(name.split(".")[:2])
+
+    def prepare(self, device=None):
+        """Build (or re-bind) the flat parameter store / engine on `device`; called automatically by forward."""
+        self._prepare(torch.device(device) if device is not None else next(self.parameters()).device)
+        return self
+
+    def _prepare(self, device):
+        named = self._ordered_named_params()
+        first_name, first_p = named[0]
+        if self._store is None or self._store.device != device or not self._store.owns(first_p, first_name):
+            if any(p.dtype != F32 for _, p in named):
+                raise RuntimeError("pixart_sigma_amd keeps fp32 master weights (bf16 shadows are maintained internally); "
+                                   "do not call .half()/.bfloat16() on the model")
+            self._store = ParamStore(named, device, group_of=self._group_of)
+            kvc = self.kv_compress_config
+            cfg = dict(hidden_size=self.hidden_size, num_heads=self.num_heads, depth=self.depth, pe_interpolation=self.pe_interpolation,
+                       base_size=self.base_size, out_channels=self.out_channels, kv_sampling=kvc["sampling"],
+                       kv_scale_factor=int(kvc["scale_factor"]), kv_layers=tuple(kvc["kv_compress_layer"]))
+            self._engine = Engine(self._store, cfg)
+            self._anchor = torch.zeros(1, device=device, requires_grad=True)
+        self._store.refresh_shadow()
+
+    # ---- forward (PixArtMS.py:165-211)
+    def forward(self, x, timestep, y, mask=None, data_info=None, **kwargs):
+        """x: (N, C, H, W) latent; timestep: (N,); y: (N, 1, L, C_caption); mask: (N, L) | (N,1,1,L) | None.
+        Returns (N, 2C, H, W) fp32."""
+        assert x.is_cuda, "pixart_sigma_amd.PixArtMS runs on the MI355X HIP kernels only (no CPU path; use oracle/ for CPU checks)"
+        dev = x.device
+        self._prepare(dev)
+        bs = x.shape[0]
+        x = x.to(F32).contiguous()
+        timestep = timestep.to(device=dev, dtype=F32)
+        self.h, self.w = x.shape[-2] // self.patch_size, x.shape[-1] // self.patch_size
+        D = self.hidden_size
+        t = self.t_embedder(timestep)                                                   # (N, D)
+        if self.micro_conditioning:
+            c_size, ar = data_info["img_hw"].to(dev, F32), data_info["aspect_ratio"].to(dev, F32)
+            t = t + torch.cat([self.csize_embedder(c_size, bs), self.ar_embedder(ar, bs)], dim=1)
+        t0 = self.t_block(t)                                                            # (N, 6D)
+        tables = torch.stack([b.scale_shift_table for b in self.blocks])                # (L, 6, D)
+        mod = (tables[:, None] + t0.reshape(bs, 6, D)[None]).contiguous()               # PixArtMS.py:74, all blocks at once
+        fin = (self.final_layer.scale_shift_table[None] + t[:, None]).contiguous()      # PixArt_blocks.py:218
+        L = y.shape[-2]
+        assert y.shape[0] == bs, "caption batch must match the latent batch"
+        y2d = y.reshape(bs * L, y.shape[-1]).to(device=dev, dtype=F32).contiguous()
+        if mask is not None:
+            m = mask.reshape(mask.shape[0], -1)
+            if m.shape[0] != bs:
+                m = m.repeat(bs // m.shape[0], 1)
+            m = (m != 0)
+            lens = m.sum(dim=1).tolist()                                                 # same host sync as PixArtMS.py:201
+            row_idx = m.flatten().nonzero().flatten().to(device=dev, dtype=torch.int32)
+        else:
+            lens = [L] * bs
+            row_idx = torch.arange(bs * L, device=dev, dtype=torch.int32)
+        drop = None
+        if self.training:
+            assert tuple(y.shape[2:]) == tuple(self.y_embedder.y_embedding.shape)       # PixArt_blocks.py:401-402
+            if self.y_embedder.uncond_prob > 0:                                         # token_drop, PixArt_blocks.py:389-398 (CPU RNG draw)
+                drop = (torch.rand(bs) < self.y_embedder.uncond_prob).to(device=dev, dtype=torch.int32)
+        anchor = self._anchor if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()) else None
+        return _CoreFn.apply(self, x, y2d, mod, fin, row_idx, lens, drop, anchor)
+
+    def forward_with_dpmsolver(self, x, timestep, y, data_info, **kwargs):
+        """dpm solver does not need the variance prediction (PixArtMS.py:213-219)."""
+        model_out = self.forward(x, timestep, y, data_info=data_info, **kwargs)
+        return model_out.chunk(2, dim=1)[0]
+
+    def forward_with_cfg(self, x, timestep, y, cfg_scale, data_info, mask=None, **kwargs):
+        """PixArtMS.py:221-234 (CFG mix on the first 3 channels, GLIDE legacy)."""
+        half = x[: len(x) // 2]
+        combined = torch.cat([half, half], dim=0)
+        model_out = self.forward(combined, timestep, y, mask, data_info=data_info, **kwargs)
+        eps, rest = model_out[:, :3], model_out[:, 3:]
+        cond_eps, uncond_eps = torch.split(eps, len(eps) // 2, dim=0)
+        half_eps = uncond_eps + cfg_scale * (cond_eps - uncond_eps)
+        eps = torch.cat([half_eps, half_eps], dim=0)
+        return torch.cat([eps, rest], dim=1)
+
+    def unpatchify(self, x):
+        """x: (N, T, patch_size**2 * C) -> (N, C, H, W)  (PixArtMS.py:236-248); HIP kernel, fp32."""
+        from ... import ops
+        assert self.h * self.w == x.shape[1]
+        return ops.unpatchify_fwd(x.to(F32).contiguous().view(-1, x.shape[-1]), x.shape[0], self.h, self.w, self.out_channels)
+
+
+@MODELS.register_module()
+def PixArtMS_XL_2(**kwargs):
+    return PixArtMS(depth=28, hidden_size=1152, patch_size=2, num_heads=16, **kwargs)

@@ -64,7 +64,7 @@ def gemm(a, b, layout=NT, bias=None, act=ACT_NONE, aux=None, out=None, out2=None
     return out_f32 if want_f32 else out
 
 
-def ln_mod_fwd(x, shift=None, scale=None, mod_stride=0, u=None, gate=None, x_out=None, want_xn=True, want_xb=False,
+def ln_mod_fwd(x, shift=None, scale=None, mod_stride=0, u=None, gate=None, gate_stride=None, x_out=None, want_xn=True, want_xb=False,
                want_stats=False, rows_per_batch=None, eps=1e-6):
     """x' = x + gate*u; xn = LN(x')*(1+scale)+shift.  x: (R,D) fp32.  shift/scale/gate: fp32 views whose sample b
     starts at data_ptr + b*mod_stride floats.  Returns dict(x, xn, xb, mean, rstd)."""
@@ -77,7 +77,7 @@ def ln_mod_fwd(x, shift=None, scale=None, mod_stride=0, u=None, gate=None, x_out
     rstd = torch.empty(R, dtype=F32, device=x.device) if want_stats else None
     if u is not None and x_out is None:
         x_out = torch.empty_like(x)
-    call("pxa_ln_mod_fwd", ptr(x), ptr(u), ptr(gate), ptr(shift), ptr(scale), mod_stride, ptr(x_out), ptr(xn), ptr(xb),
+    call("pxa_ln_mod_fwd", ptr(x), ptr(u), ptr(gate), mod_stride if gate_stride is None else gate_stride, ptr(shift), ptr(scale), mod_stride, ptr(x_out), ptr(xn), ptr(xb),
          ptr(mean), ptr(rstd), R, D, rpb, eps)
     return {"x": x_out if x_out is not None else x, "xn": xn, "xb": xb, "mean": mean, "rstd": rstd}
 

@@ -1,0 +1,105 @@
+"""CPU tests of the host-side logic around the HIP path: the diffusion loss and DPM-Solver loop (run here with the
+oracle denoiser as the model callable, against the reference-generated goldens), the positional table, the registry,
+state-dict compatibility, and the flat parameter store."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import rel_l2
+from oracle import pixart_oracle as po
+from oracle.weights import make_inputs, make_state_dict, param_shapes
+
+
+def _setup(g):
+    cfg = po.OracleCfg(**g["cfg"])
+    sd = make_state_dict(cfg, seed=g["weights_seed"])
+    inp = make_inputs(seed=g["inputs_seed"], **g["inputs"])
+    return cfg, sd, inp, inp["mask"] if g["inputs"].get("lens") is not None else None
+
+
+def test_training_losses_host_code_matches_reference(golden):
+    from pixart_sigma_amd.diffusion import IDDPM
+    g = golden("train_d2")
+    cfg, sd, inp, mask = _setup(g)
+    diff = IDDPM(str(1000), learn_sigma=True, pred_sigma=True, snr=False)
+    model = lambda x, timestep, **kw: po.forward(sd, cfg, x, timestep, inp["y"], mask)
+    with torch.no_grad():
+        terms = diff.training_losses(model, inp["x"], g["t"], model_kwargs={}, noise=inp["noise"])
+    for k in ("loss", "mse", "vb"):
+        assert torch.allclose(terms[k], g[k], rtol=2e-5, atol=1e-6), k
+
+
+def test_dpm_solver_host_code_matches_reference(golden):
+    from pixart_sigma_amd.diffusion import DPMS
+    g = golden("dpms_d2")
+    cfg, sd, inp, mask = _setup(g)
+    gen = torch.Generator().manual_seed(g["null_seed"])
+    null_y = torch.randn(1, 1, g["inputs"]["L"], 4096, generator=gen).repeat(inp["x"].shape[0], 1, 1, 1)
+    model = lambda x, t, y, mask=None, **kw: po.forward_with_dpmsolver(sd, cfg, x, t, y, mask)
+    s = DPMS(model, condition=inp["y"], uncondition=null_y, cfg_scale=4.5, model_kwargs=dict(mask=mask)).sample(
+        inp["x"], steps=2, order=2, skip_type="time_uniform", method="multistep")
+    assert rel_l2(s, g["sample"]) < 5e-5
+
+
+def test_dpm_solver_20_steps_runs_and_is_finite():
+    from pixart_sigma_amd.diffusion import DPMS
+    model = lambda x, t, y, **kw: 0.1 * x + 0.01 * y.mean()
+    z = torch.randn(2, 4, 8, 8, generator=torch.Generator().manual_seed(0))
+    s = DPMS(model, condition=torch.ones(2, 1), uncondition=torch.zeros(2, 1), cfg_scale=4.5).sample(z, steps=20, order=2)
+    assert torch.isfinite(s).all()
+
+
+def test_pos_table_matches_reference(golden):
+    from pixart_sigma_amd.engine import sincos_pos_embed
+    g = golden("tables")
+    for (h, w, pe, base), ref in g["pos"].items():
+        tab = sincos_pos_embed(1152, h, w, pe, base)
+        assert np.array_equal(tab[:: max(1, (h * w) // 37)], ref.numpy())
+
+
+def test_registry_and_state_dict_keys_match_reference():
+    """Constructor surface + state-dict wire format (tools/convert_pixart_to_diffusers.py:29-155)."""
+    from pixart_sigma_amd import MODELS, build_model
+    kv = {"sampling": "conv", "scale_factor": 2, "kv_compress_layer": [1]}
+    m = build_model("PixArtMS", depth=2, hidden_size=1152, num_heads=16, input_size=16, model_max_length=20, kv_compress_config=kv,
+                    use_grad_checkpoint=True, use_fp32_attention=True, gc_step=1)
+    assert MODELS.get("PixArtMS_XL_2") is not None
+    cfg = po.OracleCfg(depth=2, input_size=16, model_max_length=20, kv_sampling="conv", kv_scale_factor=2, kv_layers=(1,))
+    want = {k: tuple(s) for k, s in param_shapes(cfg).items()}
+    want["pos_embed"] = (1, 64, 1152)
+    got = {k: tuple(v.shape) for k, v in m.state_dict().items()}
+    assert got == want
+    assert m.grad_checkpointing and m.blocks[0].fp32_attention
+    m.load_state_dict(make_state_dict(cfg, seed=0))
+    # reference init invariants (PixArtMS.py:278-285, PixArt_blocks.py:86-88)
+    m2 = build_model("PixArtMS", depth=1, hidden_size=1152, num_heads=16, input_size=16, kv_compress_config={"sampling": "conv", "scale_factor": 2, "kv_compress_layer": [0]})
+    assert m2.final_layer.linear.weight.abs().max() == 0 and m2.blocks[0].cross_attn.proj.weight.abs().max() == 0
+    assert torch.all(m2.blocks[0].attn.sr.weight == 0.25)
+
+
+def test_xl2_parameter_count():
+    from pixart_sigma_amd.model.nets import PixArtMS
+    with torch.device("meta"):
+        m = PixArtMS(depth=28, hidden_size=1152, patch_size=2, num_heads=16, input_size=128)
+    assert sum(p.numel() for p in m.parameters()) == 610856096  # reference notebook known answer
+
+
+def test_param_store_flat_views_cpu():
+    from pixart_sigma_amd.engine import ParamStore
+    lin1, lin2 = torch.nn.Linear(8, 6), torch.nn.Linear(6, 3)
+    named = [("a.weight", lin1.weight), ("a.bias", lin1.bias), ("b.weight", lin2.weight), ("b.bias", lin2.bias)]
+    w0 = lin1.weight.detach().clone()
+    st = ParamStore(named, torch.device("cpu"))
+    assert torch.equal(lin1.weight, w0) and lin1.weight.data_ptr() == st.master.data_ptr()
+    assert st.range_of("a.") == (0, 128) and st.range_of("b.") == (128, 256)
+    lin2(lin1(torch.ones(2, 8))).sum().backward()            # autograd accumulates into the flat views
+    assert st.grad[: 48].abs().sum() > 0 and lin1.weight.grad.data_ptr() == st.grad.data_ptr()
+    lin1.weight.grad = None
+    assert st.attach_grads() and lin1.weight.grad.data_ptr() == st.grad.data_ptr()
+
+
+def test_model_refuses_cpu_forward():
+    from pixart_sigma_amd.model.nets import PixArtMS
+    m = PixArtMS(depth=1, hidden_size=1152, num_heads=16, input_size=8, model_max_length=4)
+    with pytest.raises(AssertionError, match="HIP kernels only"):
+        m(torch.zeros(1, 4, 8, 8), torch.zeros(1), torch.zeros(1, 1, 4, 4096))
