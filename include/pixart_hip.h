@@ -49,7 +49,7 @@ typedef struct {
   void* out_bf16; void* out2_bf16; int ld_out;
   float* out_f32; int ld_f32;
   int accumulate;                /* out_f32: 0 = store, 1 = atomicAdd (gradient accumulation / split-K) */
-  int split_k;                   /* >1 only with accumulate */
+  int split_k;                   /* >1 only with accumulate; 0 = library picks tile shape and split for the dW case */
 } pxa_gemm_args;
 int pxa_gemm(const pxa_gemm_args* args, hipStream_t stream);
 

@@ -21,8 +21,16 @@ using namespace pxa;
 constexpr int DH = 72;
 constexpr int NCH = DH / 8;          // 9 16-byte chunks per head row
 constexpr int KSTEPS = 5;            // ceil(72/16)
-constexpr int S80 = 160;             // LDS row stride (bytes) of a [..][80] tile (b128 reads only)
-constexpr int S96 = 192;             // LDS row stride (bytes) of a [..][96] tile (b128 + transpose reads)
+// LDS tile layouts (row-major [64 rows][head_dim], 16-byte chunks), both conflict-free for their read patterns:
+//   LIN : stride 176 B (11 chunks: 9 data + zero pad).  ds_read_b128 serves 16-lane groups whose rows cover all residues
+//         mod 16; 11 is odd, so the 16 rows hit 16 distinct 16-byte slots of the 256-byte bank row.
+//   SWZ : stride 192 B (12 chunks: 9 data + 3 zero pad), chunk index XOR ((row>>2)&3).  The transpose reads
+//         (ds_read_b64_tr_b16) take 4 consecutive rows x 64 B per 32-lane group: 192 B = 48 banks puts the 4 rows on the
+//         4 disjoint 16-bank quarters, and the XOR (constant over an aligned group of 4 rows, closed on aligned groups of
+//         4 chunks) only permutes inside each row's 64-byte window.  For ds_read_b128 the same XOR separates the rows
+//         r, r+4, r+8, r+12 that a bare 192-byte stride would pile onto one slot (4-way conflict).
+constexpr int S_LIN = 176;
+constexpr int S_SWZ = 192;
 constexpr int BKV = 64;
 
 struct AttnParams {
@@ -48,20 +56,36 @@ __device__ __forceinline__ void kv_range(const AttnParams& p, int b, long& kbase
   }
 }
 
-// stage a [64][72] bf16 tile (rows row0..row0+63 of a strided matrix, zero beyond `nrows`) into LDS with row stride `ls`
-__device__ __forceinline__ void stage_tile(char* lds, int ls, const bf16_t* __restrict__ src, long ts, int row0, int nrows, int tid) {
-  for (int c = tid; c < BKV * NCH; c += 256) {
-    const int r = c / NCH, ch = c - r * NCH;
-    uint4 v = make_uint4(0, 0, 0, 0);
-    if (row0 + r < nrows) v = *reinterpret_cast<const uint4*>(src + (long)(row0 + r) * ts + ch * 8);
-    *reinterpret_cast<uint4*>(lds + r * ls + ch * 16) = v;
+template <bool SWZ>
+__device__ __forceinline__ int soff(int r, int c) {  // byte offset of chunk c of row r
+  return SWZ ? r * S_SWZ + ((c ^ ((r >> 2) & 3)) << 4) : r * S_LIN + (c << 4);
+}
+constexpr int TILE_CH = BKV * NCH;                     // 576 16-byte chunks per [64][72] tile
+constexpr int PF = (TILE_CH + 255) / 256;              // 3 chunks per thread
+
+// global -> registers for tile rows row0..row0+63 (zero beyond nrows); issued one tile ahead of its use
+__device__ __forceinline__ void tile_g2r(uint4 (&reg)[PF], const bf16_t* __restrict__ src, long ts, int row0, int nrows, int tid) {
+#pragma unroll
+  for (int i = 0; i < PF; i++) {
+    const int c = tid + 256 * i, r = c / NCH, ch = c - r * NCH;
+    reg[i] = make_uint4(0, 0, 0, 0);
+    if (c < TILE_CH && row0 + r < nrows) reg[i] = *reinterpret_cast<const uint4*>(src + (long)(row0 + r) * ts + ch * 8);
   }
 }
-__device__ __forceinline__ void zero_pad(char* lds, int ls, int tid) {  // chunks 9.. of every row
-  const int npad = ls / 16 - NCH;
+template <bool SWZ>
+__device__ __forceinline__ void tile_r2s(char* lds, const uint4 (&reg)[PF], int tid) {
+#pragma unroll
+  for (int i = 0; i < PF; i++) {
+    const int c = tid + 256 * i, r = c / NCH, ch = c - r * NCH;
+    if (c < TILE_CH) *reinterpret_cast<uint4*>(lds + soff<SWZ>(r, ch)) = reg[i];
+  }
+}
+template <bool SWZ>
+__device__ __forceinline__ void zero_pad(char* lds, int tid) {  // chunks 9.. of every row (never overwritten afterwards)
+  constexpr int npad = (SWZ ? S_SWZ : S_LIN) / 16 - NCH;
   for (int c = tid; c < BKV * npad; c += 256) {
     const int r = c / npad, ch = NCH + (c - r * npad);
-    *reinterpret_cast<uint4*>(lds + r * ls + ch * 16) = make_uint4(0, 0, 0, 0);
+    *reinterpret_cast<uint4*>(lds + soff<SWZ>(r, ch)) = make_uint4(0, 0, 0, 0);
   }
 }
 // B-operand fragments of a row held in registers: X[row][ks*16 + 8*hi .. +8], zero for d >= 72 or invalid row
@@ -75,16 +99,17 @@ __device__ __forceinline__ void load_row_frags(bf16x8 (&f)[KSTEPS], const bf16_t
   }
 }
 // A-operand from a row-major tile: rows sub*32 + (lane&31), k = d
-__device__ __forceinline__ bf16x8 rowfrag(const char* lds, int ls, int sub, int ks, int lane) {
-  return *reinterpret_cast<const bf16x8*>(lds + (sub * 32 + (lane & 31)) * ls + (ks * 2 + (lane >> 5)) * 16);
+template <bool SWZ>
+__device__ __forceinline__ bf16x8 rowfrag(const char* lds, int sub, int ks, int lane) {
+  return *reinterpret_cast<const bf16x8*>(lds + soff<SWZ>(sub * 32 + (lane & 31), ks * 2 + (lane >> 5)));
 }
-// A-operand X^T[d = dt*32 + (lane&31)][k-slots of step u] from a row-major [row][d] tile (stride S96) via transpose reads.
+// A-operand X^T[d = dt*32 + (lane&31)][k-slots of step u] from a SWZ row-major [row][d] tile via transpose reads.
 // slot j <-> row 16u + (j&3) + 8*(j>>2) + 4*hi : the same permutation the accumulator layout gives the B operand.
 __device__ __forceinline__ bf16x8 trfrag(const char* lds, int dt, int u, int lane) {
   const int gg = lane >> 4, tt = lane & 15, hi = gg >> 1;
-  const int row = 16 * u + 4 * hi + (tt >> 2), col = dt * 32 + 16 * (gg & 1) + (tt & 3) * 4;
-  const char* p = lds + row * S96 + col * 2;
-  return concat_tr(lds_tr_read(p), lds_tr_read(p + 8 * S96));
+  const int row = 16 * u + 4 * hi + (tt >> 2);
+  const int c = dt * 4 + 2 * (gg & 1) + ((tt & 3) >> 1), sub8 = (tt & 1) * 8;
+  return concat_tr(lds_tr_read(lds + soff<true>(row, c) + sub8), lds_tr_read(lds + soff<true>(row + 8, c) + sub8));
 }
 __device__ __forceinline__ bf16x8 pack8(const f32x16& v, int off) {
   bf16x8 r;
@@ -112,8 +137,8 @@ __device__ __forceinline__ void zero3(f32x16 (&a)[3]) {
 
 // ------------------------------------------------------------------------------------------------ forward
 __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
-  __shared__ __attribute__((aligned(16))) char ldsK[BKV * S80];
-  __shared__ __attribute__((aligned(16))) char ldsV[BKV * S96];
+  __shared__ __attribute__((aligned(16))) char ldsK[BKV * S_LIN];
+  __shared__ __attribute__((aligned(16))) char ldsV[BKV * S_SWZ];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hi = lane >> 5;
   const int b = blockIdx.z, h = blockIdx.y;
   const int q = blockIdx.x * 128 + wave * 32 + (lane & 31);
@@ -125,26 +150,33 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
 
   bf16x8 qf[KSTEPS];
   load_row_frags(qf, p.Q + (long)b * p.q_bs + (long)q * p.q_ts + (long)h * p.q_hs, qvalid, hi);
-  zero_pad(ldsK, S80, tid);
-  zero_pad(ldsV, S96, tid);
+  zero_pad<false>(ldsK, tid);
+  zero_pad<true>(ldsV, tid);
 
   f32x16 o[3];
   zero3(o);
   float m = -INFINITY, l = 0.f;
   const float c = p.scale_log2;
+  uint4 rk[PF], rv[PF];
+  tile_g2r(rk, Kp, p.k_ts, 0, kvlen, tid);
+  tile_g2r(rv, Vp, p.v_ts, 0, kvlen, tid);
 
   for (int kv0 = 0; kv0 < kvlen; kv0 += BKV) {
+    __syncthreads();                       // every wave is done reading the previous tile
+    tile_r2s<false>(ldsK, rk, tid);
+    tile_r2s<true>(ldsV, rv, tid);
     __syncthreads();
-    stage_tile(ldsK, S80, Kp, p.k_ts, kv0, kvlen, tid);
-    stage_tile(ldsV, S96, Vp, p.v_ts, kv0, kvlen, tid);
-    __syncthreads();
+    if (kv0 + BKV < kvlen) {               // next tile's HBM/L2 latency hides under this tile's MFMAs
+      tile_g2r(rk, Kp, p.k_ts, kv0 + BKV, kvlen, tid);
+      tile_g2r(rv, Vp, p.v_ts, kv0 + BKV, kvlen, tid);
+    }
     f32x16 s[2];
 #pragma unroll
     for (int sub = 0; sub < 2; sub++) {
 #pragma unroll
       for (int g = 0; g < 16; g++) s[sub][g] = 0.f;
 #pragma unroll
-      for (int ks = 0; ks < KSTEPS; ks++) s[sub] = mfma32(rowfrag(ldsK, S80, sub, ks, lane), qf[ks], s[sub]);
+      for (int ks = 0; ks < KSTEPS; ks++) s[sub] = mfma32(rowfrag<false>(ldsK, sub, ks, lane), qf[ks], s[sub]);
     }
     if (kv0 + BKV > kvlen) {
 #pragma unroll
@@ -215,9 +247,12 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* __restric
 }
 
 // ------------------------------------------------------------------------------------------------ backward: dQ
-__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnParams p) {
-  __shared__ __attribute__((aligned(16))) char ldsK[BKV * S96];
-  __shared__ __attribute__((aligned(16))) char ldsV[BKV * S80];
+#ifndef ATTN_BWD_WAVES
+#define ATTN_BWD_WAVES 1
+#endif
+__global__ __launch_bounds__(256, ATTN_BWD_WAVES) void attn_bwd_dq_kernel(AttnParams p) {
+  __shared__ __attribute__((aligned(16))) char ldsK[BKV * S_SWZ];
+  __shared__ __attribute__((aligned(16))) char ldsV[BKV * S_LIN];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hi = lane >> 5;
   const int b = blockIdx.z, h = blockIdx.y;
   const int q = blockIdx.x * 128 + wave * 32 + (lane & 31);
@@ -233,17 +268,24 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnParams p) {
   const long sidx = ((long)b * p.H + h) * p.Nq + q;
   const float lse = qvalid ? p.LSE[sidx] : 0.f;
   const float delta = qvalid ? p.Delta[sidx] : 0.f;
-  zero_pad(ldsK, S96, tid);
-  zero_pad(ldsV, S80, tid);
+  zero_pad<true>(ldsK, tid);
+  zero_pad<false>(ldsV, tid);
 
   f32x16 dq[3];
   zero3(dq);
   const float c = p.scale_log2;
+  uint4 rk[PF], rv[PF];
+  tile_g2r(rk, Kp, p.k_ts, 0, kvlen, tid);
+  tile_g2r(rv, Vp, p.v_ts, 0, kvlen, tid);
   for (int kv0 = 0; kv0 < kvlen; kv0 += BKV) {
     __syncthreads();
-    stage_tile(ldsK, S96, Kp, p.k_ts, kv0, kvlen, tid);
-    stage_tile(ldsV, S80, Vp, p.v_ts, kv0, kvlen, tid);
+    tile_r2s<true>(ldsK, rk, tid);
+    tile_r2s<false>(ldsV, rv, tid);
     __syncthreads();
+    if (kv0 + BKV < kvlen) {
+      tile_g2r(rk, Kp, p.k_ts, kv0 + BKV, kvlen, tid);
+      tile_g2r(rv, Vp, p.v_ts, kv0 + BKV, kvlen, tid);
+    }
     f32x16 s[2], dp[2];
 #pragma unroll
     for (int sub = 0; sub < 2; sub++) {
@@ -251,8 +293,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnParams p) {
       for (int g = 0; g < 16; g++) { s[sub][g] = 0.f; dp[sub][g] = 0.f; }
 #pragma unroll
       for (int ks = 0; ks < KSTEPS; ks++) {
-        s[sub] = mfma32(rowfrag(ldsK, S96, sub, ks, lane), qf[ks], s[sub]);
-        dp[sub] = mfma32(rowfrag(ldsV, S80, sub, ks, lane), dof[ks], dp[sub]);
+        s[sub] = mfma32(rowfrag<true>(ldsK, sub, ks, lane), qf[ks], s[sub]);
+        dp[sub] = mfma32(rowfrag<false>(ldsV, sub, ks, lane), dof[ks], dp[sub]);
       }
     }
 #pragma unroll
@@ -274,9 +316,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnParams p) {
 }
 
 // ------------------------------------------------------------------------------------------------ backward: dK, dV
-__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnParams p) {
-  __shared__ __attribute__((aligned(16))) char ldsQ[BKV * S96];
-  __shared__ __attribute__((aligned(16))) char ldsD[BKV * S96];
+__global__ __launch_bounds__(256, ATTN_BWD_WAVES) void attn_bwd_dkv_kernel(AttnParams p) {
+  __shared__ __attribute__((aligned(16))) char ldsQ[BKV * S_SWZ];
+  __shared__ __attribute__((aligned(16))) char ldsD[BKV * S_SWZ];
   __shared__ __attribute__((aligned(16))) float ldsL[BKV];
   __shared__ __attribute__((aligned(16))) float ldsDl[BKV];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hi = lane >> 5;
@@ -294,23 +336,32 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnParams p) {
   const bf16_t* Dp = p.dO + (long)b * p.o_bs + (long)h * p.o_hs;
   const float* Lp = p.LSE + ((long)b * p.H + h) * p.Nq;
   const float* Dl = p.Delta + ((long)b * p.H + h) * p.Nq;
-  zero_pad(ldsQ, S96, tid);
-  zero_pad(ldsD, S96, tid);
+  zero_pad<true>(ldsQ, tid);
+  zero_pad<true>(ldsD, tid);
 
   f32x16 dk[3], dv[3];
   zero3(dk);
   zero3(dv);
   const float c = p.scale_log2;
-  for (int q0 = 0; q0 < p.Nq; q0 += BKV) {
-    __syncthreads();
-    stage_tile(ldsQ, S96, Qp, p.q_ts, q0, p.Nq, tid);
-    stage_tile(ldsD, S96, Dp, p.o_ts, q0, p.Nq, tid);
+  uint4 rq[PF], rd[PF];
+  float rl = INFINITY, rdl = 0.f;
+  auto fetch = [&](int q0) {
+    tile_g2r(rq, Qp, p.q_ts, q0, p.Nq, tid);
+    tile_g2r(rd, Dp, p.o_ts, q0, p.Nq, tid);
     if (tid < BKV) {
       const bool ok = q0 + tid < p.Nq;
-      ldsL[tid] = ok ? Lp[q0 + tid] : INFINITY;   // +inf -> P = exp2(-inf) = 0 for rows beyond Nq
-      ldsDl[tid] = ok ? Dl[q0 + tid] : 0.f;
+      rl = ok ? Lp[q0 + tid] : INFINITY;    // +inf -> P = exp2(-inf) = 0 for rows beyond Nq
+      rdl = ok ? Dl[q0 + tid] : 0.f;
     }
+  };
+  fetch(0);
+  for (int q0 = 0; q0 < p.Nq; q0 += BKV) {
     __syncthreads();
+    tile_r2s<true>(ldsQ, rq, tid);
+    tile_r2s<true>(ldsD, rd, tid);
+    if (tid < BKV) { ldsL[tid] = rl; ldsDl[tid] = rdl; }
+    __syncthreads();
+    if (q0 + BKV < p.Nq) fetch(q0 + BKV);
 #pragma unroll
     for (int sub = 0; sub < 2; sub++) {
       f32x16 s, dp;
@@ -318,8 +369,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnParams p) {
       for (int g = 0; g < 16; g++) { s[g] = 0.f; dp[g] = 0.f; }
 #pragma unroll
       for (int ks = 0; ks < KSTEPS; ks++) {
-        s = mfma32(rowfrag(ldsQ, S96, sub, ks, lane), kf[ks], s);    // S[q][kv], col = kv (lane), rows = q
-        dp = mfma32(rowfrag(ldsD, S96, sub, ks, lane), vf[ks], dp);  // dP[q][kv]
+        s = mfma32(rowfrag<true>(ldsQ, sub, ks, lane), kf[ks], s);    // S[q][kv], col = kv (lane), rows = q
+        dp = mfma32(rowfrag<true>(ldsD, sub, ks, lane), vf[ks], dp);  // dP[q][kv]
       }
 #pragma unroll
       for (int qd = 0; qd < 4; qd++) {

@@ -10,6 +10,8 @@
 // k-strided operands sit as [64][128+32] and are read with ds_read_b64_tr_b16 (hardware transpose).
 #include "common.h"
 #include "../../include/pixart_hip.h"
+#include <cstdlib>
+#include <cstring>
 
 namespace {
 using namespace pxa;
@@ -25,7 +27,7 @@ struct GemmParams {
   const float* bias; const bf16_t* aux; int ldaux;
   bf16_t* out; bf16_t* out2; int ldo;
   float* outf; int ldf;
-  int act, accumulate, k_per_split;
+  int act, accumulate, k_per_split, tile_hint;
 };
 
 // ---- global -> registers (4 x 16 B per thread per operand tile), zero-filled out of bounds
@@ -78,6 +80,68 @@ __device__ __forceinline__ bf16x8 frag(const char* lds, int rbase, int ks, int l
   }
 }
 
+// blockIdx -> output tile.  Workgroup b runs on XCD b % 8 (each XCD has a private 4 MiB L2), so every XCD is given a
+// CONTIGUOUS range of the logical tile order, and the logical order walks the tile grid in groups of GROUP_M m-tiles
+// (column-major inside a group): the ~64 workgroups resident on one XCD then cover an 8 x 8 super-tile whose 8 A panels
+// and 8 B panels (K = 1152: 2 x 2.4 MB) are fetched once into that L2 and reused 8x, instead of 8 XCDs each streaming
+// every panel.  Bijective for any tile count.
+constexpr int NXCD = 8, GROUP_M = 8;
+__device__ __forceinline__ void tile_coords(int bid, int mt, int nt, int& tm, int& tn) {
+  const int T = mt * nt, q = T / NXCD, r = T % NXCD;
+  const int x = bid % NXCD, idx = bid / NXCD;
+  const int L = x * q + min(x, r) + idx;               // logical id: XCD x owns [x*q + min(x,r), +q + (x<r))
+  const int per_group = GROUP_M * nt;
+  const int g = L / per_group, first_m = g * GROUP_M;
+  const int gsz = min(mt - first_m, GROUP_M);
+  const int in_g = L - g * per_group;
+  tm = first_m + in_g % gsz;
+  tn = in_g / gsz;
+}
+
+// ---- epilogue: lane owns row m, 4 consecutive n per accumulator quad (bias / GELU / GELU' / bf16 + fp32 / atomic stores)
+__device__ __forceinline__ void epilogue(const GemmParams& p, const f32x16 (&acc)[2][2], int m0, int n0, int wm, int wn, int lane, int hi) {
+#pragma unroll
+  for (int i = 0; i < 2; i++) {
+    const int m = m0 + wm * 64 + i * 32 + (lane & 31);
+    if (m >= p.M) continue;
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const int n = n0 + wn * 64 + j * 32 + 8 * q + 4 * hi;
+        if (n >= p.N) continue;
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; e++) v[e] = acc[i][j][q * 4 + e];
+        if (p.bias) {
+          const float4 b = *reinterpret_cast<const float4*>(p.bias + n);
+          v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+        }
+        if (p.act == 1) {
+          if (p.out2) *reinterpret_cast<uint2*>(p.out2 + (size_t)m * p.ldo + n) = pack_bf16x4(v[0], v[1], v[2], v[3]);
+#pragma unroll
+          for (int e = 0; e < 4; e++) v[e] = gelu_tanh(v[e]);
+        } else if (p.act == 2) {
+          const uint2 a = *reinterpret_cast<const uint2*>(p.aux + (size_t)m * p.ldaux + n);
+          float a0, a1, a2, a3;
+          unpack_bf16x2(a.x, a0, a1); unpack_bf16x2(a.y, a2, a3);
+          v[0] *= gelu_tanh_grad(a0); v[1] *= gelu_tanh_grad(a1); v[2] *= gelu_tanh_grad(a2); v[3] *= gelu_tanh_grad(a3);
+        }
+        if (p.out) *reinterpret_cast<uint2*>(p.out + (size_t)m * p.ldo + n) = pack_bf16x4(v[0], v[1], v[2], v[3]);
+        if (p.outf) {
+          float* dst = p.outf + (size_t)m * p.ldf + n;
+          if (p.accumulate) {
+#pragma unroll
+            for (int e = 0; e < 4; e++) atomicAdd(dst + e, v[e]);
+          } else {
+            *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+          }
+        }
+      }
+    }
+  }
+}
+
 template <int LAYOUT>
 __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
   constexpr bool A_KC = (LAYOUT != 2), B_KC = (LAYOUT == 0);
@@ -86,8 +150,9 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
   constexpr int STAGE = A_BYTES + B_BYTES;  // stage s: [A tile][B tile] at smem + s*STAGE
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1, hi = lane >> 5;
-  const int ntn = (p.N + BN - 1) / BN;
-  const int m0 = (blockIdx.x / ntn) * BM, n0 = (blockIdx.x % ntn) * BN;
+  int tm_, tn_;
+  tile_coords(blockIdx.x, (p.M + BM - 1) / BM, (p.N + BN - 1) / BN, tm_, tn_);
+  const int m0 = tm_ * BM, n0 = tn_ * BN;
   const int kbeg = blockIdx.z * p.k_per_split;
   const int kend = min(p.K, kbeg + p.k_per_split);
   const int nk = (kend - kbeg + BK - 1) / BK;
@@ -136,16 +201,69 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
     __syncthreads();
   }
 
-  // ---- epilogue: lane owns row m, 4 consecutive n per accumulator quad
+  epilogue(p, acc, m0, n0, wm, wn, lane, hi);
+}
+
+// =====================================================================================================================
+// Fast path (every K range a multiple of 64): operands go HBM -> LDS by LDS-DMA (global_load_lds_dwordx4, 1 KiB per wave
+// instruction, no VGPR round trip and no ds_write issue slots).  The DMA writes lane-linear (wave-uniform base + lane*16),
+// so the bank swizzles move to the per-lane SOURCE address and the same XOR is applied on the fragment reads (guide rule 21):
+//   k-contiguous tile  [R r][64 k]: chunk' = chunk ^ ((r>>1)&7)                         (ds_read_b128 conflict-free)
+//   k-strided   tile  [64 k][R r]: 64-byte block' = block ^ (k&3), rows unpadded         (4 tr-read rows -> 4 bank quarters)
+// Rows beyond M / N are clamped to the last valid row / column 0 (their products are never stored).
+// Tile shapes: the 128x128 tile moves 1 byte per 64 FLOP from L2 — at the MI355X's ~35 TB/s aggregate L2 that caps a GEMM
+// near 2.2 PF and in practice (L2 misses served by MALL/HBM) well under 1 PF — so the large token GEMMs use a 256x256 tile
+// (8 waves, 128x64 per wave, 128 FLOP/B) or 256x128 (8 waves, 64x64 per wave) when N is not a multiple of 256.
+// Pipeline: 2 LDS stages, ONE barrier per k-tile: barrier (vmcnt(0): tile t landed, stage t^1 free) -> issue DMA of tile
+// t+1 -> MFMA on tile t.
+template <bool KC, int ROWS, int NW>
+__device__ __forceinline__ void dma_tile(char* lds, const bf16_t* __restrict__ X, int ld, int r0, int R, int k0, int wave, int lane) {
+  constexpr int NINST = ROWS * 128 / 1024 / NW;        // 1 KiB DMA instructions per wave
+  constexpr int CPR = ROWS / 8;                         // 16-byte chunks per k-row of the k-strided image
 #pragma unroll
-  for (int i = 0; i < 2; i++) {
-    const int m = m0 + wm * 64 + i * 32 + (lane & 31);
+  for (int i = 0; i < NINST; i++) {
+    const int p = (i * NW + wave) * 64 + lane;          // linear 16-byte chunk position inside the tile
+    const bf16_t* src;
+    if (KC) {
+      const int row = p >> 3, c = (p & 7) ^ ((row >> 1) & 7);
+      const int gr = min(r0 + row, R - 1);
+      src = X + (size_t)gr * ld + k0 + c * 8;
+    } else {
+      const int kr = p / CPR, cl = p % CPR, c = ((((cl >> 2) ^ (kr & 3)) << 2) | (cl & 3));
+      int gc = r0 + c * 8;
+      gc = gc < R ? gc : 0;
+      src = X + (size_t)(k0 + kr) * ld + gc;
+    }
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)(lds + (i * NW + wave) * 1024), 16, 0, 0);
+  }
+}
+template <bool KC, int ROWS>
+__device__ __forceinline__ bf16x8 frag_g(const char* lds, int rbase, int ks, int lane) {
+  if (KC) {
+    const int row = rbase + (lane & 31), c = ks * 2 + (lane >> 5);
+    return *reinterpret_cast<const bf16x8*>(lds + row * 128 + ((c ^ ((row >> 1) & 7)) << 4));
+  } else {
+    const int gg = lane >> 4, tt = lane & 15, hi = gg >> 1;
+    const int kr = ks * 16 + 8 * hi + (tt >> 2), col = rbase + 16 * (gg & 1) + (tt & 3) * 4;
+    const int blk = col >> 5, inblk = (col & 31) * 2;
+    const char* p0 = lds + kr * (ROWS * 2) + ((blk ^ (kr & 3)) << 6) + inblk;
+    const char* p1 = lds + (kr + 4) * (ROWS * 2) + ((blk ^ ((kr + 4) & 3)) << 6) + inblk;
+    return concat_tr(lds_tr_read(p0), lds_tr_read(p1));
+  }
+}
+
+template <int TM, int TN>
+__device__ __forceinline__ void epilogue_t(const GemmParams& p, const f32x16 (&acc)[TM][TN], int mw, int nw, int lane, int hi) {
+#pragma unroll
+  for (int i = 0; i < TM; i++) {
+    const int m = mw + i * 32 + (lane & 31);
     if (m >= p.M) continue;
 #pragma unroll
-    for (int j = 0; j < 2; j++) {
+    for (int j = 0; j < TN; j++) {
 #pragma unroll
       for (int q = 0; q < 4; q++) {
-        const int n = n0 + wn * 64 + j * 32 + 8 * q + 4 * hi;
+        const int n = nw + j * 32 + 8 * q + 4 * hi;
         if (n >= p.N) continue;
         float v[4];
 #pragma unroll
@@ -179,6 +297,81 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
   }
 }
 
+template <int LAYOUT, int TBM, int TBN, int WM, int WN>
+__global__ __launch_bounds__(WM * WN * 64) void gemm_glds_kernel(GemmParams p) {
+  constexpr bool A_KC = (LAYOUT != 2), B_KC = (LAYOUT == 0);
+  constexpr int NW = WM * WN, TM = TBM / WM / 32, TN = TBN / WN / 32;
+  constexpr int A_BYTES = TBM * 128, B_BYTES = TBN * 128, STAGE = A_BYTES + B_BYTES;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), wm = wave / WN, wn = wave % WN, hi = lane >> 5;
+  int tm_, tn_;
+  tile_coords(blockIdx.x, (p.M + TBM - 1) / TBM, (p.N + TBN - 1) / TBN, tm_, tn_);
+  const int m0 = tm_ * TBM, n0 = tn_ * TBN;
+  const int kbeg = blockIdx.z * p.k_per_split;
+  const int kend = min(p.K, kbeg + p.k_per_split);
+  const int nk = (kend - kbeg) / BK;
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; i++)
+#pragma unroll
+    for (int j = 0; j < TN; j++)
+#pragma unroll
+      for (int g = 0; g < 16; g++) acc[i][j][g] = 0.f;
+
+  if (nk > 0) {
+    dma_tile<A_KC, TBM, NW>(smem, p.A, p.lda, m0, p.M, kbeg, wave, lane);
+    dma_tile<B_KC, TBN, NW>(smem + A_BYTES, p.B, p.ldb, n0, p.N, kbeg, wave, lane);
+  }
+  for (int kt = 0; kt < nk; kt++) {
+    const int cur = kt & 1;
+    __syncthreads();                                   // drains this wave's DMA (vmcnt(0)) and fences the stage hand-over
+    const char* sA = smem + cur * STAGE;
+    const char* sB = sA + A_BYTES;
+    // fragments are double-buffered in registers: the ds_reads of k-step ks+1 are in flight under the MFMAs of ks, and
+    // the DMA of the next k-tile is issued behind the first MFMA group so the matrix pipe restarts right after the barrier
+    bf16x8 af[2][TM], bf[2][TN];
+#pragma unroll
+    for (int i = 0; i < TM; i++) af[0][i] = frag_g<A_KC, TBM>(sA, wm * (TM * 32) + i * 32, 0, lane);
+#pragma unroll
+    for (int j = 0; j < TN; j++) bf[0][j] = frag_g<B_KC, TBN>(sB, wn * (TN * 32) + j * 32, 0, lane);
+#pragma unroll
+    for (int ks = 0; ks < BK / 16; ks++) {
+      if (ks + 1 < BK / 16) {
+#pragma unroll
+        for (int i = 0; i < TM; i++) af[(ks + 1) & 1][i] = frag_g<A_KC, TBM>(sA, wm * (TM * 32) + i * 32, ks + 1, lane);
+#pragma unroll
+        for (int j = 0; j < TN; j++) bf[(ks + 1) & 1][j] = frag_g<B_KC, TBN>(sB, wn * (TN * 32) + j * 32, ks + 1, lane);
+      }
+#pragma unroll
+      for (int i = 0; i < TM; i++)
+#pragma unroll
+        for (int j = 0; j < TN; j++) acc[i][j] = mfma32(bf[ks & 1][j], af[ks & 1][i], acc[i][j]);
+      if (ks == 0 && kt + 1 < nk) {
+        char* nxt = smem + (cur ^ 1) * STAGE;
+        dma_tile<A_KC, TBM, NW>(nxt, p.A, p.lda, m0, p.M, kbeg + (kt + 1) * BK, wave, lane);
+        dma_tile<B_KC, TBN, NW>(nxt + A_BYTES, p.B, p.ldb, n0, p.N, kbeg + (kt + 1) * BK, wave, lane);
+      }
+    }
+  }
+  epilogue_t<TM, TN>(p, acc, m0 + wm * (TM * 32), n0 + wn * (TN * 32), lane, hi);
+}
+
+template <int LAYOUT, int TBM, int TBN, int WM, int WN>
+int launch_glds(const GemmParams& p, int split, hipStream_t s) {
+  constexpr int LDSG = 2 * (TBM + TBN) * 128;
+  static bool attr_set_g = false;
+  if (!attr_set_g) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_glds_kernel<LAYOUT, TBM, TBN, WM, WN>), hipFuncAttributeMaxDynamicSharedMemorySize, LDSG);
+    if (e != hipSuccess) { pxa_set_error("hipFuncSetAttribute(gemm_glds<%d,%d,%d>): %s", LAYOUT, TBM, TBN, hipGetErrorString(e)); return -3; }
+    attr_set_g = true;
+  }
+  dim3 grid(((p.M + TBM - 1) / TBM) * ((p.N + TBN - 1) / TBN), 1, split);
+  hipLaunchKernelGGL((gemm_glds_kernel<LAYOUT, TBM, TBN, WM, WN>), grid, dim3(WM * WN * 64), LDSG, s, p);
+  PXA_LAUNCH_CHECK();
+  return 0;
+}
+
 template <int LAYOUT>
 int launch(const GemmParams& p, int split, hipStream_t s) {
   constexpr bool A_KC = (LAYOUT != 2), B_KC = (LAYOUT == 0);
@@ -190,6 +383,16 @@ int launch(const GemmParams& p, int split, hipStream_t s) {
     attr_set = true;
   }
   dim3 grid(((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN), 1, split);
+  const bool fast = (p.K % BK == 0) && (p.k_per_split % BK == 0) && !getenv("PXA_GEMM_NO_GLDS");
+  if (fast) {
+    static const char* force = getenv("PXA_GEMM_TILE");   // "128" | "256x128" | "256" : A/B experiments
+    int tile = force ? atoi(force) * (strstr(force, "x128") ? -1 : 1) : 0;
+    if (!tile) tile = p.tile_hint;
+    if (!tile) tile = (p.M >= 1024 && p.N >= 1024) ? 256 : 128;
+    if (tile == 128) return launch_glds<LAYOUT, 128, 128, 2, 2>(p, split, s);
+    if (tile == -256) return launch_glds<LAYOUT, 256, 128, 4, 2>(p, split, s);
+    return launch_glds<LAYOUT, 256, 256, 2, 4>(p, split, s);
+  }
   hipLaunchKernelGGL(gemm_kernel<LAYOUT>, grid, dim3(256), LDS, s, p);
   PXA_LAUNCH_CHECK();
   return 0;
@@ -209,7 +412,7 @@ extern "C" int pxa_gemm(const pxa_gemm_args* a, hipStream_t stream) {
   if (a->out_f32) PXA_CHECK(a->ld_f32 % 4 == 0, "pxa_gemm: ld_f32 must be a multiple of 4");
   PXA_CHECK(a->act >= 0 && a->act <= 2, "pxa_gemm: bad act %d", a->act);
   if (a->act == 2) PXA_CHECK(a->aux && a->ldaux % 4 == 0, "pxa_gemm: act=2 needs aux");
-  int split = a->split_k < 1 ? 1 : a->split_k;
+  int split = a->split_k < 1 ? 1 : a->split_k;   // 0 = choose here (only for fp32 atomic-accumulate outputs)
   if (split > 1) PXA_CHECK(a->out_f32 && a->accumulate && !a->out_bf16 && a->act == 0 && !a->bias, "pxa_gemm: split_k>1 needs fp32 atomic accumulate output only");
   GemmParams p;
   p.A = (const bf16_t*)a->A; p.B = (const bf16_t*)a->B; p.lda = a->lda; p.ldb = a->ldb;
@@ -218,6 +421,25 @@ extern "C" int pxa_gemm(const pxa_gemm_args* a, hipStream_t stream) {
   p.out = (bf16_t*)a->out_bf16; p.out2 = (bf16_t*)a->out2_bf16; p.ldo = a->ld_out;
   p.outf = a->out_f32; p.ldf = a->ld_f32;
   p.act = a->act; p.accumulate = a->accumulate;
+  p.tile_hint = 0;
+  if (a->split_k == 0 && a->out_f32 && a->accumulate && !a->out_bf16 && a->act == 0 && !a->bias && a->K % BK == 0) {
+    // Split-K weight-gradient GEMMs (K = tokens, 65536): a handful of long-running workgroups, so wave quantisation against the
+    // 256 CUs decides the time.  Pick (tile, split) minimising  rounds x k-tiles x tile cost  + atomic epilogue traffic.
+    struct Cfg { int tile, bm, bn, slots; double eff; };
+    const Cfg cfgs[3] = {{128, 128, 128, 512, 1.0}, {-256, 256, 128, 256, 1.0}, {256, 256, 256, 256, 1.15}};
+    double best = 1e30;
+    for (const Cfg& c : cfgs) {
+      const long tiles = (long)((a->M + c.bm - 1) / c.bm) * ((a->N + c.bn - 1) / c.bn);
+      for (int sp = 1; sp <= 64; sp++) {
+        const int kp = ((a->K + sp - 1) / sp + BK - 1) / BK * BK;
+        if ((long)kp * (sp - 1) >= a->K) continue;               // would leave an empty split
+        const long rounds = (tiles * sp + c.slots - 1) / c.slots;
+        const double per_cu = (double)c.bm * c.bn * (512.0 / c.slots) / c.eff;   // work a CU carries per k-step and round
+        const double t = rounds * (double)kp * per_cu * 2.0 / (750e12 / 256.0) + (double)sp * a->M * a->N / 300e9;
+        if (t < best) { best = t; split = sp; p.tile_hint = c.tile; }
+      }
+    }
+  }
   int kps = ((a->K + split - 1) / split + BK - 1) / BK * BK;
   p.k_per_split = kps;
   split = (a->K + kps - 1) / kps;

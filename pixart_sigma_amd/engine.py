@@ -161,7 +161,7 @@ class Engine:
         """dW += dy^T x ; db += colsum(dy) ; returns dx = dy W (bf16) if need_dx."""
         S = self.S
         M, N = S.shape[name + ".weight"]
-        ops.gemm(dy, x, TN, out_f32=S.g(name + ".weight"), accumulate=True, split_k=_splitk(M, N, dy.shape[0]))
+        ops.gemm(dy, x, TN, out_f32=S.g(name + ".weight"), accumulate=True, split_k=0)
         ops.colsum(dy, S.g(name + ".bias"))
         if need_dx:
             return ops.gemm(dy, S.w(name + ".weight"), NN, **(dx_kw or {}))
