@@ -21,17 +21,20 @@ using namespace pxa;
 constexpr int DH = 72;
 constexpr int NCH = DH / 8;          // 9 16-byte chunks per head row
 constexpr int KSTEPS = 5;            // ceil(72/16)
-// LDS tile layouts (row-major [64 rows][head_dim], 16-byte chunks), both conflict-free for their read patterns:
-//   LIN : stride 176 B (11 chunks: 9 data + zero pad).  ds_read_b128 serves 16-lane groups whose rows cover all residues
-//         mod 16; 11 is odd, so the 16 rows hit 16 distinct 16-byte slots of the 256-byte bank row.
-//   SWZ : stride 192 B (12 chunks: 9 data + 3 zero pad), chunk index XOR ((row>>2)&3).  The transpose reads
-//         (ds_read_b64_tr_b16) take 4 consecutive rows x 64 B per 32-lane group: 192 B = 48 banks puts the 4 rows on the
-//         4 disjoint 16-bank quarters, and the XOR (constant over an aligned group of 4 rows, closed on aligned groups of
-//         4 chunks) only permutes inside each row's 64-byte window.  For ds_read_b128 the same XOR separates the rows
-//         r, r+4, r+8, r+12 that a bare 192-byte stride would pile onto one slot (4-way conflict).
-constexpr int S_LIN = 176;
-constexpr int S_SWZ = 192;
+// LDS tile image: row-major [64 rows][12 chunks of 16 B] = 192-byte rows (9 data chunks + 3 pad), chunk index XOR ((row>>2)&3).
+//   * ds_read_b64_tr_b16 (transpose reads) take 4 consecutive rows x 64 B per 32-lane group: 192 B = 48 banks puts the 4 rows on
+//     the 4 disjoint 16-bank quarters; the XOR is constant over an aligned group of 4 rows and closed on aligned groups of 4
+//     chunks, so it only permutes inside each row's 64-byte window -> conflict-free.
+//   * ds_read_b128 serves 16-lane groups whose rows cover all residues mod 16; a bare 192-byte stride would pile rows r, r+4,
+//     r+8, r+12 onto one 16-byte slot (4-way conflict), the XOR separates them -> conflict-free.
+// Tiles are filled by LDS-DMA (global_load_lds_dwordx4: wave-uniform LDS base + lane*16, per-lane source address), so the image
+// is lane-linear and the swizzle lives in the SOURCE address (guide rule 21).  Pad chunks receive a duplicate of chunk 0 and rows
+// beyond the valid range a duplicate of the last valid row: only finite values, always multiplied by a zero operand or masked.
+constexpr int ROWB = 192;
+constexpr int TILE_B = 64 * ROWB;        // 12288 B per tile
 constexpr int BKV = 64;
+constexpr float RESCALE_LOG2 = 6.0f;     // online-softmax rescale threshold, log2 domain (P <= 64)
+constexpr int NDMA = TILE_B / 1024 / 4;  // 3 DMA instructions per wave per tile
 
 struct AttnParams {
   const bf16_t *Q, *K, *V, *dO;
@@ -56,36 +59,27 @@ __device__ __forceinline__ void kv_range(const AttnParams& p, int b, long& kbase
   }
 }
 
-template <bool SWZ>
-__device__ __forceinline__ int soff(int r, int c) {  // byte offset of chunk c of row r
-  return SWZ ? r * S_SWZ + ((c ^ ((r >> 2) & 3)) << 4) : r * S_LIN + (c << 4);
-}
-constexpr int TILE_CH = BKV * NCH;                     // 576 16-byte chunks per [64][72] tile
-constexpr int PF = (TILE_CH + 255) / 256;              // 3 chunks per thread
 
-// global -> registers for tile rows row0..row0+63 (zero beyond nrows); issued one tile ahead of its use
-__device__ __forceinline__ void tile_g2r(uint4 (&reg)[PF], const bf16_t* __restrict__ src, long ts, int row0, int nrows, int tid) {
+__device__ __forceinline__ int soff(int r, int c) { return r * ROWB + ((c ^ ((r >> 2) & 3)) << 4); }
+
+struct DmaPlan { int row[NDMA], coff[NDMA]; };   // per-lane constants: tile row and source element offset of each DMA chunk
+__device__ __forceinline__ void dma_plan(DmaPlan& pl, int wave, int lane) {
 #pragma unroll
-  for (int i = 0; i < PF; i++) {
-    const int c = tid + 256 * i, r = c / NCH, ch = c - r * NCH;
-    reg[i] = make_uint4(0, 0, 0, 0);
-    if (c < TILE_CH && row0 + r < nrows) reg[i] = *reinterpret_cast<const uint4*>(src + (long)(row0 + r) * ts + ch * 8);
+  for (int i = 0; i < NDMA; i++) {
+    const int p = (i * 4 + wave) * 64 + lane, r = p / 12, cl = p - r * 12;
+    int c = cl ^ ((r >> 2) & 3);
+    c = c < NCH ? c : 0;
+    pl.row[i] = r;
+    pl.coff[i] = c * 8;
   }
 }
-template <bool SWZ>
-__device__ __forceinline__ void tile_r2s(char* lds, const uint4 (&reg)[PF], int tid) {
+__device__ __forceinline__ void dma_tile(char* lds, const bf16_t* __restrict__ base, int ts, int row0, int nrows, const DmaPlan& pl, int wave) {
 #pragma unroll
-  for (int i = 0; i < PF; i++) {
-    const int c = tid + 256 * i, r = c / NCH, ch = c - r * NCH;
-    if (c < TILE_CH) *reinterpret_cast<uint4*>(lds + soff<SWZ>(r, ch)) = reg[i];
-  }
-}
-template <bool SWZ>
-__device__ __forceinline__ void zero_pad(char* lds, int tid) {  // chunks 9.. of every row (never overwritten afterwards)
-  constexpr int npad = (SWZ ? S_SWZ : S_LIN) / 16 - NCH;
-  for (int c = tid; c < BKV * npad; c += 256) {
-    const int r = c / npad, ch = NCH + (c - r * npad);
-    *reinterpret_cast<uint4*>(lds + soff<SWZ>(r, ch)) = make_uint4(0, 0, 0, 0);
+  for (int i = 0; i < NDMA; i++) {
+    const int gr = min(row0 + pl.row[i], nrows - 1);
+    const bf16_t* src = base + (long)gr * ts + pl.coff[i];
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)(lds + (i * 4 + wave) * 1024), 16, 0, 0);
   }
 }
 // B-operand fragments of a row held in registers: X[row][ks*16 + 8*hi .. +8], zero for d >= 72 or invalid row
@@ -99,17 +93,16 @@ __device__ __forceinline__ void load_row_frags(bf16x8 (&f)[KSTEPS], const bf16_t
   }
 }
 // A-operand from a row-major tile: rows sub*32 + (lane&31), k = d
-template <bool SWZ>
 __device__ __forceinline__ bf16x8 rowfrag(const char* lds, int sub, int ks, int lane) {
-  return *reinterpret_cast<const bf16x8*>(lds + soff<SWZ>(sub * 32 + (lane & 31), ks * 2 + (lane >> 5)));
+  return *reinterpret_cast<const bf16x8*>(lds + soff(sub * 32 + (lane & 31), ks * 2 + (lane >> 5)));
 }
-// A-operand X^T[d = dt*32 + (lane&31)][k-slots of step u] from a SWZ row-major [row][d] tile via transpose reads.
+// A-operand X^T[d = dt*32 + (lane&31)][k-slots of step u] from a row-major [row][d] tile via transpose reads.
 // slot j <-> row 16u + (j&3) + 8*(j>>2) + 4*hi : the same permutation the accumulator layout gives the B operand.
 __device__ __forceinline__ bf16x8 trfrag(const char* lds, int dt, int u, int lane) {
   const int gg = lane >> 4, tt = lane & 15, hi = gg >> 1;
   const int row = 16 * u + 4 * hi + (tt >> 2);
   const int c = dt * 4 + 2 * (gg & 1) + ((tt & 3) >> 1), sub8 = (tt & 1) * 8;
-  return concat_tr(lds_tr_read(lds + soff<true>(row, c) + sub8), lds_tr_read(lds + soff<true>(row + 8, c) + sub8));
+  return concat_tr(lds_tr_read(lds + soff(row, c) + sub8), lds_tr_read(lds + soff(row + 8, c) + sub8));
 }
 __device__ __forceinline__ bf16x8 pack8(const f32x16& v, int off) {
   bf16x8 r;
@@ -134,12 +127,12 @@ __device__ __forceinline__ void zero3(f32x16 (&a)[3]) {
 #pragma unroll
     for (int g = 0; g < 16; g++) a[i][g] = 0.f;
 }
+template <bool B> struct BoolC { static constexpr bool value = B; };
 
 // ------------------------------------------------------------------------------------------------ forward
-__global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
-  __shared__ __attribute__((aligned(16))) char ldsK[BKV * S_LIN];
-  __shared__ __attribute__((aligned(16))) char ldsV[BKV * S_SWZ];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hi = lane >> 5;
+__global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
+  __shared__ __attribute__((aligned(16))) char smem[4 * TILE_B];   // 2 stages x {K, V}
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), hi = lane >> 5;
   const int b = blockIdx.z, h = blockIdx.y;
   const int q = blockIdx.x * 128 + wave * 32 + (lane & 31);
   const bool qvalid = q < p.Nq;
@@ -147,38 +140,29 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
   kv_range(p, b, kbase, vbase, d0_, d1_, kvlen);
   const bf16_t* Kp = p.K + kbase + (long)h * p.k_hs;
   const bf16_t* Vp = p.V + vbase + (long)h * p.v_hs;
+  const int kts = (int)p.k_ts, vts = (int)p.v_ts;
 
   bf16x8 qf[KSTEPS];
   load_row_frags(qf, p.Q + (long)b * p.q_bs + (long)q * p.q_ts + (long)h * p.q_hs, qvalid, hi);
-  zero_pad<false>(ldsK, tid);
-  zero_pad<true>(ldsV, tid);
+  DmaPlan pl;
+  dma_plan(pl, wave, lane);
 
   f32x16 o[3];
   zero3(o);
   float m = -INFINITY, l = 0.f;
   const float c = p.scale_log2;
-  uint4 rk[PF], rv[PF];
-  tile_g2r(rk, Kp, p.k_ts, 0, kvlen, tid);
-  tile_g2r(rv, Vp, p.v_ts, 0, kvlen, tid);
 
-  for (int kv0 = 0; kv0 < kvlen; kv0 += BKV) {
-    __syncthreads();                       // every wave is done reading the previous tile
-    tile_r2s<false>(ldsK, rk, tid);
-    tile_r2s<true>(ldsV, rv, tid);
-    __syncthreads();
-    if (kv0 + BKV < kvlen) {               // next tile's HBM/L2 latency hides under this tile's MFMAs
-      tile_g2r(rk, Kp, p.k_ts, kv0 + BKV, kvlen, tid);
-      tile_g2r(rv, Vp, p.v_ts, kv0 + BKV, kvlen, tid);
-    }
+  auto tile = [&](auto tailc, const char* sK, const char* sV, int kv0) {
+    constexpr bool TAIL = decltype(tailc)::value;
     f32x16 s[2];
 #pragma unroll
     for (int sub = 0; sub < 2; sub++) {
 #pragma unroll
       for (int g = 0; g < 16; g++) s[sub][g] = 0.f;
 #pragma unroll
-      for (int ks = 0; ks < KSTEPS; ks++) s[sub] = mfma32(rowfrag<false>(ldsK, sub, ks, lane), qf[ks], s[sub]);
+      for (int ks = 0; ks < KSTEPS; ks++) s[sub] = mfma32(rowfrag(sK, sub, ks, lane), qf[ks], s[sub]);
     }
-    if (kv0 + BKV > kvlen) {
+    if (TAIL) {
 #pragma unroll
       for (int sub = 0; sub < 2; sub++)
 #pragma unroll
@@ -191,10 +175,20 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
 #pragma unroll
       for (int g = 0; g < 16; g++) mt = fmaxf(mt, s[sub][g]);
     mt = fmaxf(mt, __shfl_xor(mt, 32));
-    const float mn = fmaxf(m, mt);
-    const float alpha = __builtin_amdgcn_exp2f((m - mn) * c);
-    const float mc = mn * c;
-    m = mn;
+    // Deferred rescale (guide T13): keep the stale running max while no query of this wave grew by more than 2^RESCALE_LOG2;
+    // P is then bounded by 2^RESCALE_LOG2 instead of 1 (bf16 keeps its relative precision, l and O are fp32).  When the branch
+    // fires, O and l — everything still expressed against the old max — are scaled exactly once, before any P of this tile.
+    if (__builtin_amdgcn_readfirstlane(__any((mt - m) * c > RESCALE_LOG2))) {
+      const float mn = fmaxf(m, mt);
+      const float alpha = __builtin_amdgcn_exp2f((m - mn) * c);
+      m = mn;
+      l *= alpha;
+#pragma unroll
+      for (int dt = 0; dt < 3; dt++)
+#pragma unroll
+        for (int g = 0; g < 16; g++) o[dt][g] *= alpha;
+    }
+    const float mc = m * c;
     float ps = 0.f;
 #pragma unroll
     for (int sub = 0; sub < 2; sub++)
@@ -204,17 +198,30 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
         s[sub][g] = e;
         ps += e;
       }
-    l = l * alpha + ps;
-#pragma unroll
-    for (int dt = 0; dt < 3; dt++)
-#pragma unroll
-      for (int g = 0; g < 16; g++) o[dt][g] *= alpha;
+    l += ps;
 #pragma unroll
     for (int u = 0; u < 4; u++) {
       const bf16x8 pb = pack8(s[u >> 1], 8 * (u & 1));
 #pragma unroll
-      for (int dt = 0; dt < 3; dt++) o[dt] = mfma32(trfrag(ldsV, dt, u, lane), pb, o[dt]);
+      for (int dt = 0; dt < 3; dt++) o[dt] = mfma32(trfrag(sV, dt, u, lane), pb, o[dt]);
     }
+  };
+
+  const int T = (kvlen + BKV - 1) / BKV;
+  if (T > 0) {
+    dma_tile(smem, Kp, kts, 0, kvlen, pl, wave);
+    dma_tile(smem + TILE_B, Vp, vts, 0, kvlen, pl, wave);
+  }
+  for (int t = 0; t < T; t++) {
+    char* st = smem + (t & 1) * 2 * TILE_B;
+    __syncthreads();                       // own DMA drained (vmcnt(0)) + stage hand-over; ONE barrier per tile
+    if (t + 1 < T) {
+      char* nx = smem + ((t + 1) & 1) * 2 * TILE_B;
+      dma_tile(nx, Kp, kts, (t + 1) * BKV, kvlen, pl, wave);
+      dma_tile(nx + TILE_B, Vp, vts, (t + 1) * BKV, kvlen, pl, wave);
+    }
+    if (t + 1 < T || (kvlen % BKV) == 0) tile(BoolC<false>{}, st, st + TILE_B, t * BKV);
+    else tile(BoolC<true>{}, st, st + TILE_B, t * BKV);
   }
   l += __shfl_xor(l, 32);
   if (qvalid) {
@@ -248,12 +255,11 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* __restric
 
 // ------------------------------------------------------------------------------------------------ backward: dQ
 #ifndef ATTN_BWD_WAVES
-#define ATTN_BWD_WAVES 1
+#define ATTN_BWD_WAVES 2
 #endif
 __global__ __launch_bounds__(256, ATTN_BWD_WAVES) void attn_bwd_dq_kernel(AttnParams p) {
-  __shared__ __attribute__((aligned(16))) char ldsK[BKV * S_SWZ];
-  __shared__ __attribute__((aligned(16))) char ldsV[BKV * S_LIN];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hi = lane >> 5;
+  __shared__ __attribute__((aligned(16))) char smem[4 * TILE_B];   // 2 stages x {K, V}
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), hi = lane >> 5;
   const int b = blockIdx.z, h = blockIdx.y;
   const int q = blockIdx.x * 128 + wave * 32 + (lane & 31);
   const bool qvalid = q < p.Nq;
@@ -261,6 +267,7 @@ __global__ __launch_bounds__(256, ATTN_BWD_WAVES) void attn_bwd_dq_kernel(AttnPa
   kv_range(p, b, kbase, vbase, d0_, d1_, kvlen);
   const bf16_t* Kp = p.K + kbase + (long)h * p.k_hs;
   const bf16_t* Vp = p.V + vbase + (long)h * p.v_hs;
+  const int kts = (int)p.k_ts, vts = (int)p.v_ts;
 
   bf16x8 qf[KSTEPS], dof[KSTEPS];
   load_row_frags(qf, p.Q + (long)b * p.q_bs + (long)q * p.q_ts + (long)h * p.q_hs, qvalid, hi);
@@ -268,24 +275,14 @@ __global__ __launch_bounds__(256, ATTN_BWD_WAVES) void attn_bwd_dq_kernel(AttnPa
   const long sidx = ((long)b * p.H + h) * p.Nq + q;
   const float lse = qvalid ? p.LSE[sidx] : 0.f;
   const float delta = qvalid ? p.Delta[sidx] : 0.f;
-  zero_pad<true>(ldsK, tid);
-  zero_pad<false>(ldsV, tid);
+  DmaPlan pl;
+  dma_plan(pl, wave, lane);
 
   f32x16 dq[3];
   zero3(dq);
   const float c = p.scale_log2;
-  uint4 rk[PF], rv[PF];
-  tile_g2r(rk, Kp, p.k_ts, 0, kvlen, tid);
-  tile_g2r(rv, Vp, p.v_ts, 0, kvlen, tid);
-  for (int kv0 = 0; kv0 < kvlen; kv0 += BKV) {
-    __syncthreads();
-    tile_r2s<true>(ldsK, rk, tid);
-    tile_r2s<false>(ldsV, rv, tid);
-    __syncthreads();
-    if (kv0 + BKV < kvlen) {
-      tile_g2r(rk, Kp, p.k_ts, kv0 + BKV, kvlen, tid);
-      tile_g2r(rv, Vp, p.v_ts, kv0 + BKV, kvlen, tid);
-    }
+  auto tile = [&](auto tailc, const char* sK, const char* sV, int kv0) {
+    constexpr bool TAIL = decltype(tailc)::value;
     f32x16 s[2], dp[2];
 #pragma unroll
     for (int sub = 0; sub < 2; sub++) {
@@ -293,35 +290,49 @@ __global__ __launch_bounds__(256, ATTN_BWD_WAVES) void attn_bwd_dq_kernel(AttnPa
       for (int g = 0; g < 16; g++) { s[sub][g] = 0.f; dp[sub][g] = 0.f; }
 #pragma unroll
       for (int ks = 0; ks < KSTEPS; ks++) {
-        s[sub] = mfma32(rowfrag<true>(ldsK, sub, ks, lane), qf[ks], s[sub]);
-        dp[sub] = mfma32(rowfrag<false>(ldsV, sub, ks, lane), dof[ks], dp[sub]);
+        s[sub] = mfma32(rowfrag(sK, sub, ks, lane), qf[ks], s[sub]);
+        dp[sub] = mfma32(rowfrag(sV, sub, ks, lane), dof[ks], dp[sub]);
       }
     }
 #pragma unroll
     for (int sub = 0; sub < 2; sub++)
 #pragma unroll
       for (int g = 0; g < 16; g++) {
-        const bool kvok = kv0 + sub * 32 + (g & 3) + 8 * (g >> 2) + 4 * hi < kvlen;
-        const float pr = kvok ? __builtin_amdgcn_exp2f(s[sub][g] * c - lse) : 0.f;
+        float pr = __builtin_amdgcn_exp2f(s[sub][g] * c - lse);
+        if (TAIL && kv0 + sub * 32 + (g & 3) + 8 * (g >> 2) + 4 * hi >= kvlen) pr = 0.f;
         s[sub][g] = pr * (dp[sub][g] - delta);  // dS^T (without the softmax scale, applied at the end)
       }
 #pragma unroll
     for (int u = 0; u < 4; u++) {
       const bf16x8 db = pack8(s[u >> 1], 8 * (u & 1));
 #pragma unroll
-      for (int dt = 0; dt < 3; dt++) dq[dt] = mfma32(trfrag(ldsK, dt, u, lane), db, dq[dt]);
+      for (int dt = 0; dt < 3; dt++) dq[dt] = mfma32(trfrag(sK, dt, u, lane), db, dq[dt]);
     }
+  };
+  const int T = (kvlen + BKV - 1) / BKV;
+  if (T > 0) {
+    dma_tile(smem, Kp, kts, 0, kvlen, pl, wave);
+    dma_tile(smem + TILE_B, Vp, vts, 0, kvlen, pl, wave);
+  }
+  for (int t = 0; t < T; t++) {
+    char* st = smem + (t & 1) * 2 * TILE_B;
+    __syncthreads();
+    if (t + 1 < T) {
+      char* nx = smem + ((t + 1) & 1) * 2 * TILE_B;
+      dma_tile(nx, Kp, kts, (t + 1) * BKV, kvlen, pl, wave);
+      dma_tile(nx + TILE_B, Vp, vts, (t + 1) * BKV, kvlen, pl, wave);
+    }
+    if (t + 1 < T || (kvlen % BKV) == 0) tile(BoolC<false>{}, st, st + TILE_B, t * BKV);
+    else tile(BoolC<true>{}, st, st + TILE_B, t * BKV);
   }
   if (qvalid) store_rows(p.dQ + (long)b * p.dq_bs + (long)q * p.dq_ts + (long)h * p.dq_hs, dq, p.scale, hi);
 }
 
 // ------------------------------------------------------------------------------------------------ backward: dK, dV
 __global__ __launch_bounds__(256, ATTN_BWD_WAVES) void attn_bwd_dkv_kernel(AttnParams p) {
-  __shared__ __attribute__((aligned(16))) char ldsQ[BKV * S_SWZ];
-  __shared__ __attribute__((aligned(16))) char ldsD[BKV * S_SWZ];
-  __shared__ __attribute__((aligned(16))) float ldsL[BKV];
-  __shared__ __attribute__((aligned(16))) float ldsDl[BKV];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, hi = lane >> 5;
+  __shared__ __attribute__((aligned(16))) char smem[4 * TILE_B + 4 * BKV * 4];   // 2 stages x {Q, dO} + 2 stages x {lse, delta}
+  float* ldsL = reinterpret_cast<float*>(smem + 4 * TILE_B);                      // [2][2][64]
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), hi = lane >> 5;
   const int b = blockIdx.z, h = blockIdx.y;
   long kbase, vbase, dkbase, dvbase; int kvlen;
   kv_range(p, b, kbase, vbase, dkbase, dvbase, kvlen);
@@ -336,32 +347,38 @@ __global__ __launch_bounds__(256, ATTN_BWD_WAVES) void attn_bwd_dkv_kernel(AttnP
   const bf16_t* Dp = p.dO + (long)b * p.o_bs + (long)h * p.o_hs;
   const float* Lp = p.LSE + ((long)b * p.H + h) * p.Nq;
   const float* Dl = p.Delta + ((long)b * p.H + h) * p.Nq;
-  zero_pad<true>(ldsQ, tid);
-  zero_pad<true>(ldsD, tid);
+  const int qts = (int)p.q_ts, ots = (int)p.o_ts;
+  DmaPlan pl;
+  dma_plan(pl, wave, lane);
 
   f32x16 dk[3], dv[3];
   zero3(dk);
   zero3(dv);
   const float c = p.scale_log2;
-  uint4 rq[PF], rd[PF];
+  const int T = (p.Nq + BKV - 1) / BKV;
   float rl = INFINITY, rdl = 0.f;
-  auto fetch = [&](int q0) {
-    tile_g2r(rq, Qp, p.q_ts, q0, p.Nq, tid);
-    tile_g2r(rd, Dp, p.o_ts, q0, p.Nq, tid);
+  auto fetch_stats = [&](int q0) {
     if (tid < BKV) {
       const bool ok = q0 + tid < p.Nq;
       rl = ok ? Lp[q0 + tid] : INFINITY;    // +inf -> P = exp2(-inf) = 0 for rows beyond Nq
       rdl = ok ? Dl[q0 + tid] : 0.f;
     }
   };
-  fetch(0);
-  for (int q0 = 0; q0 < p.Nq; q0 += BKV) {
+  dma_tile(smem, Qp, qts, 0, p.Nq, pl, wave);
+  dma_tile(smem + TILE_B, Dp, ots, 0, p.Nq, pl, wave);
+  fetch_stats(0);
+  for (int t = 0; t < T; t++) {
+    const char* sQ = smem + (t & 1) * 2 * TILE_B;
+    const char* sD = sQ + TILE_B;
+    float* sL = ldsL + (t & 1) * 2 * BKV;
+    if (tid < BKV) { sL[tid] = rl; sL[BKV + tid] = rdl; }   // buffer (t&1) was last read two iterations ago
     __syncthreads();
-    tile_r2s<true>(ldsQ, rq, tid);
-    tile_r2s<true>(ldsD, rd, tid);
-    if (tid < BKV) { ldsL[tid] = rl; ldsDl[tid] = rdl; }
-    __syncthreads();
-    if (q0 + BKV < p.Nq) fetch(q0 + BKV);
+    if (t + 1 < T) {
+      char* nx = smem + ((t + 1) & 1) * 2 * TILE_B;
+      dma_tile(nx, Qp, qts, (t + 1) * BKV, p.Nq, pl, wave);
+      dma_tile(nx + TILE_B, Dp, ots, (t + 1) * BKV, p.Nq, pl, wave);
+      fetch_stats((t + 1) * BKV);
+    }
 #pragma unroll
     for (int sub = 0; sub < 2; sub++) {
       f32x16 s, dp;
@@ -369,14 +386,14 @@ __global__ __launch_bounds__(256, ATTN_BWD_WAVES) void attn_bwd_dkv_kernel(AttnP
       for (int g = 0; g < 16; g++) { s[g] = 0.f; dp[g] = 0.f; }
 #pragma unroll
       for (int ks = 0; ks < KSTEPS; ks++) {
-        s = mfma32(rowfrag<true>(ldsQ, sub, ks, lane), kf[ks], s);    // S[q][kv], col = kv (lane), rows = q
-        dp = mfma32(rowfrag<true>(ldsD, sub, ks, lane), vf[ks], dp);  // dP[q][kv]
+        s = mfma32(rowfrag(sQ, sub, ks, lane), kf[ks], s);    // S[q][kv], col = kv (lane), rows = q
+        dp = mfma32(rowfrag(sD, sub, ks, lane), vf[ks], dp);  // dP[q][kv]
       }
 #pragma unroll
       for (int qd = 0; qd < 4; qd++) {
         const int ql = sub * 32 + 8 * qd + 4 * hi;
-        const float4 L4 = *reinterpret_cast<const float4*>(&ldsL[ql]);
-        const float4 D4 = *reinterpret_cast<const float4*>(&ldsDl[ql]);
+        const float4 L4 = *reinterpret_cast<const float4*>(&sL[ql]);
+        const float4 D4 = *reinterpret_cast<const float4*>(&sL[BKV + ql]);
         const float Lv[4] = {L4.x, L4.y, L4.z, L4.w}, Dv[4] = {D4.x, D4.y, D4.z, D4.w};
 #pragma unroll
         for (int e = 0; e < 4; e++) {
@@ -391,8 +408,8 @@ __global__ __launch_bounds__(256, ATTN_BWD_WAVES) void attn_bwd_dkv_kernel(AttnP
         const int u = sub * 2 + uu;
 #pragma unroll
         for (int dt = 0; dt < 3; dt++) {
-          dv[dt] = mfma32(trfrag(ldsD, dt, u, lane), pb, dv[dt]);
-          dk[dt] = mfma32(trfrag(ldsQ, dt, u, lane), db, dk[dt]);
+          dv[dt] = mfma32(trfrag(sD, dt, u, lane), pb, dv[dt]);
+          dk[dt] = mfma32(trfrag(sQ, dt, u, lane), db, dk[dt]);
         }
       }
     }
