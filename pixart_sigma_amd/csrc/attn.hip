@@ -28,8 +28,10 @@ constexpr int KSTEPS = 5;            // ceil(72/16)
 //   * ds_read_b128 serves 16-lane groups whose rows cover all residues mod 16; a bare 192-byte stride would pile rows r, r+4,
 //     r+8, r+12 onto one 16-byte slot (4-way conflict), the XOR separates them -> conflict-free.
 // Tiles are filled by LDS-DMA (global_load_lds_dwordx4: wave-uniform LDS base + lane*16, per-lane source address), so the image
-// is lane-linear and the swizzle lives in the SOURCE address (guide rule 21).  Pad chunks receive a duplicate of chunk 0 and rows
-// beyond the valid range a duplicate of the last valid row: only finite values, always multiplied by a zero operand or masked.
+// is lane-linear and the swizzle lives in the SOURCE address (guide rule 21).  Lanes that map to pad chunks are exec-masked
+// (no DMA, 25 % less traffic); the pads are written once per kernel: zero, except that the forward's V tiles carry 1.0 in
+// column 72 so the PV MFMA also produces the softmax row-sum (row 72 of O^T).  Rows beyond the valid range receive a duplicate
+// of the last valid row (finite, masked by index).
 constexpr int ROWB = 192;
 constexpr int TILE_B = 64 * ROWB;        // 12288 B per tile
 constexpr int BKV = 64;
@@ -67,19 +69,31 @@ __device__ __forceinline__ void dma_plan(DmaPlan& pl, int wave, int lane) {
 #pragma unroll
   for (int i = 0; i < NDMA; i++) {
     const int p = (i * 4 + wave) * 64 + lane, r = p / 12, cl = p - r * 12;
-    int c = cl ^ ((r >> 2) & 3);
-    c = c < NCH ? c : 0;
+    const int c = cl ^ ((r >> 2) & 3);
     pl.row[i] = r;
-    pl.coff[i] = c * 8;
+    pl.coff[i] = c < NCH ? c * 8 : -1;       // pad chunk: this lane issues no DMA (the pads are written once at kernel start)
   }
 }
+// Source addresses are wave-uniform base (SGPR pair) + 32-bit per-lane element offset, so the DMA uses the saddr form and
+// the per-tile address update is one integer add per chunk.  `FULL` tiles need no row clamp.
+template <bool FULL>
 __device__ __forceinline__ void dma_tile(char* lds, const bf16_t* __restrict__ base, int ts, int row0, int nrows, const DmaPlan& pl, int wave) {
 #pragma unroll
   for (int i = 0; i < NDMA; i++) {
-    const int gr = min(row0 + pl.row[i], nrows - 1);
-    const bf16_t* src = base + (long)gr * ts + pl.coff[i];
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                     (__attribute__((address_space(3))) void*)(lds + (i * 4 + wave) * 1024), 16, 0, 0);
+    const int gr = FULL ? row0 + pl.row[i] : min(row0 + pl.row[i], nrows - 1);
+    const unsigned off = (unsigned)(gr * ts + pl.coff[i]);
+    if (pl.coff[i] >= 0)                       // exec-masked: inactive lanes write nothing (LDS address = M0 + lane*16)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + off),
+                                       (__attribute__((address_space(3))) void*)(lds + (i * 4 + wave) * 1024), 16, 0, 0);
+  }
+}
+// one-time pad initialisation of a [64][12-chunk] tile: chunks 9..11 <- 0, optionally element (row, 72) <- 1.0
+__device__ __forceinline__ void init_pads(char* tile, bool ones_col72, int tid) {
+  for (int i = tid; i < BKV * 3; i += 256) {
+    const int r = i / 3, c = NCH + (i - r * 3);
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (ones_col72 && c == NCH) v.x = 0x3f80u;   // bf16 1.0 in the low half = column 72
+    *reinterpret_cast<uint4*>(tile + soff(r, c)) = v;
   }
 }
 // B-operand fragments of a row held in registers: X[row][ks*16 + 8*hi .. +8], zero for d >= 72 or invalid row
@@ -92,17 +106,28 @@ __device__ __forceinline__ void load_row_frags(bf16x8 (&f)[KSTEPS], const bf16_t
     f[ks] = __builtin_bit_cast(bf16x8, v);
   }
 }
+// Fragment addressing with per-lane constants + compile-time immediates.  With s = ((lane&31)>>2)&3 the XOR swizzle only touches
+// the low two chunk bits, and sub*32 / 16u / dt*4 are multiples of 4 (rows) resp. 4 (chunks), so:
+//   rowfrag(sub, ks)  = lds + rb[ks&1] + sub*32*ROWB + (ks>>1)*64       rb[e] = r*ROWB + (((2e + hi) ^ s) << 4),  r = lane&31
+//   trfrag(dt, u)     = lds + tb[h]    + u*16*ROWB  + dt*64            tb[h] = row_h*ROWB + ((cc ^ s_h) << 4) + sub8
+struct FragAddr { int rb[2], tb[2]; };
+__device__ __forceinline__ void frag_addr(FragAddr& fa, int lane) {
+  const int r = lane & 31, hi = lane >> 5, s = (r >> 2) & 3;
+  fa.rb[0] = r * ROWB + (((0 + hi) ^ s) << 4);
+  fa.rb[1] = r * ROWB + (((2 + hi) ^ s) << 4);
+  const int gg = lane >> 4, tt = lane & 15, h2 = gg >> 1;
+  const int row0 = 4 * h2 + (tt >> 2), cc = 2 * (gg & 1) + ((tt & 3) >> 1), sub8 = (tt & 1) * 8;
+  fa.tb[0] = row0 * ROWB + ((cc ^ ((row0 >> 2) & 3)) << 4) + sub8;
+  fa.tb[1] = (row0 + 8) * ROWB + ((cc ^ (((row0 + 8) >> 2) & 3)) << 4) + sub8;
+}
 // A-operand from a row-major tile: rows sub*32 + (lane&31), k = d
-__device__ __forceinline__ bf16x8 rowfrag(const char* lds, int sub, int ks, int lane) {
-  return *reinterpret_cast<const bf16x8*>(lds + soff(sub * 32 + (lane & 31), ks * 2 + (lane >> 5)));
+__device__ __forceinline__ bf16x8 rowfrag(const char* lds, const FragAddr& fa, int sub, int ks) {
+  return *reinterpret_cast<const bf16x8*>(lds + fa.rb[ks & 1] + sub * 32 * ROWB + (ks >> 1) * 64);
 }
 // A-operand X^T[d = dt*32 + (lane&31)][k-slots of step u] from a row-major [row][d] tile via transpose reads.
 // slot j <-> row 16u + (j&3) + 8*(j>>2) + 4*hi : the same permutation the accumulator layout gives the B operand.
-__device__ __forceinline__ bf16x8 trfrag(const char* lds, int dt, int u, int lane) {
-  const int gg = lane >> 4, tt = lane & 15, hi = gg >> 1;
-  const int row = 16 * u + 4 * hi + (tt >> 2);
-  const int c = dt * 4 + 2 * (gg & 1) + ((tt & 3) >> 1), sub8 = (tt & 1) * 8;
-  return concat_tr(lds_tr_read(lds + soff(row, c) + sub8), lds_tr_read(lds + soff(row + 8, c) + sub8));
+__device__ __forceinline__ bf16x8 trfrag(const char* lds, const FragAddr& fa, int dt, int u) {
+  return concat_tr(lds_tr_read(lds + fa.tb[0] + u * 16 * ROWB + dt * 64), lds_tr_read(lds + fa.tb[1] + u * 16 * ROWB + dt * 64));
 }
 __device__ __forceinline__ bf16x8 pack8(const f32x16& v, int off) {
   bf16x8 r;
@@ -146,10 +171,16 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
   load_row_frags(qf, p.Q + (long)b * p.q_bs + (long)q * p.q_ts + (long)h * p.q_hs, qvalid, hi);
   DmaPlan pl;
   dma_plan(pl, wave, lane);
+  FragAddr fa;
+  frag_addr(fa, lane);
 
+  for (int st = 0; st < 2; st++) {
+    init_pads(smem + st * 2 * TILE_B, false, tid);            // K
+    init_pads(smem + st * 2 * TILE_B + TILE_B, true, tid);    // V: column 72 = 1 -> O^T row 72 accumulates sum_kv P = l
+  }
   f32x16 o[3];
   zero3(o);
-  float m = -INFINITY, l = 0.f;
+  float m = -INFINITY;
   const float c = p.scale_log2;
 
   auto tile = [&](auto tailc, const char* sK, const char* sV, int kv0) {
@@ -160,7 +191,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
 #pragma unroll
       for (int g = 0; g < 16; g++) s[sub][g] = 0.f;
 #pragma unroll
-      for (int ks = 0; ks < KSTEPS; ks++) s[sub] = mfma32(rowfrag(sK, sub, ks, lane), qf[ks], s[sub]);
+      for (int ks = 0; ks < KSTEPS; ks++) s[sub] = mfma32(rowfrag(sK, fa, sub, ks), qf[ks], s[sub]);
     }
     if (TAIL) {
 #pragma unroll
@@ -179,51 +210,53 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
     // P is then bounded by 2^RESCALE_LOG2 instead of 1 (bf16 keeps its relative precision, l and O are fp32).  When the branch
     // fires, O and l — everything still expressed against the old max — are scaled exactly once, before any P of this tile.
     if (__builtin_amdgcn_readfirstlane(__any((mt - m) * c > RESCALE_LOG2))) {
+      asm volatile("" ::: "memory");       // keep this a real (rare) branch: if-conversion would run the 48 multiplies every tile
       const float mn = fmaxf(m, mt);
       const float alpha = __builtin_amdgcn_exp2f((m - mn) * c);
       m = mn;
-      l *= alpha;
 #pragma unroll
       for (int dt = 0; dt < 3; dt++)
 #pragma unroll
-        for (int g = 0; g < 16; g++) o[dt][g] *= alpha;
+        for (int g = 0; g < 16; g++) o[dt][g] *= alpha;   // includes the row-sum row (d = 72)
     }
     const float mc = m * c;
-    float ps = 0.f;
 #pragma unroll
     for (int sub = 0; sub < 2; sub++)
 #pragma unroll
-      for (int g = 0; g < 16; g++) {
-        const float e = __builtin_amdgcn_exp2f(s[sub][g] * c - mc);
-        s[sub][g] = e;
-        ps += e;
-      }
-    l += ps;
+      for (int g = 0; g < 16; g++) s[sub][g] = __builtin_amdgcn_exp2f(s[sub][g] * c - mc);
 #pragma unroll
     for (int u = 0; u < 4; u++) {
       const bf16x8 pb = pack8(s[u >> 1], 8 * (u & 1));
 #pragma unroll
-      for (int dt = 0; dt < 3; dt++) o[dt] = mfma32(trfrag(sV, dt, u, lane), pb, o[dt]);
+      for (int dt = 0; dt < 3; dt++) o[dt] = mfma32(trfrag(sV, fa, dt, u), pb, o[dt]);
     }
   };
 
-  const int T = (kvlen + BKV - 1) / BKV;
-  if (T > 0) {
-    dma_tile(smem, Kp, kts, 0, kvlen, pl, wave);
-    dma_tile(smem + TILE_B, Vp, vts, 0, kvlen, pl, wave);
-  }
-  for (int t = 0; t < T; t++) {
-    char* st = smem + (t & 1) * 2 * TILE_B;
-    __syncthreads();                       // own DMA drained (vmcnt(0)) + stage hand-over; ONE barrier per tile
-    if (t + 1 < T) {
-      char* nx = smem + ((t + 1) & 1) * 2 * TILE_B;
-      dma_tile(nx, Kp, kts, (t + 1) * BKV, kvlen, pl, wave);
-      dma_tile(nx + TILE_B, Vp, vts, (t + 1) * BKV, kvlen, pl, wave);
+  const int Tfull = kvlen / BKV, rem = kvlen - Tfull * BKV, T = Tfull + (rem ? 1 : 0);
+  auto issue = [&](int t) {                // DMA of tile t into stage t&1
+    char* nx = smem + (t & 1) * 2 * TILE_B;
+    if (t < Tfull) {
+      dma_tile<true>(nx, Kp, kts, t * BKV, kvlen, pl, wave);
+      dma_tile<true>(nx + TILE_B, Vp, vts, t * BKV, kvlen, pl, wave);
+    } else {
+      dma_tile<false>(nx, Kp, kts, t * BKV, kvlen, pl, wave);
+      dma_tile<false>(nx + TILE_B, Vp, vts, t * BKV, kvlen, pl, wave);
     }
-    if (t + 1 < T || (kvlen % BKV) == 0) tile(BoolC<false>{}, st, st + TILE_B, t * BKV);
-    else tile(BoolC<true>{}, st, st + TILE_B, t * BKV);
+  };
+  if (T > 0) issue(0);
+  for (int t = 0; t < Tfull; t++) {
+    __syncthreads();                       // own DMA drained (vmcnt(0)) + stage hand-over; ONE barrier per tile
+    if (t + 1 < T) issue(t + 1);
+    const char* st = smem + (t & 1) * 2 * TILE_B;
+    tile(BoolC<false>{}, st, st + TILE_B, t * BKV);
   }
-  l += __shfl_xor(l, 32);
+  if (rem) {                               // ragged last tile: the only place that pays for masking
+    __syncthreads();
+    const char* st = smem + (Tfull & 1) * 2 * TILE_B;
+    tile(BoolC<true>{}, st, st + TILE_B, Tfull * BKV);
+  }
+  // row 72 of O^T (dt = 2, g = 4, lanes with hi = 0) = sum over keys of the bf16 P actually multiplied into O
+  const float l = __shfl(o[2][4], lane & 31);
   if (qvalid) {
     const float inv = l > 0.f ? 1.f / l : 0.f;
     store_rows(p.O + (long)b * p.o_bs + (long)q * p.o_ts + (long)h * p.o_hs, o, inv, hi);
@@ -277,7 +310,10 @@ __global__ __launch_bounds__(256, ATTN_BWD_WAVES) void attn_bwd_dq_kernel(AttnPa
   const float delta = qvalid ? p.Delta[sidx] : 0.f;
   DmaPlan pl;
   dma_plan(pl, wave, lane);
+  FragAddr fa;
+  frag_addr(fa, lane);
 
+  for (int st = 0; st < 4; st++) init_pads(smem + st * TILE_B, false, tid);
   f32x16 dq[3];
   zero3(dq);
   const float c = p.scale_log2;
@@ -290,8 +326,8 @@ __global__ __launch_bounds__(256, ATTN_BWD_WAVES) void attn_bwd_dq_kernel(AttnPa
       for (int g = 0; g < 16; g++) { s[sub][g] = 0.f; dp[sub][g] = 0.f; }
 #pragma unroll
       for (int ks = 0; ks < KSTEPS; ks++) {
-        s[sub] = mfma32(rowfrag(sK, sub, ks, lane), qf[ks], s[sub]);
-        dp[sub] = mfma32(rowfrag(sV, sub, ks, lane), dof[ks], dp[sub]);
+        s[sub] = mfma32(rowfrag(sK, fa, sub, ks), qf[ks], s[sub]);
+        dp[sub] = mfma32(rowfrag(sV, fa, sub, ks), dof[ks], dp[sub]);
       }
     }
 #pragma unroll
@@ -306,24 +342,31 @@ __global__ __launch_bounds__(256, ATTN_BWD_WAVES) void attn_bwd_dq_kernel(AttnPa
     for (int u = 0; u < 4; u++) {
       const bf16x8 db = pack8(s[u >> 1], 8 * (u & 1));
 #pragma unroll
-      for (int dt = 0; dt < 3; dt++) dq[dt] = mfma32(trfrag(sK, dt, u, lane), db, dq[dt]);
+      for (int dt = 0; dt < 3; dt++) dq[dt] = mfma32(trfrag(sK, fa, dt, u), db, dq[dt]);
     }
   };
-  const int T = (kvlen + BKV - 1) / BKV;
-  if (T > 0) {
-    dma_tile(smem, Kp, kts, 0, kvlen, pl, wave);
-    dma_tile(smem + TILE_B, Vp, vts, 0, kvlen, pl, wave);
-  }
-  for (int t = 0; t < T; t++) {
-    char* st = smem + (t & 1) * 2 * TILE_B;
-    __syncthreads();
-    if (t + 1 < T) {
-      char* nx = smem + ((t + 1) & 1) * 2 * TILE_B;
-      dma_tile(nx, Kp, kts, (t + 1) * BKV, kvlen, pl, wave);
-      dma_tile(nx + TILE_B, Vp, vts, (t + 1) * BKV, kvlen, pl, wave);
+  const int Tfull = kvlen / BKV, rem = kvlen - Tfull * BKV, T = Tfull + (rem ? 1 : 0);
+  auto issue = [&](int t) {                // DMA of tile t into stage t&1
+    char* nx = smem + (t & 1) * 2 * TILE_B;
+    if (t < Tfull) {
+      dma_tile<true>(nx, Kp, kts, t * BKV, kvlen, pl, wave);
+      dma_tile<true>(nx + TILE_B, Vp, vts, t * BKV, kvlen, pl, wave);
+    } else {
+      dma_tile<false>(nx, Kp, kts, t * BKV, kvlen, pl, wave);
+      dma_tile<false>(nx + TILE_B, Vp, vts, t * BKV, kvlen, pl, wave);
     }
-    if (t + 1 < T || (kvlen % BKV) == 0) tile(BoolC<false>{}, st, st + TILE_B, t * BKV);
-    else tile(BoolC<true>{}, st, st + TILE_B, t * BKV);
+  };
+  if (T > 0) issue(0);
+  for (int t = 0; t < Tfull; t++) {
+    __syncthreads();                       // own DMA drained (vmcnt(0)) + stage hand-over; ONE barrier per tile
+    if (t + 1 < T) issue(t + 1);
+    const char* st = smem + (t & 1) * 2 * TILE_B;
+    tile(BoolC<false>{}, st, st + TILE_B, t * BKV);
+  }
+  if (rem) {                               // ragged last tile: the only place that pays for masking
+    __syncthreads();
+    const char* st = smem + (Tfull & 1) * 2 * TILE_B;
+    tile(BoolC<true>{}, st, st + TILE_B, Tfull * BKV);
   }
   if (qvalid) store_rows(p.dQ + (long)b * p.dq_bs + (long)q * p.dq_ts + (long)h * p.dq_hs, dq, p.scale, hi);
 }
@@ -350,7 +393,10 @@ __global__ __launch_bounds__(256, ATTN_BWD_WAVES) void attn_bwd_dkv_kernel(AttnP
   const int qts = (int)p.q_ts, ots = (int)p.o_ts;
   DmaPlan pl;
   dma_plan(pl, wave, lane);
+  FragAddr fa;
+  frag_addr(fa, lane);
 
+  for (int st = 0; st < 4; st++) init_pads(smem + st * TILE_B, false, tid);
   f32x16 dk[3], dv[3];
   zero3(dk);
   zero3(dv);
@@ -364,21 +410,26 @@ __global__ __launch_bounds__(256, ATTN_BWD_WAVES) void attn_bwd_dkv_kernel(AttnP
       rdl = ok ? Dl[q0 + tid] : 0.f;
     }
   };
-  dma_tile(smem, Qp, qts, 0, p.Nq, pl, wave);
-  dma_tile(smem + TILE_B, Dp, ots, 0, p.Nq, pl, wave);
-  fetch_stats(0);
+  const int Tfull = p.Nq / BKV;
+  auto issue = [&](int t) {
+    char* nx = smem + (t & 1) * 2 * TILE_B;
+    if (t < Tfull) {
+      dma_tile<true>(nx, Qp, qts, t * BKV, p.Nq, pl, wave);
+      dma_tile<true>(nx + TILE_B, Dp, ots, t * BKV, p.Nq, pl, wave);
+    } else {
+      dma_tile<false>(nx, Qp, qts, t * BKV, p.Nq, pl, wave);
+      dma_tile<false>(nx + TILE_B, Dp, ots, t * BKV, p.Nq, pl, wave);
+    }
+    fetch_stats(t * BKV);
+  };
+  issue(0);
   for (int t = 0; t < T; t++) {
     const char* sQ = smem + (t & 1) * 2 * TILE_B;
     const char* sD = sQ + TILE_B;
     float* sL = ldsL + (t & 1) * 2 * BKV;
     if (tid < BKV) { sL[tid] = rl; sL[BKV + tid] = rdl; }   // buffer (t&1) was last read two iterations ago
     __syncthreads();
-    if (t + 1 < T) {
-      char* nx = smem + ((t + 1) & 1) * 2 * TILE_B;
-      dma_tile(nx, Qp, qts, (t + 1) * BKV, p.Nq, pl, wave);
-      dma_tile(nx + TILE_B, Dp, ots, (t + 1) * BKV, p.Nq, pl, wave);
-      fetch_stats((t + 1) * BKV);
-    }
+    if (t + 1 < T) issue(t + 1);
 #pragma unroll
     for (int sub = 0; sub < 2; sub++) {
       f32x16 s, dp;
@@ -386,8 +437,8 @@ __global__ __launch_bounds__(256, ATTN_BWD_WAVES) void attn_bwd_dkv_kernel(AttnP
       for (int g = 0; g < 16; g++) { s[g] = 0.f; dp[g] = 0.f; }
 #pragma unroll
       for (int ks = 0; ks < KSTEPS; ks++) {
-        s = mfma32(rowfrag(sQ, sub, ks, lane), kf[ks], s);    // S[q][kv], col = kv (lane), rows = q
-        dp = mfma32(rowfrag(sD, sub, ks, lane), vf[ks], dp);  // dP[q][kv]
+        s = mfma32(rowfrag(sQ, fa, sub, ks), kf[ks], s);    // S[q][kv], col = kv (lane), rows = q
+        dp = mfma32(rowfrag(sD, fa, sub, ks), vf[ks], dp);  // dP[q][kv]
       }
 #pragma unroll
       for (int qd = 0; qd < 4; qd++) {
@@ -408,8 +459,8 @@ __global__ __launch_bounds__(256, ATTN_BWD_WAVES) void attn_bwd_dkv_kernel(AttnP
         const int u = sub * 2 + uu;
 #pragma unroll
         for (int dt = 0; dt < 3; dt++) {
-          dv[dt] = mfma32(trfrag(sD, dt, u, lane), pb, dv[dt]);
-          dk[dt] = mfma32(trfrag(sQ, dt, u, lane), db, dk[dt]);
+          dv[dt] = mfma32(trfrag(sD, fa, dt, u), pb, dv[dt]);
+          dk[dt] = mfma32(trfrag(sQ, fa, dt, u), db, dk[dt]);
         }
       }
     }
