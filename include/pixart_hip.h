@@ -62,9 +62,9 @@ int pxa_gemm(const pxa_gemm_args* args, hipStream_t stream);
 int pxa_ln_mod_fwd(const float* x, const void* u_bf16, const float* gate, int gate_stride, const float* shift, const float* scale, int mod_stride,
                    float* x_out, void* xn_bf16, void* xb_bf16, float* mean, float* rstd,
                    int R, int D, int rows_per_batch, float eps, hipStream_t stream);
-/* dx_out = dx_in + dLN(dy*(1+scale));  dshift[b] += sum dy;  dscale[b] += sum dy*xhat  (atomic; caller zeroes). */
+/* dx_out = dx_in + dLN(dy*(1+scale)) (optionally also as bf16);  dshift[b] += sum dy;  dscale[b] += sum dy*xhat  (atomic; caller zeroes). */
 int pxa_ln_mod_bwd(const void* dy_bf16, const float* x, const float* mean, const float* rstd, const float* scale, int mod_stride,
-                   const float* dx_in, float* dx_out, float* dshift, float* dscale, int dmod_stride,
+                   const float* dx_in, float* dx_out, void* dx_bf16, float* dshift, float* dscale, int dmod_stride,
                    int R, int D, int rows_per_batch, hipStream_t stream);
 /* g = dx (+ add_bf16);  dx_out = g (optional);  du = gate*g (bf16; plain cast if gate NULL);  dgate[b] += sum g*u. */
 int pxa_gate_bwd(const float* dx, const void* add_bf16, const void* u_bf16, const float* gate, int mod_stride,

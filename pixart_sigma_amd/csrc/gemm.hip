@@ -27,7 +27,7 @@ struct GemmParams {
   const float* bias; const bf16_t* aux; int ldaux;
   bf16_t* out; bf16_t* out2; int ldo;
   float* outf; int ldf;
-  int act, accumulate, k_per_split, tile_hint;
+  int act, accumulate, k_per_split, tile_hint, split;
 };
 
 // ---- global -> registers (4 x 16 B per thread per operand tile), zero-filled out of bounds
@@ -86,14 +86,16 @@ __device__ __forceinline__ bf16x8 frag(const char* lds, int rbase, int ks, int l
 // and 8 B panels (K = 1152: 2 x 2.4 MB) are fetched once into that L2 and reused 8x, instead of 8 XCDs each streaming
 // every panel.  Bijective for any tile count.
 constexpr int NXCD = 8, GROUP_M = 8;
-__device__ __forceinline__ void tile_coords(int bid, int mt, int nt, int& tm, int& tn) {
-  const int T = mt * nt, q = T / NXCD, r = T % NXCD;
+__device__ __forceinline__ void tile_coords(int bid, int mt, int nt, int split, int& tm, int& tn, int& z) {
+  const int tiles = mt * nt, T = tiles * split, q = T / NXCD, r = T % NXCD;
   const int x = bid % NXCD, idx = bid / NXCD;
   const int L = x * q + min(x, r) + idx;               // logical id: XCD x owns [x*q + min(x,r), +q + (x<r))
+  z = L / tiles;                                       // split-K slice major: an XCD's range shares its k-range
+  const int t = L - z * tiles;
   const int per_group = GROUP_M * nt;
-  const int g = L / per_group, first_m = g * GROUP_M;
+  const int g = t / per_group, first_m = g * GROUP_M;
   const int gsz = min(mt - first_m, GROUP_M);
-  const int in_g = L - g * per_group;
+  const int in_g = t - g * per_group;
   tm = first_m + in_g % gsz;
   tn = in_g / gsz;
 }
@@ -150,10 +152,10 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
   constexpr int STAGE = A_BYTES + B_BYTES;  // stage s: [A tile][B tile] at smem + s*STAGE
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1, hi = lane >> 5;
-  int tm_, tn_;
-  tile_coords(blockIdx.x, (p.M + BM - 1) / BM, (p.N + BN - 1) / BN, tm_, tn_);
+  int tm_, tn_, z_;
+  tile_coords(blockIdx.x, (p.M + BM - 1) / BM, (p.N + BN - 1) / BN, p.split, tm_, tn_, z_);
   const int m0 = tm_ * BM, n0 = tn_ * BN;
-  const int kbeg = blockIdx.z * p.k_per_split;
+  const int kbeg = z_ * p.k_per_split;
   const int kend = min(p.K, kbeg + p.k_per_split);
   const int nk = (kend - kbeg + BK - 1) / BK;
 
@@ -304,10 +306,10 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_glds_kernel(GemmParams p) {
   constexpr int A_BYTES = TBM * 128, B_BYTES = TBN * 128, STAGE = A_BYTES + B_BYTES;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), wm = wave / WN, wn = wave % WN, hi = lane >> 5;
-  int tm_, tn_;
-  tile_coords(blockIdx.x, (p.M + TBM - 1) / TBM, (p.N + TBN - 1) / TBN, tm_, tn_);
+  int tm_, tn_, z_;
+  tile_coords(blockIdx.x, (p.M + TBM - 1) / TBM, (p.N + TBN - 1) / TBN, p.split, tm_, tn_, z_);
   const int m0 = tm_ * TBM, n0 = tn_ * TBN;
-  const int kbeg = blockIdx.z * p.k_per_split;
+  const int kbeg = z_ * p.k_per_split;
   const int kend = min(p.K, kbeg + p.k_per_split);
   const int nk = (kend - kbeg) / BK;
 
@@ -358,7 +360,8 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_glds_kernel(GemmParams p) {
 }
 
 template <int LAYOUT, int TBM, int TBN, int WM, int WN>
-int launch_glds(const GemmParams& p, int split, hipStream_t s) {
+int launch_glds(GemmParams p, int split, hipStream_t s) {
+  p.split = split;
   constexpr int LDSG = 2 * (TBM + TBN) * 128;
   static bool attr_set_g = false;
   if (!attr_set_g) {
@@ -366,14 +369,15 @@ int launch_glds(const GemmParams& p, int split, hipStream_t s) {
     if (e != hipSuccess) { pxa_set_error("hipFuncSetAttribute(gemm_glds<%d,%d,%d>): %s", LAYOUT, TBM, TBN, hipGetErrorString(e)); return -3; }
     attr_set_g = true;
   }
-  dim3 grid(((p.M + TBM - 1) / TBM) * ((p.N + TBN - 1) / TBN), 1, split);
+  dim3 grid(((p.M + TBM - 1) / TBM) * ((p.N + TBN - 1) / TBN) * split, 1, 1);
   hipLaunchKernelGGL((gemm_glds_kernel<LAYOUT, TBM, TBN, WM, WN>), grid, dim3(WM * WN * 64), LDSG, s, p);
   PXA_LAUNCH_CHECK();
   return 0;
 }
 
 template <int LAYOUT>
-int launch(const GemmParams& p, int split, hipStream_t s) {
+int launch(GemmParams p, int split, hipStream_t s) {
+  p.split = split;
   constexpr bool A_KC = (LAYOUT != 2), B_KC = (LAYOUT == 0);
   constexpr int LDS = 2 * ((A_KC ? KC_BYTES : RC_BYTES) + (B_KC ? KC_BYTES : RC_BYTES));
   static bool attr_set = false;
@@ -382,7 +386,7 @@ int launch(const GemmParams& p, int split, hipStream_t s) {
     if (e != hipSuccess) { pxa_set_error("hipFuncSetAttribute(gemm<%d>, %d): %s", LAYOUT, LDS, hipGetErrorString(e)); return -3; }
     attr_set = true;
   }
-  dim3 grid(((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN), 1, split);
+  dim3 grid(((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN) * split, 1, 1);
   const bool fast = (p.K % BK == 0) && (p.k_per_split % BK == 0) && !getenv("PXA_GEMM_NO_GLDS");
   if (fast) {
     static const char* force = getenv("PXA_GEMM_TILE");   // "128" | "256x128" | "256" : A/B experiments

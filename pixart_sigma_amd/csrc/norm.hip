@@ -79,7 +79,7 @@ constexpr int BWD_ROWS = 16;  // rows per half-wave in the reducing backward ker
 template <int NV>
 __global__ __launch_bounds__(256) void ln_mod_bwd_kernel(
     const bf16_t* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ rstd,
-    const float* __restrict__ scale, int mod_stride, const float* dx_in, float* dx_out,
+    const float* __restrict__ scale, int mod_stride, const float* dx_in, float* dx_out, bf16_t* __restrict__ dx_bf16,
     float* __restrict__ dshift, float* __restrict__ dscale, int dmod_stride, int R, int D, int rows_per_batch) {
   const int hl = threadIdx.x & 31;
   const int chunk = blockIdx.x * 8 + (threadIdx.x >> 5);
@@ -133,6 +133,7 @@ __global__ __launch_bounds__(256) void ln_mod_bwd_kernel(
         o.x += di.x; o.y += di.y; o.z += di.z; o.w += di.w;
       }
       *reinterpret_cast<float4*>(dx_out + base + c) = o;
+      if (dx_bf16) *reinterpret_cast<uint2*>(dx_bf16 + base + c) = pack_bf16x4(o.x, o.y, o.z, o.w);
     }
   }
   flush(cur_b);
@@ -190,22 +191,39 @@ __global__ __launch_bounds__(256) void gate_bwd_kernel(
   flush(cur_b);
 }
 
-// db[n] += sum_r dY[r][n];  thread = 8 columns (16-byte loads), block = 128 threads x ROWS rows
-constexpr int CS_ROWS = 256;
-__global__ __launch_bounds__(128) void colsum_kernel(const bf16_t* __restrict__ dy, int ld, float* __restrict__ out, int R, int N) {
-  const int c = (blockIdx.x * 128 + threadIdx.x) * 8;
-  if (c >= N) return;
+// db[n] += sum_r dY[r][n].  Block = 64 column-threads (8 columns = one 16-byte load each, 512 columns) x 4 row-lanes over
+// CS_ROWS rows; 8 independent row loads in flight per thread; the row-lanes are combined through LDS, one atomic per column.
+constexpr int CS_ROWS = 128;
+__global__ __launch_bounds__(256) void colsum_kernel(const bf16_t* __restrict__ dy, int ld, float* __restrict__ out, int R, int N) {
+  __shared__ float red[4][64][8];
+  const int ct = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int c = (blockIdx.x * 64 + ct) * 8;
   const int r0 = blockIdx.y * CS_ROWS, r1 = min(R, r0 + CS_ROWS);
   float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  for (int r = r0; r < r1; r++) {
-    const uint4 v = *reinterpret_cast<const uint4*>(dy + (size_t)r * ld + c);
-    float f[8];
-    unpack_bf16x8(v, f);
+  if (c < N) {
+    for (int r = r0 + rl; r < r1; r += 32) {
+      uint4 v[8];
 #pragma unroll
-    for (int e = 0; e < 8; e++) acc[e] += f[e];
+      for (int u = 0; u < 8; u++) {
+        const int rr = r + 4 * u;
+        v[u] = rr < r1 ? *reinterpret_cast<const uint4*>(dy + (size_t)rr * ld + c) : make_uint4(0, 0, 0, 0);
+      }
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        float f[8];
+        unpack_bf16x8(v[u], f);
+#pragma unroll
+        for (int e = 0; e < 8; e++) acc[e] += f[e];
+      }
+    }
   }
 #pragma unroll
-  for (int e = 0; e < 8; e++) atomicAdd(out + c + e, acc[e]);
+  for (int e = 0; e < 8; e++) red[rl][ct][e] = acc[e];
+  __syncthreads();
+  if (rl == 0 && c < N) {
+#pragma unroll
+    for (int e = 0; e < 8; e++) atomicAdd(out + c + e, red[0][ct][e] + red[1][ct][e] + red[2][ct][e] + red[3][ct][e]);
+  }
 }
 
 #define DISPATCH_NV(D, CALL)                                            \
@@ -232,13 +250,13 @@ extern "C" int pxa_ln_mod_fwd(const float* x, const void* u_bf16, const float* g
 }
 
 extern "C" int pxa_ln_mod_bwd(const void* dy_bf16, const float* x, const float* mean, const float* rstd, const float* scale,
-                              int mod_stride, const float* dx_in, float* dx_out, float* dshift, float* dscale, int dmod_stride,
+                              int mod_stride, const float* dx_in, float* dx_out, void* dx_bf16, float* dshift, float* dscale, int dmod_stride,
                               int R, int D, int rows_per_batch, hipStream_t stream) {
   PXA_CHECK(dy_bf16 && x && mean && rstd && scale && dx_out && dshift && dscale, "pxa_ln_mod_bwd: null pointer");
   PXA_CHECK(R > 0 && D % 128 == 0 && rows_per_batch > 0, "pxa_ln_mod_bwd: bad shape");
   const int chunks = (R + BWD_ROWS - 1) / BWD_ROWS;
   DISPATCH_NV(D, hipLaunchKernelGGL(ln_mod_bwd_kernel<NV>, dim3((chunks + 7) / 8), dim3(256), 0, stream, (const bf16_t*)dy_bf16, x, mean, rstd,
-                                     scale, mod_stride, dx_in, dx_out, dshift, dscale, dmod_stride, R, D, rows_per_batch));
+                                     scale, mod_stride, dx_in, dx_out, (bf16_t*)dx_bf16, dshift, dscale, dmod_stride, R, D, rows_per_batch));
   PXA_LAUNCH_CHECK();
   return 0;
 }
@@ -257,8 +275,8 @@ extern "C" int pxa_gate_bwd(const float* dx, const void* add_bf16, const void* u
 
 extern "C" int pxa_colsum_bf16(const void* dy_bf16, int ld, float* out, int R, int N, hipStream_t stream) {
   PXA_CHECK(dy_bf16 && out && R > 0 && N % 8 == 0 && ld % 8 == 0, "pxa_colsum_bf16: bad args");
-  dim3 grid((N / 8 + 127) / 128, (R + CS_ROWS - 1) / CS_ROWS);
-  hipLaunchKernelGGL(colsum_kernel, grid, dim3(128), 0, stream, (const bf16_t*)dy_bf16, ld, out, R, N);
+  dim3 grid((N / 8 + 63) / 64, (R + CS_ROWS - 1) / CS_ROWS);
+  hipLaunchKernelGGL(colsum_kernel, grid, dim3(256), 0, stream, (const bf16_t*)dy_bf16, ld, out, R, N);
   PXA_LAUNCH_CHECK();
   return 0;
 }

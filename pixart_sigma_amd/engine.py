@@ -259,9 +259,8 @@ class Engine:
         dh = self._lin_bwd(du, sv["h"], p + "mlp.fc2", dx_kw=dict(act=ops.ACT_GELU_GRAD, aux=sv["hpre"]))
         dxn = self._lin_bwd(dh, sv["xn2"], p + "mlp.fc1")
         del dh
-        ops.ln_mod_bwd(dxn, sv["x2"], sv["mean2"], sv["rstd2"], mod[:, 4], st, G, G, dmod[:, 3], dmod[:, 4], st, N)
-        # ---- cross attention: x2 = x1 + u2 (no gate, no norm)
-        ops.gate_bwd(G, du=du, rows_per_batch=N)
+        # ---- cross attention: x2 = x1 + u2 (no gate, no norm): du2 = bf16(G2) comes out of the LN backward pass itself
+        ops.ln_mod_bwd(dxn, sv["x2"], sv["mean2"], sv["rstd2"], mod[:, 4], st, G, G, dmod[:, 3], dmod[:, 4], st, N, dx_bf16=du)
         dc = self._lin_bwd(du, sv["cr"], p + "cross_attn.proj")
         dqc = torch.empty((R, D), dtype=BF16, device=dev)
         dkvc = torch.empty_like(sv["kvc"])

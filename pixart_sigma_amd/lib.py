@@ -39,7 +39,7 @@ _P, _I, _L, _F = c_void_p, c_int, c_long, c_float
 SIGNATURES = {
     "pxa_gemm": [C.POINTER(GemmArgs), _P],
     "pxa_ln_mod_fwd": [_P, _P, _P, _I, _P, _P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _F, _P],
-    "pxa_ln_mod_bwd": [_P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _I, _I, _I, _I, _P],
+    "pxa_ln_mod_bwd": [_P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
     "pxa_gate_bwd": [_P, _P, _P, _P, _I, _P, _P, _P, _I, _I, _I, _I, _P],
     "pxa_colsum_bf16": [_P, _I, _P, _I, _I, _P],
     "pxa_attn_fwd": [C.POINTER(AttnArgs), _P],
