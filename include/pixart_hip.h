@@ -115,6 +115,15 @@ int pxa_gather_rows_bf16(const float* src, const float* alt, const int* row_idx,
 int pxa_kv_compress_fwd(const void* in_bf16, long in_bs, long in_ts, const float* conv_w, const float* conv_b,
                         const float* ln_w, const float* ln_b, void* out_bf16, int B, int H, int W, int C, int sr, float eps,
                         hipStream_t stream);
+/* Backward of the above for one of K / V: din (same strided layout as in) <- gradient w.r.t. the sr*sr source tokens of every
+ * compressed token; d_conv_w / d_conv_b / d_ln_w / d_ln_b += parameter gradients (atomic; the parameters are shared by K and V). */
+int pxa_kv_compress_bwd(const void* dyc_bf16, const void* in_bf16, long in_bs, long in_ts, const float* conv_w, const float* conv_b,
+                        const float* ln_w, void* din_bf16, long din_bs, long din_ts, float* d_conv_w, float* d_conv_b, float* d_ln_w,
+                        float* d_ln_b, int B, int H, int W, int C, int sr, float eps, hipStream_t stream);
+/* 'uniform' and 'ave' sampling (PixArt_blocks.py:110-115; nearest interpolation == strided pick): token (r*sr, c*sr) of the
+ * (H,W) grid.  backward=0: dst (B, nH*nW, C) <- picked rows of the strided src; backward=1: strided dst <- rows of src. */
+int pxa_kv_pick(int backward, const void* src_bf16, void* dst_bf16, long full_bs, long full_ts, int B, int H, int W, int C, int sr,
+                hipStream_t stream);
 
 /* ---------------------------------------------------------------------------------------------- optimizer
  * Global grad norm + clip coefficient (accelerator.clip_grad_norm_, train.py:182) and torch.optim.AdamW

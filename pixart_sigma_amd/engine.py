@@ -216,8 +216,16 @@ class Engine:
                 Nk = (N + sr - 1) // sr
                 sk = (N * 3 * D, 3 * D * sr, 72)
                 ops.attention_fwd(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], a, lse, B, H, N, Nk, (s3, sk, sk, (N * D, D, 72)))
+            elif c["kv_sampling"] in ("uniform", "ave"):      # 'ave' = nearest interpolation = the same strided pick (PixArt_blocks.py:110-115)
+                Nk = (hh // sr) * (ww // sr)
+                kc = torch.empty((B, Nk, D), dtype=BF16, device=qkv.device)
+                vc = torch.empty((B, Nk, D), dtype=BF16, device=qkv.device)
+                ops.kv_pick(qkv[:, D:2 * D], kc, N * 3 * D, 3 * D, B, hh, ww, D, sr)
+                ops.kv_pick(qkv[:, 2 * D:], vc, N * 3 * D, 3 * D, B, hh, ww, D, sr)
+                sk = (Nk * D, D, 72)
+                ops.attention_fwd(qkv[:, :D], kc, vc, a, lse, B, H, N, Nk, (s3, sk, sk, (N * D, D, 72)))
             else:
-                raise NotImplementedError(f"kv sampling mode {c['kv_sampling']!r} (conv and uniform_every are implemented)")
+                raise ValueError(f"unknown kv sampling mode {c['kv_sampling']!r}")
         else:
             ops.attention_fwd(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], a, lse, B, H, N, N, (s3, s3, s3, (N * D, D, 72)))
         u1 = self._lin(a, p + "attn.proj")
@@ -251,8 +259,6 @@ class Engine:
         mod, dmod = ctx["mod"][l], ctx["dmod"][l]
         st = 6 * D
         dev = G.device
-        if sv["sr"] > 1:
-            raise NotImplementedError("backward through KV-compressed attention layers is not implemented yet (DESIGN.md: next)")
         # ---- MLP branch: x3 = x2 + gate_mlp * u3
         du = torch.empty((R, D), dtype=BF16, device=dev)
         ops.gate_bwd(G, u=sv["u3"], gate=mod[:, 5], mod_stride=st, du=du, dgate=dmod[:, 5], dmod_stride=st, rows_per_batch=N)
@@ -275,10 +281,38 @@ class Engine:
         ops.gate_bwd(G, add=gq, u=sv["u1"], gate=mod[:, 2], mod_stride=st, dx_out=G, du=du, dgate=dmod[:, 2], dmod_stride=st, rows_per_batch=N)
         da = self._lin_bwd(du, sv["a"], p + "attn.proj")
         qkv = sv["qkv"]
-        dqkv = torch.empty_like(qkv)
         s3 = (N * 3 * D, 3 * D, 72)
-        ops.attention_bwd(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], sv["a"], da, sv["lse"], delta, dqkv[:, :D], dqkv[:, D:2 * D], dqkv[:, 2 * D:],
-                          B, H, N, N, (s3, s3, s3, (N * D, D, 72)), (s3, s3, s3))
+        so = (N * D, D, 72)
+        sr = sv["sr"]
+        if sr == 1:
+            dqkv = torch.empty_like(qkv)
+            ops.attention_bwd(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], sv["a"], da, sv["lse"], delta, dqkv[:, :D], dqkv[:, D:2 * D], dqkv[:, 2 * D:],
+                              B, H, N, N, (s3, s3, s3, so), (s3, s3, s3))
+        elif c["kv_sampling"] == "uniform_every":          # strided keys: gradients land on the picked tokens, the rest stay zero
+            dqkv = torch.zeros_like(qkv)
+            Nk = (N + sr - 1) // sr
+            sk = (N * 3 * D, 3 * D * sr, 72)
+            ops.attention_bwd(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], sv["a"], da, sv["lse"], delta, dqkv[:, :D], dqkv[:, D:2 * D], dqkv[:, 2 * D:],
+                              B, H, N, Nk, (s3, sk, sk, so), (s3, sk, sk))
+        else:                                               # compressed K/V buffers: attention backward, then the compression's backward
+            hh, ww = ctx["hw"]
+            kc, vc = sv["kc"], sv["vc"]
+            Nk = kc.shape[1]
+            sk = (Nk * D, D, 72)
+            covered = (hh % sr == 0) and (ww % sr == 0) and c["kv_sampling"] == "conv"
+            dqkv = torch.empty_like(qkv) if covered else torch.zeros_like(qkv)
+            dkc, dvc = torch.empty_like(kc), torch.empty_like(vc)
+            ops.attention_bwd(qkv[:, :D], kc, vc, sv["a"], da, sv["lse"], delta, dqkv[:, :D], dkc, dvc, B, H, N, Nk, (s3, sk, sk, so), (s3, sk, sk))
+            if c["kv_sampling"] == "conv":
+                cw, cb, lw = S.f(p + "attn.sr.weight"), S.f(p + "attn.sr.bias"), S.f(p + "attn.norm.weight")
+                gcw, gcb = S.g(p + "attn.sr.weight"), S.g(p + "attn.sr.bias")
+                glw, glb = S.g(p + "attn.norm.weight"), S.g(p + "attn.norm.bias")
+                for dyc, lo in ((dkc, D), (dvc, 2 * D)):   # the same sr / norm parameters process K and V (PixArt_blocks.py:138-139)
+                    ops.kv_compress_bwd(dyc, qkv[:, lo:lo + D], N * 3 * D, 3 * D, cw, cb, lw, dqkv[:, lo:lo + D], N * 3 * D, 3 * D,
+                                        gcw, gcb, glw, glb, B, hh, ww, D, sr)
+            else:
+                ops.kv_pick(dkc, dqkv[:, D:2 * D], N * 3 * D, 3 * D, B, hh, ww, D, sr, backward=True)
+                ops.kv_pick(dvc, dqkv[:, 2 * D:], N * 3 * D, 3 * D, B, hh, ww, D, sr, backward=True)
         dxn = self._lin_bwd(dqkv, sv["xn1"], p + "attn.qkv")
         ops.ln_mod_bwd(dxn, sv["x_in"], sv["mean1"], sv["rstd1"], mod[:, 1], st, G, G, dmod[:, 0], dmod[:, 1], st, N)
         if self.grad_ready_hook:

@@ -50,6 +50,8 @@ SIGNATURES = {
     "pxa_patchify_bwd": [_P, _P, _I, _I, _I, _I, _P],
     "pxa_gather_rows_bf16": [_P, _P, _P, _P, _P, _I, _I, _I, _P],
     "pxa_kv_compress_fwd": [_P, _L, _L, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _P],
+    "pxa_kv_compress_bwd": [_P, _P, _L, _L, _P, _P, _P, _P, _L, _L, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _P],
+    "pxa_kv_pick": [_I, _P, _P, _L, _L, _I, _I, _I, _I, _I, _P],
     "pxa_sumsq_f32": [_P, _L, _P, _P],
     "pxa_clip_coef": [_P, _P, _F, _F, _P],
     "pxa_adamw_step": [_P, _P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _I, _P, _P],

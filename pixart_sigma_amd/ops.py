@@ -169,6 +169,15 @@ def kv_compress_fwd(inp, in_bs, in_ts, conv_w, conv_b, ln_w, ln_b, B, H, W, Cc, 
     return out
 
 
+def kv_compress_bwd(dyc, inp, in_bs, in_ts, conv_w, conv_b, ln_w, din, din_bs, din_ts, d_conv_w, d_conv_b, d_ln_w, d_ln_b, B, H, W, Cc, sr, eps=1e-5):
+    call("pxa_kv_compress_bwd", ptr(dyc), ptr(inp), in_bs, in_ts, ptr(conv_w), ptr(conv_b), ptr(ln_w), ptr(din), din_bs, din_ts,
+         ptr(d_conv_w), ptr(d_conv_b), ptr(d_ln_w), ptr(d_ln_b), B, H, W, Cc, sr, eps)
+
+
+def kv_pick(src, dst, full_bs, full_ts, B, H, W, Cc, sr, backward=False):
+    call("pxa_kv_pick", int(backward), ptr(src), ptr(dst), full_bs, full_ts, B, H, W, Cc, sr)
+
+
 def sumsq(x, out):
     call("pxa_sumsq_f32", ptr(x), x.numel(), ptr(out))
 

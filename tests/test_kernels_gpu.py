@@ -301,6 +301,37 @@ def test_kv_compress_fwd(ops):
     assert rel_l2(out.float(), ref) < BF16_TOL
 
 
+def test_kv_compress_bwd_and_pick(ops):
+    B, H, W, C, sr = 2, 8, 12, 1152, 2
+    N, Nk = H * W, (H // sr) * (W // sr)
+    qkv = bf(rnd(B * N, 3 * C, seed=1))
+    cw, cb = 0.25 + rnd(C, 1, sr, sr, scale=0.05, seed=2), rnd(C, scale=0.05, seed=3)
+    lw, lb = 1 + rnd(C, scale=0.05, seed=4), rnd(C, scale=0.05, seed=5)
+    dyc = bf(rnd(B, Nk, C, seed=6))
+    k = qkv[:, C:2 * C]
+    kr = k.float().clone().requires_grad_(True)
+    cwr, cbr, lwr, lbr = (t.clone().requires_grad_(True) for t in (cw, cb, lw, lb))
+    t = F.conv2d(kr.reshape(B, H, W, C).permute(0, 3, 1, 2), cwr, cbr, stride=sr, groups=C).reshape(B, C, -1).permute(0, 2, 1)
+    F.layer_norm(t, (C,), lwr, lbr, eps=1e-5).backward(dyc.float())
+    dqkv = torch.zeros_like(qkv)
+    gcw, gcb, glw, glb = (torch.zeros_like(t) for t in (cw, cb, lw, lb))
+    ops.kv_compress_bwd(dyc, k, N * 3 * C, 3 * C, cw, cb, lw, dqkv[:, C:2 * C], N * 3 * C, 3 * C, gcw, gcb, glw, glb, B, H, W, C, sr)
+    assert rel_l2(dqkv[:, C:2 * C].float(), kr.grad) < BF16_TOL
+    for got, ref, nm in ((gcw, cwr.grad, "conv_w"), (gcb, cbr.grad, "conv_b"), (glw, lwr.grad, "ln_w"), (glb, lbr.grad, "ln_b")):
+        assert rel_l2(got, ref) < 1e-4, nm
+    assert dqkv[:, :C].abs().max() == 0 and dqkv[:, 2 * C:].abs().max() == 0
+    # token pick ('uniform' / 'ave') forward + scatter backward
+    kc = torch.empty(B, Nk, C, dtype=torch.bfloat16, device="cuda")
+    ops.kv_pick(k, kc, N * 3 * C, 3 * C, B, H, W, C, sr)
+    ref = k.reshape(B, H, W, C)[:, ::sr, ::sr].reshape(B, Nk, C)
+    assert torch.equal(kc, ref)
+    back = torch.zeros_like(qkv)
+    ops.kv_pick(kc, back[:, C:2 * C], N * 3 * C, 3 * C, B, H, W, C, sr, backward=True)
+    refb = torch.zeros(B, H, W, C, dtype=torch.bfloat16, device="cuda")
+    refb[:, ::sr, ::sr] = ref.reshape(B, H // sr, W // sr, C)
+    assert torch.equal(back[:, C:2 * C].reshape(B, H, W, C), refb)
+
+
 # ------------------------------------------------------------------------------------------------ optimizer
 def test_adamw_matches_torch(ops):
     n = 1 << 16

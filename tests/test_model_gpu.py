@@ -40,7 +40,7 @@ def _build(g, train=False):
     return cfg, sd, inp, mask, m
 
 
-@pytest.mark.parametrize("name", ["fwd_d2_sq", "fwd_d2_nomask", "fwd_d2_kvconv"])
+@pytest.mark.parametrize("name", ["fwd_d2_sq", "fwd_d2_nomask", "fwd_d2_kvconv", "fwd_d2_kvuniform", "fwd_d2_kvave"])
 def test_forward_matches_reference_and_oracle(golden, name):
     g = golden(name)
     cfg, sd, inp, mask, m = _build(g)
@@ -54,9 +54,11 @@ def test_forward_matches_reference_and_oracle(golden, name):
     assert e_f32 < FWD_F32_TOL
 
 
-def test_training_step_loss_and_grads(golden):
+@pytest.mark.parametrize("gname", ["train_d2_plain", "train_d2"])
+def test_training_step_loss_and_grads(golden, gname):
+    """train_d2 has KV compression ('conv', x2) on block 1: exercises kv_compress_bwd and the shared sr/norm gradients."""
     from pixart_sigma_amd import IDDPM
-    g = golden("train_d2_plain")
+    g = golden(gname)
     cfg, sd, inp, mask, m = _build(g, train=True)
     diff = IDDPM(str(1000), learn_sigma=True, pred_sigma=True, snr=False)
     kw = dict(y=inp["y"].cuda(), mask=mask[:, None, None, :].cuda(), data_info=None)
