@@ -50,7 +50,11 @@ typedef struct {
   float* out_f32; int ld_f32;
   int accumulate;                /* out_f32: 0 = store, 1 = atomicAdd (gradient accumulation / split-K) */
   int split_k;                   /* >1 only with accumulate; 0 = library picks tile shape and split for the dW case */
+  float* splitk_ws;              /* optional caller-owned workspace for split-K partial slabs (>= split*M*N floats, see    */
+  long splitk_ws_elems;          /*  pxa_gemm_splitk_ws_elems); NULL -> partials are combined with fp32 atomics (slow)       */
 } pxa_gemm_args;
+/* Upper bound of the split-K workspace (in floats) pxa_gemm may use for an (M, N) fp32-accumulate output. */
+long pxa_gemm_splitk_ws_elems(int M, int N);
 int pxa_gemm(const pxa_gemm_args* args, hipStream_t stream);
 
 /* ---------------------------------------------------------------------------------------------- adaLN-single rows

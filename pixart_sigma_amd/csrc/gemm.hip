@@ -28,6 +28,7 @@ struct GemmParams {
   bf16_t* out; bf16_t* out2; int ldo;
   float* outf; int ldf;
   int act, accumulate, k_per_split, tile_hint, split;
+  float* slab;
 };
 
 // ---- global -> registers (4 x 16 B per thread per operand tile), zero-filled out of bounds
@@ -101,7 +102,7 @@ __device__ __forceinline__ void tile_coords(int bid, int mt, int nt, int split, 
 }
 
 // ---- epilogue: lane owns row m, 4 consecutive n per accumulator quad (bias / GELU / GELU' / bf16 + fp32 / atomic stores)
-__device__ __forceinline__ void epilogue(const GemmParams& p, const f32x16 (&acc)[2][2], int m0, int n0, int wm, int wn, int lane, int hi) {
+__device__ __forceinline__ void epilogue(const GemmParams& p, const f32x16 (&acc)[2][2], int m0, int n0, int wm, int wn, int lane, int hi, int z) {
 #pragma unroll
   for (int i = 0; i < 2; i++) {
     const int m = m0 + wm * 64 + i * 32 + (lane & 31);
@@ -132,7 +133,12 @@ __device__ __forceinline__ void epilogue(const GemmParams& p, const f32x16 (&acc
         if (p.out) *reinterpret_cast<uint2*>(p.out + (size_t)m * p.ldo + n) = pack_bf16x4(v[0], v[1], v[2], v[3]);
         if (p.outf) {
           float* dst = p.outf + (size_t)m * p.ldf + n;
-          if (p.accumulate) {
+          if (p.accumulate == 3) {            // split-K partial slab z (dense [M][N]), summed into outf by splitk_reduce_kernel
+            *reinterpret_cast<float4*>(p.slab + ((size_t)z * p.M + m) * p.N + n) = make_float4(v[0], v[1], v[2], v[3]);
+          } else if (p.accumulate == 2) {     // single k-slice: this thread owns the element -> plain read-modify-write
+            float4 o = *reinterpret_cast<const float4*>(dst);
+            *reinterpret_cast<float4*>(dst) = make_float4(o.x + v[0], o.y + v[1], o.z + v[2], o.w + v[3]);
+          } else if (p.accumulate) {          // fallback: fp32 atomics (scattered 4-byte atomics: ~40 G/s, avoid)
 #pragma unroll
             for (int e = 0; e < 4; e++) atomicAdd(dst + e, v[e]);
           } else {
@@ -203,7 +209,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmParams p) {
     __syncthreads();
   }
 
-  epilogue(p, acc, m0, n0, wm, wn, lane, hi);
+  epilogue(p, acc, m0, n0, wm, wn, lane, hi, z_);
 }
 
 // =====================================================================================================================
@@ -256,7 +262,7 @@ __device__ __forceinline__ bf16x8 frag_g(const char* lds, int rbase, int ks, int
 }
 
 template <int TM, int TN>
-__device__ __forceinline__ void epilogue_t(const GemmParams& p, const f32x16 (&acc)[TM][TN], int mw, int nw, int lane, int hi) {
+__device__ __forceinline__ void epilogue_t(const GemmParams& p, const f32x16 (&acc)[TM][TN], int mw, int nw, int lane, int hi, int z) {
 #pragma unroll
   for (int i = 0; i < TM; i++) {
     const int m = mw + i * 32 + (lane & 31);
@@ -287,7 +293,12 @@ __device__ __forceinline__ void epilogue_t(const GemmParams& p, const f32x16 (&a
         if (p.out) *reinterpret_cast<uint2*>(p.out + (size_t)m * p.ldo + n) = pack_bf16x4(v[0], v[1], v[2], v[3]);
         if (p.outf) {
           float* dst = p.outf + (size_t)m * p.ldf + n;
-          if (p.accumulate) {
+          if (p.accumulate == 3) {            // split-K partial slab z (dense [M][N]), summed into outf by splitk_reduce_kernel
+            *reinterpret_cast<float4*>(p.slab + ((size_t)z * p.M + m) * p.N + n) = make_float4(v[0], v[1], v[2], v[3]);
+          } else if (p.accumulate == 2) {     // single k-slice: this thread owns the element -> plain read-modify-write
+            float4 o = *reinterpret_cast<const float4*>(dst);
+            *reinterpret_cast<float4*>(dst) = make_float4(o.x + v[0], o.y + v[1], o.z + v[2], o.w + v[3]);
+          } else if (p.accumulate) {          // fallback: fp32 atomics (scattered 4-byte atomics: ~40 G/s, avoid)
 #pragma unroll
             for (int e = 0; e < 4; e++) atomicAdd(dst + e, v[e]);
           } else {
@@ -356,7 +367,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_glds_kernel(GemmParams p) {
       }
     }
   }
-  epilogue_t<TM, TN>(p, acc, m0 + wm * (TM * 32), n0 + wn * (TN * 32), lane, hi);
+  epilogue_t<TM, TN>(p, acc, m0 + wm * (TM * 32), n0 + wn * (TN * 32), lane, hi, z_);
 }
 
 // =====================================================================================================================
@@ -456,7 +467,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_pipe_kernel(GemmParams p) {
         for (int j = 0; j < TN; j++) acc[i][j] = mfma32(bf[j], af[i], acc[i][j]);
     }
   }
-  epilogue_t<TM, TN>(p, acc, m0 + wm * (TM * 32), n0 + wn * (TN * 32), lane, hi);
+  epilogue_t<TM, TN>(p, acc, m0 + wm * (TM * 32), n0 + wn * (TN * 32), lane, hi, z_);
 }
 
 // =====================================================================================================================
@@ -533,7 +544,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_phase_kernel(GemmParams p) 
     }
   }
   if (!late) __builtin_amdgcn_s_barrier();             // every wave executes the same number of barriers
-  epilogue_t<TM, TN>(p, acc, m0 + wm * (TM * 32), n0 + wn * (TN * 32), lane, hi);
+  epilogue_t<TM, TN>(p, acc, m0 + wm * (TM * 32), n0 + wn * (TN * 32), lane, hi, z_);
 }
 
 template <int LAYOUT, int TBM, int TBN, int WM, int WN>
@@ -621,6 +632,21 @@ int launch(GemmParams p, int split, hipStream_t s) {
 }
 }  // namespace
 
+namespace {
+// out[m][n] += sum_z slab[z][m][n]   (split-K combine at the launch boundary: plain 16-byte loads/stores, no atomics)
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ slab, float* __restrict__ out, int ld, int M, int N, int split) {
+  const long i4 = blockIdx.x * 256L + threadIdx.x, n4 = N / 4;
+  if (i4 >= (long)M * n4) return;
+  const int m = i4 / n4, n = (i4 - (long)m * n4) * 4;
+  float4 s = *reinterpret_cast<const float4*>(out + (size_t)m * ld + n);
+  for (int z = 0; z < split; z++) {
+    const float4 v = *reinterpret_cast<const float4*>(slab + ((size_t)z * M + m) * N + n);
+    s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+  }
+  *reinterpret_cast<float4*>(out + (size_t)m * ld + n) = s;
+}
+}  // namespace
+
 extern "C" int pxa_gemm(const pxa_gemm_args* a, hipStream_t stream) {
   PXA_CHECK(a && a->A && a->B, "pxa_gemm: null operand");
   PXA_CHECK(a->layout >= 0 && a->layout <= 2, "pxa_gemm: bad layout %d", a->layout);
@@ -652,7 +678,7 @@ extern "C" int pxa_gemm(const pxa_gemm_args* a, hipStream_t stream) {
     double best = 1e30;
     for (const Cfg& c : cfgs) {
       const long tiles = (long)((a->M + c.bm - 1) / c.bm) * ((a->N + c.bn - 1) / c.bn);
-      for (int sp = 1; sp <= 64; sp++) {
+      for (int sp = 1; sp <= 16; sp++) {
         const int kp = ((a->K + sp - 1) / sp + BK - 1) / BK * BK;
         if ((long)kp * (sp - 1) >= a->K) continue;               // would leave an empty split
         const long rounds = (tiles * sp + c.slots - 1) / c.slots;
@@ -665,9 +691,23 @@ extern "C" int pxa_gemm(const pxa_gemm_args* a, hipStream_t stream) {
   int kps = ((a->K + split - 1) / split + BK - 1) / BK * BK;
   p.k_per_split = kps;
   split = (a->K + kps - 1) / kps;
-  switch (a->layout) {
-    case 0: return launch<0>(p, split, stream);
-    case 1: return launch<1>(p, split, stream);
-    default: return launch<2>(p, split, stream);
+  p.slab = nullptr;
+  if (p.accumulate && p.outf) {
+    if (split == 1) p.accumulate = 2;
+    else if (a->splitk_ws && a->splitk_ws_elems >= (long)split * a->M * a->N) { p.accumulate = 3; p.slab = a->splitk_ws; }
   }
+  int rc;
+  switch (a->layout) {
+    case 0: rc = launch<0>(p, split, stream); break;
+    case 1: rc = launch<1>(p, split, stream); break;
+    default: rc = launch<2>(p, split, stream); break;
+  }
+  if (rc == 0 && p.accumulate == 3) {
+    const long n4 = (long)a->M * (a->N / 4);
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((n4 + 255) / 256), dim3(256), 0, stream, p.slab, a->out_f32, a->ld_f32, a->M, a->N, split);
+    PXA_LAUNCH_CHECK();
+  }
+  return rc;
 }
+
+extern "C" long pxa_gemm_splitk_ws_elems(int M, int N) { return 16L * M * N; }

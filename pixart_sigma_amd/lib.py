@@ -18,7 +18,8 @@ class GemmArgs(C.Structure):
                 ("M", c_int), ("N", c_int), ("K", c_int), ("layout", c_int),
                 ("bias", c_void_p), ("act", c_int), ("aux", c_void_p), ("ldaux", c_int),
                 ("out_bf16", c_void_p), ("out2_bf16", c_void_p), ("ld_out", c_int),
-                ("out_f32", c_void_p), ("ld_f32", c_int), ("accumulate", c_int), ("split_k", c_int)]
+                ("out_f32", c_void_p), ("ld_f32", c_int), ("accumulate", c_int), ("split_k", c_int),
+                ("splitk_ws", c_void_p), ("splitk_ws_elems", c_long)]
 
 
 class AttnArgs(C.Structure):
@@ -57,7 +58,7 @@ SIGNATURES = {
     "pxa_adamw_step": [_P, _P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _I, _P, _P],
     "pxa_cast_f32_bf16": [_P, _P, _L, _P],
 }
-OTHER_SYMBOLS = ["pxa_last_error", "pxa_abi_version", "pxa_device_info"]
+OTHER_SYMBOLS = ["pxa_last_error", "pxa_abi_version", "pxa_device_info", "pxa_gemm_splitk_ws_elems"]
 
 _lib = None
 

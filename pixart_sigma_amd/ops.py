@@ -11,6 +11,7 @@ from .lib import AttnArgs, GemmArgs, call, ptr
 BF16, F32 = torch.bfloat16, torch.float32
 NT, NN, TN = 0, 1, 2
 ACT_NONE, ACT_GELU, ACT_GELU_GRAD = 0, 1, 2
+_SPLITK_WS = {}
 
 
 def _chk(t, dtype, name):
@@ -60,6 +61,12 @@ def gemm(a, b, layout=NT, bias=None, act=ACT_NONE, aux=None, out=None, out2=None
         assert out is not None and out2.stride(0) == out.stride(0)
         g.out2_bf16 = ptr(out2)
     g.accumulate, g.split_k = int(accumulate), split_k
+    if accumulate and split_k != 1:       # split-K partial slabs: caller-owned workspace, cached per device (max 16 slabs)
+        need = 16 * M * N
+        ws = _SPLITK_WS.get(a.device)
+        if ws is None or ws.numel() < need:
+            ws = _SPLITK_WS[a.device] = torch.empty(need, dtype=F32, device=a.device)
+        g.splitk_ws, g.splitk_ws_elems = ptr(ws), ws.numel()
     call("pxa_gemm", g)
     return out_f32 if want_f32 else out
 

@@ -11,3 +11,10 @@ for n in (4096, 8192):
     for lay, nm in ((ops.NT, "NT"), (ops.NN, "NN")):
         t = timed(lambda: ops.gemm(a, b, lay, out=out), iters=10)
         print(f"{nm} {n}^3: {t*1e3:.3f} ms {2.0*n**3/t/1e12:.1f} TF/s")
+    outf = torch.zeros(n, n, device="cuda")
+    for tile in ("128", "256"):
+        os.environ["PXA_GEMM_TILE"] = tile
+    t = timed(lambda: ops.gemm(a, b, ops.TN, out_f32=outf, accumulate=False, split_k=1), iters=10)
+    print(f"TN {n}^3 fp32 store: {t*1e3:.3f} ms {2.0*n**3/t/1e12:.1f} TF/s")
+    t = timed(lambda: ops.gemm(a, b, ops.TN, out_f32=outf, accumulate=True, split_k=1), iters=10)
+    print(f"TN {n}^3 fp32 atomic: {t*1e3:.3f} ms {2.0*n**3/t/1e12:.1f} TF/s")
