@@ -261,6 +261,77 @@ __device__ __forceinline__ bf16x8 frag_g(const char* lds, int rbase, int ks, int
   }
 }
 
+// bf16 epilogue staged through LDS: the accumulator layout gives every lane 4 consecutive columns of ONE row, i.e. a store
+// instruction touches 32 rows x 16 bytes (32 partial cache lines; measured 6-17 us per 256x256 tile, 15-30 % of a K=1152 GEMM).
+// Here each wave first parks its (TM*32) x 64 tile in its own LDS region (128-byte rows, 16-byte chunk XOR (row&7)), then reads it back row-wise so one
+// instruction stores 8 complete 128-byte row segments, 16 bytes per lane.  Bias / GELU are applied on the fp32 accumulators
+// before the tile is parked; with the dual-output GELU epilogue the tile makes two trips (pre-activation, activation).
+constexpr int EPI_STRIDE = 128;
+template <int TM>
+__device__ __forceinline__ void stage_store(const char* wl, bf16_t* __restrict__ out, int ldo, int mw, int nw, int M, int N, int lane) {
+#pragma unroll
+  for (int t = 0; t < TM * 4; t++) {                   // 8 rows x 128 B per instruction
+    const int row = t * 8 + (lane >> 3), ch = lane & 7;
+    const uint4 v = *reinterpret_cast<const uint4*>(wl + row * EPI_STRIDE + ((ch ^ (row & 7)) << 4));
+    const int m = mw + row, n = nw + ch * 8;
+    if (m < M && n < N) *reinterpret_cast<uint4*>(out + (size_t)m * ldo + n) = v;
+  }
+}
+template <int TM, int TN>
+__device__ __forceinline__ void epilogue_staged(const GemmParams& p, f32x16 (&acc)[TM][TN], char* smem, int wave, int mw, int nw, int lane, int hi) {
+  static_assert(TN == 2, "staged epilogue assumes 64-column wave tiles");
+  char* wl = smem + wave * (TM * 32 * EPI_STRIDE);
+  __syncthreads();                                     // every wave is done reading the operand stages
+  const bool dual = (p.act == 1 && p.out2 != nullptr);
+  if (p.bias) {
+#pragma unroll
+    for (int j = 0; j < TN; j++)
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const int n = nw + j * 32 + 8 * q + 4 * hi;
+        if (n < p.N) {
+          const float4 b = *reinterpret_cast<const float4*>(p.bias + n);
+#pragma unroll
+          for (int i = 0; i < TM; i++) { acc[i][j][q * 4] += b.x; acc[i][j][q * 4 + 1] += b.y; acc[i][j][q * 4 + 2] += b.z; acc[i][j][q * 4 + 3] += b.w; }
+        }
+      }
+  }
+#pragma unroll
+  for (int pass = 0; pass < 2; pass++) {               // pass 0: pre-activation copy (dual output only); pass 1: final values
+    if (pass == 0 && !dual) continue;
+#pragma unroll
+    for (int i = 0; i < TM; i++)
+#pragma unroll
+      for (int j = 0; j < TN; j++)
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          const int col = j * 32 + 8 * q + 4 * hi;
+          float v[4];
+#pragma unroll
+          for (int e = 0; e < 4; e++) v[e] = acc[i][j][q * 4 + e];
+          if (pass == 1) {
+            if (p.act == 1) {
+#pragma unroll
+              for (int e = 0; e < 4; e++) v[e] = gelu_tanh(v[e]);
+            } else if (p.act == 2) {
+              const int m = mw + i * 32 + (lane & 31), n = nw + col;
+              if (m < p.M && n < p.N) {
+                const uint2 a = *reinterpret_cast<const uint2*>(p.aux + (size_t)m * p.ldaux + n);
+                float a0, a1, a2, a3;
+                unpack_bf16x2(a.x, a0, a1); unpack_bf16x2(a.y, a2, a3);
+                v[0] *= gelu_tanh_grad(a0); v[1] *= gelu_tanh_grad(a1); v[2] *= gelu_tanh_grad(a2); v[3] *= gelu_tanh_grad(a3);
+              }
+            }
+          }
+          *reinterpret_cast<uint2*>(wl + (i * 32 + (lane & 31)) * EPI_STRIDE + (((col >> 3) ^ (lane & 7)) << 4) + (col & 4) * 2) = pack_bf16x4(v[0], v[1], v[2], v[3]);
+        }
+    // the region is private to this wave: only its own LDS writes must have landed before the row-wise reads
+    __builtin_amdgcn_s_waitcnt(0xc07f);                // lgkmcnt(0)
+    stage_store<TM>(wl, pass == 0 ? p.out2 : p.out, p.ldo, mw, nw, p.M, p.N, lane);
+    __builtin_amdgcn_s_waitcnt(0xc07f);                // reads returned before the next trip overwrites the region
+  }
+}
+
 template <int TM, int TN>
 __device__ __forceinline__ void epilogue_t(const GemmParams& p, const f32x16 (&acc)[TM][TN], int mw, int nw, int lane, int hi, int z) {
 #pragma unroll
@@ -310,7 +381,7 @@ __device__ __forceinline__ void epilogue_t(const GemmParams& p, const f32x16 (&a
   }
 }
 
-template <int LAYOUT, int TBM, int TBN, int WM, int WN>
+template <int LAYOUT, int TBM, int TBN, int WM, int WN, int EPI>
 __global__ __launch_bounds__(WM * WN * 64) void gemm_glds_kernel(GemmParams p) {
   constexpr bool A_KC = (LAYOUT != 2), B_KC = (LAYOUT == 0);
   constexpr int NW = WM * WN, TM = TBM / WM / 32, TN = TBN / WN / 32;
@@ -367,7 +438,8 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_glds_kernel(GemmParams p) {
       }
     }
   }
-  epilogue_t<TM, TN>(p, acc, m0 + wm * (TM * 32), n0 + wn * (TN * 32), lane, hi, z_);
+  if (EPI == 1) epilogue_staged<TM, TN>(p, acc, smem, wave, m0 + wm * (TM * 32), n0 + wn * (TN * 32), lane, hi);
+  else epilogue_t<TM, TN>(p, acc, m0 + wm * (TM * 32), n0 + wn * (TN * 32), lane, hi, z_);
 }
 
 // =====================================================================================================================
@@ -579,20 +651,30 @@ int launch_pipe(GemmParams p, int split, hipStream_t s) {
   return 0;
 }
 
-template <int LAYOUT, int TBM, int TBN, int WM, int WN>
-int launch_glds(GemmParams p, int split, hipStream_t s) {
+template <int LAYOUT, int TBM, int TBN, int WM, int WN, int EPI>
+int launch_glds_e(GemmParams p, int split, hipStream_t s) {
   p.split = split;
   constexpr int LDSG = 2 * (TBM + TBN) * 128;
+  static_assert(WM * WN * (TBM / WM) * EPI_STRIDE <= LDSG, "staged epilogue must fit the operand stages");
   static bool attr_set_g = false;
   if (!attr_set_g) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_glds_kernel<LAYOUT, TBM, TBN, WM, WN>), hipFuncAttributeMaxDynamicSharedMemorySize, LDSG);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_glds_kernel<LAYOUT, TBM, TBN, WM, WN, EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, LDSG);
     if (e != hipSuccess) { pxa_set_error("hipFuncSetAttribute(gemm_glds<%d,%d,%d>): %s", LAYOUT, TBM, TBN, hipGetErrorString(e)); return -3; }
     attr_set_g = true;
   }
   dim3 grid(((p.M + TBM - 1) / TBM) * ((p.N + TBN - 1) / TBN) * split, 1, 1);
-  hipLaunchKernelGGL((gemm_glds_kernel<LAYOUT, TBM, TBN, WM, WN>), grid, dim3(WM * WN * 64), LDSG, s, p);
+  hipLaunchKernelGGL((gemm_glds_kernel<LAYOUT, TBM, TBN, WM, WN, EPI>), grid, dim3(WM * WN * 64), LDSG, s, p);
   PXA_LAUNCH_CHECK();
   return 0;
+}
+template <int LAYOUT, int TBM, int TBN, int WM, int WN>
+int launch_glds(GemmParams p, int split, hipStream_t s) {
+  // bf16-only outputs of the forward / dX GEMMs take the LDS-staged, fully coalesced epilogue (separate kernel instances, so
+  // neither epilogue's registers burden the other)
+  static const bool no_stage = getenv("PXA_GEMM_NO_STAGED_EPILOGUE") != nullptr;
+  const bool dual = (p.act == 1 && p.out2 != nullptr);   // two LDS trips: measured slower than the direct epilogue
+  if (LAYOUT != 2 && p.out && !p.outf && !dual && !no_stage) return launch_glds_e<LAYOUT, TBM, TBN, WM, WN, 1>(p, split, s);
+  return launch_glds_e<LAYOUT, TBM, TBN, WM, WN, 0>(p, split, s);
 }
 
 template <int LAYOUT>
