@@ -24,6 +24,9 @@ extern "C" {
 #endif
 
 #define PXA_ABI_VERSION 1
+/* Kernels that fuse a bias-gradient column sum add into one of PXA_COLSUM_SLOTS partial rows ([slot][stride] fp32, caller-zeroed),
+ * chosen per sample / row tile, so no address sees thousands of atomics; pxa_colsum_reduce folds the partials into the gradient. */
+#define PXA_COLSUM_SLOTS 16
 
 const char* pxa_last_error(void);
 int pxa_abi_version(void);
@@ -52,6 +55,8 @@ typedef struct {
   int split_k;                   /* >1 only with accumulate; 0 = library picks tile shape and split for the dW case */
   float* splitk_ws;              /* optional caller-owned workspace for split-K partial slabs (>= split*M*N floats, see    */
   long splitk_ws_elems;          /*  pxa_gemm_splitk_ws_elems); NULL -> partials are combined with fp32 atomics (slow)       */
+  float* colsum;                 /* optional slotted partials: += column sums of the bf16 output (bias gradient)              */
+  long colsum_stride;
 } pxa_gemm_args;
 /* Upper bound of the split-K workspace (in floats) pxa_gemm may use for an (M, N) fp32-accumulate output. */
 long pxa_gemm_splitk_ws_elems(int M, int N);
@@ -70,9 +75,13 @@ int pxa_ln_mod_fwd(const float* x, const void* u_bf16, const float* gate, int ga
 int pxa_ln_mod_bwd(const void* dy_bf16, const float* x, const float* mean, const float* rstd, const float* scale, int mod_stride,
                    const float* dx_in, float* dx_out, void* dx_bf16, float* dshift, float* dscale, int dmod_stride,
                    int R, int D, int rows_per_batch, hipStream_t stream);
-/* g = dx (+ add_bf16);  dx_out = g (optional);  du = gate*g (bf16; plain cast if gate NULL);  dgate[b] += sum g*u. */
+/* g = dx (+ add_bf16);  dx_out = g (optional);  du = gate*g (bf16; plain cast if gate NULL);  dgate[b] += sum g*u;
+ * dbias[b % PXA_COLSUM_SLOTS][d] += sum_rows du (optional slotted partials: bias gradient of the Linear whose output gradient du is). */
 int pxa_gate_bwd(const float* dx, const void* add_bf16, const void* u_bf16, const float* gate, int mod_stride,
-                 float* dx_out, void* du_bf16, float* dgate, int dmod_stride, int R, int D, int rows_per_batch, hipStream_t stream);
+                 float* dx_out, void* du_bf16, float* dgate, int dmod_stride, float* dbias, long dbias_stride, int R, int D,
+                 int rows_per_batch, hipStream_t stream);
+/* out[i] += sum_p part[p*stride + i], p < PXA_COLSUM_SLOTS, i < n. */
+int pxa_colsum_reduce(const float* part, long stride, float* out, long n, hipStream_t stream);
 /* out[n] += sum_r dY[r][n]  — nn.Linear bias gradients. */
 int pxa_colsum_bf16(const void* dy_bf16, int ld, float* out, int R, int N, hipStream_t stream);
 
@@ -96,6 +105,8 @@ typedef struct {
   const int* kv_start; const int* kv_len;  /* device int32 [B] or NULL */
   int max_kv_len;                           /* host-known max(kv_len) for the varlen backward grid (0: use Nk) */
   float scale;
+  float* dq_colsum; float* dk_colsum; float* dv_colsum;  /* optional (bwd) slotted partials: += column sums of dq / dk / dv (bias gradients) */
+  long colsum_stride;
 } pxa_attn_args;
 int pxa_attn_fwd(const pxa_attn_args* args, hipStream_t stream);
 int pxa_attn_bwd(const pxa_attn_args* args, hipStream_t stream);

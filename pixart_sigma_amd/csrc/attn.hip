@@ -43,6 +43,8 @@ struct AttnParams {
   bf16_t *O, *dQ, *dK, *dV;
   float* LSE;          // [B][H][Nq], log2 domain: m*c + log2(l)
   const float* Delta;  // [B][H][Nq]
+  float *dq_colsum, *dk_colsum, *dv_colsum;   // optional [PXA_COLSUM_SLOTS][colsum_stride] fp32 partials: += column sums of dQ / dK / dV
+  long colsum_stride;
   long q_bs, q_ts, k_bs, k_ts, v_bs, v_ts, o_bs, o_ts;  // element strides (batch, token)
   int q_hs, k_hs, v_hs, o_hs;                            // head strides
   long dq_bs, dq_ts, dk_bs, dk_ts, dv_bs, dv_ts;
@@ -144,6 +146,25 @@ __device__ __forceinline__ void store_rows(bf16_t* __restrict__ rowptr, const f3
       const int d0 = dt * 32 + 8 * qd + 4 * hi;
       if (d0 < DH)
         *reinterpret_cast<uint2*>(rowptr + d0) = pack_bf16x4(acc[dt][qd * 4] * mul, acc[dt][qd * 4 + 1] * mul, acc[dt][qd * 4 + 2] * mul, acc[dt][qd * 4 + 3] * mul);
+    }
+}
+// bias gradient of the Linear that produced this operand: colsum[h*72 + d] += sum over the wave's 32 rows of X[row][d] (invalid rows
+// contribute 0).  One cross-lane tree per stored value, once per workgroup: negligible next to the tile loop, and it removes a
+// full extra HBM pass over the gradient tensor (the separate column-sum kernel).
+__device__ __forceinline__ void colsum_rows(float* __restrict__ dst, const f32x16 (&acc)[3], float mul, bool valid, int hi, int lane) {
+#pragma unroll
+  for (int dt = 0; dt < 3; dt++)
+#pragma unroll
+    for (int qd = 0; qd < 4; qd++) {
+      const int d0 = dt * 32 + 8 * qd + 4 * hi;
+      if (dt * 32 + 8 * qd < DH) {                       // compile-time prune of the pad tiles (hi-dependent part checked below)
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+          float v = valid ? acc[dt][qd * 4 + e] * mul : 0.f;
+          v += __shfl_xor(v, 16); v += __shfl_xor(v, 8); v += __shfl_xor(v, 4); v += __shfl_xor(v, 2); v += __shfl_xor(v, 1);
+          if ((lane & 31) == 0 && d0 < DH) atomicAdd(dst + d0 + e, v);
+        }
+      }
     }
 }
 __device__ __forceinline__ void zero3(f32x16 (&a)[3]) {
@@ -369,6 +390,7 @@ __global__ __launch_bounds__(256, ATTN_BWD_WAVES) void attn_bwd_dq_kernel(AttnPa
     tile(BoolC<true>{}, st, st + TILE_B, Tfull * BKV);
   }
   if (qvalid) store_rows(p.dQ + (long)b * p.dq_bs + (long)q * p.dq_ts + (long)h * p.dq_hs, dq, p.scale, hi);
+  if (p.dq_colsum) colsum_rows(p.dq_colsum + (b % PXA_COLSUM_SLOTS) * p.colsum_stride + h * DH, dq, p.scale, qvalid, hi, lane);
 }
 
 // ------------------------------------------------------------------------------------------------ backward: dK, dV
@@ -469,6 +491,8 @@ __global__ __launch_bounds__(256, ATTN_BWD_WAVES) void attn_bwd_dkv_kernel(AttnP
     store_rows(p.dK + dkbase + (long)kv * p.dk_ts + (long)h * p.dk_hs, dk, p.scale, hi);
     store_rows(p.dV + dvbase + (long)kv * p.dv_ts + (long)h * p.dv_hs, dv, 1.f, hi);
   }
+  if (p.dk_colsum) colsum_rows(p.dk_colsum + (b % PXA_COLSUM_SLOTS) * p.colsum_stride + h * DH, dk, p.scale, kvvalid, hi, lane);
+  if (p.dv_colsum) colsum_rows(p.dv_colsum + (b % PXA_COLSUM_SLOTS) * p.colsum_stride + h * DH, dv, 1.f, kvvalid, hi, lane);
 }
 
 int fill(AttnParams& p, const pxa_attn_args* a) {
@@ -479,6 +503,7 @@ int fill(AttnParams& p, const pxa_attn_args* a) {
   p.Q = (const bf16_t*)a->q; p.K = (const bf16_t*)a->k; p.V = (const bf16_t*)a->v; p.dO = (const bf16_t*)a->d_o;
   p.O = (bf16_t*)a->o; p.dQ = (bf16_t*)a->dq; p.dK = (bf16_t*)a->dk; p.dV = (bf16_t*)a->dv;
   p.LSE = a->lse; p.Delta = a->delta;
+  p.dq_colsum = a->dq_colsum; p.dk_colsum = a->dk_colsum; p.dv_colsum = a->dv_colsum; p.colsum_stride = a->colsum_stride;
   p.q_bs = a->q_bs; p.q_ts = a->q_ts; p.q_hs = a->q_hs;
   p.k_bs = a->k_bs; p.k_ts = a->k_ts; p.k_hs = a->k_hs;
   p.v_bs = a->v_bs; p.v_ts = a->v_ts; p.v_hs = a->v_hs;

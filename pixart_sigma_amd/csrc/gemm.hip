@@ -29,6 +29,8 @@ struct GemmParams {
   float* outf; int ldf;
   int act, accumulate, k_per_split, tile_hint, split;
   float* slab;
+  float* colsum;   // optional [PXA_COLSUM_SLOTS][colsum_stride] partials: += column sums of the bf16 output, staged epilogue only
+  long colsum_stride;
 };
 
 // ---- global -> registers (4 x 16 B per thread per operand tile), zero-filled out of bounds
@@ -283,6 +285,11 @@ __device__ __forceinline__ void epilogue_staged(const GemmParams& p, f32x16 (&ac
   char* wl = smem + wave * (TM * 32 * EPI_STRIDE);
   __syncthreads();                                     // every wave is done reading the operand stages
   const bool dual = (p.act == 1 && p.out2 != nullptr);
+  float cs[TN][16];
+#pragma unroll
+  for (int j = 0; j < TN; j++)
+#pragma unroll
+    for (int g = 0; g < 16; g++) cs[j][g] = 0.f;
   if (p.bias) {
 #pragma unroll
     for (int j = 0; j < TN; j++)
@@ -324,11 +331,26 @@ __device__ __forceinline__ void epilogue_staged(const GemmParams& p, f32x16 (&ac
             }
           }
           *reinterpret_cast<uint2*>(wl + (i * 32 + (lane & 31)) * EPI_STRIDE + (((col >> 3) ^ (lane & 7)) << 4) + (col & 4) * 2) = pack_bf16x4(v[0], v[1], v[2], v[3]);
+          if (pass == 1 && p.colsum && mw + i * 32 + (lane & 31) < p.M) {
+#pragma unroll
+            for (int e = 0; e < 4; e++) cs[j][q * 4 + e] += v[e];
+          }
         }
     // the region is private to this wave: only its own LDS writes must have landed before the row-wise reads
     __builtin_amdgcn_s_waitcnt(0xc07f);                // lgkmcnt(0)
     stage_store<TM>(wl, pass == 0 ? p.out2 : p.out, p.ldo, mw, nw, p.M, p.N, lane);
     __builtin_amdgcn_s_waitcnt(0xc07f);                // reads returned before the next trip overwrites the region
+  }
+  if (p.colsum) {                                      // column sums over this wave's rows: lane tree, one atomic per column
+#pragma unroll
+    for (int j = 0; j < TN; j++)
+#pragma unroll
+      for (int g = 0; g < 16; g++) {
+        float v = cs[j][g];
+        v += __shfl_xor(v, 16); v += __shfl_xor(v, 8); v += __shfl_xor(v, 4); v += __shfl_xor(v, 2); v += __shfl_xor(v, 1);
+        const int n = nw + j * 32 + 8 * (g >> 2) + 4 * hi + (g & 3);
+        if ((lane & 31) == 0 && n < p.N) atomicAdd(p.colsum + (size_t)((mw >> 7) % PXA_COLSUM_SLOTS) * p.colsum_stride + n, v);
+      }
   }
 }
 
@@ -674,6 +696,12 @@ int launch_glds(GemmParams p, int split, hipStream_t s) {
   static const bool no_stage = getenv("PXA_GEMM_NO_STAGED_EPILOGUE") != nullptr;
   const bool dual = (p.act == 1 && p.out2 != nullptr);   // two LDS trips: measured slower than the direct epilogue
   if (LAYOUT != 2 && p.out && !p.outf && !dual && !no_stage) return launch_glds_e<LAYOUT, TBM, TBN, WM, WN, 1>(p, split, s);
+  if (p.colsum) {                                         // not fused on this path: separate column-sum pass over the output
+    float* cs = p.colsum;
+    p.colsum = nullptr;
+    int rc = launch_glds_e<LAYOUT, TBM, TBN, WM, WN, 0>(p, split, s);
+    return rc ? rc : pxa_colsum_bf16(p.out, p.ldo, cs, p.M, p.N, s);
+  }
   return launch_glds_e<LAYOUT, TBM, TBN, WM, WN, 0>(p, split, s);
 }
 
@@ -708,8 +736,11 @@ int launch(GemmParams p, int split, hipStream_t s) {
     if (tile == -256) return launch_glds<LAYOUT, 256, 128, 4, 2>(p, split, s);
     return launch_glds<LAYOUT, 256, 256, 2, 4>(p, split, s);
   }
+  float* cs_fallback = p.colsum;
+  p.colsum = nullptr;
   hipLaunchKernelGGL(gemm_kernel<LAYOUT>, grid, dim3(256), LDS, s, p);
   PXA_LAUNCH_CHECK();
+  if (cs_fallback) return pxa_colsum_bf16(p.out, p.ldo, cs_fallback, p.M, p.N, s);
   return 0;
 }
 }  // namespace
@@ -742,6 +773,7 @@ extern "C" int pxa_gemm(const pxa_gemm_args* a, hipStream_t stream) {
   if (a->out_f32) PXA_CHECK(a->ld_f32 % 4 == 0, "pxa_gemm: ld_f32 must be a multiple of 4");
   PXA_CHECK(a->act >= 0 && a->act <= 2, "pxa_gemm: bad act %d", a->act);
   if (a->act == 2) PXA_CHECK(a->aux && a->ldaux % 4 == 0, "pxa_gemm: act=2 needs aux");
+  if (a->colsum) PXA_CHECK(a->out_bf16 && !a->out_f32, "pxa_gemm: colsum needs a bf16 output");
   int split = a->split_k < 1 ? 1 : a->split_k;   // 0 = choose here (only for fp32 atomic-accumulate outputs)
   if (split > 1) PXA_CHECK(a->out_f32 && a->accumulate && !a->out_bf16 && a->act == 0 && !a->bias, "pxa_gemm: split_k>1 needs fp32 atomic accumulate output only");
   GemmParams p;
@@ -774,6 +806,7 @@ extern "C" int pxa_gemm(const pxa_gemm_args* a, hipStream_t stream) {
   p.k_per_split = kps;
   split = (a->K + kps - 1) / kps;
   p.slab = nullptr;
+  p.colsum = a->colsum; p.colsum_stride = a->colsum_stride;
   if (p.accumulate && p.outf) {
     if (split == 1) p.accumulate = 2;
     else if (a->splitk_ws && a->splitk_ws_elems >= (long)split * a->M * a->N) { p.accumulate = 3; p.slab = a->splitk_ws; }

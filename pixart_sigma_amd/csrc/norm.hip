@@ -142,23 +142,32 @@ __global__ __launch_bounds__(256) void ln_mod_bwd_kernel(
 template <int NV>
 __global__ __launch_bounds__(256) void gate_bwd_kernel(
     const float* dx, const bf16_t* __restrict__ add, const bf16_t* __restrict__ u, const float* __restrict__ gate,
-    int mod_stride, float* dx_out, bf16_t* __restrict__ du, float* __restrict__ dgate, int dmod_stride,
-    int R, int D, int rows_per_batch) {
+    int mod_stride, float* dx_out, bf16_t* __restrict__ du, float* __restrict__ dgate, int dmod_stride, float* __restrict__ dbias,
+    long dbias_stride, int R, int D, int rows_per_batch) {
   const int hl = threadIdx.x & 31;
   const int chunk = blockIdx.x * 8 + (threadIdx.x >> 5);
   const int r_beg = chunk * BWD_ROWS, r_end = min(R, r_beg + BWD_ROWS);
   if (r_beg >= R) return;
-  float4 ag[NV];
+  float4 ag[NV], ab[NV];
 #pragma unroll
-  for (int j = 0; j < NV; j++) ag[j] = make_float4(0, 0, 0, 0);
+  for (int j = 0; j < NV; j++) { ag[j] = make_float4(0, 0, 0, 0); ab[j] = make_float4(0, 0, 0, 0); }
   int cur_b = r_beg / rows_per_batch;
   auto flush = [&](int b) {
-    if (!dgate) return;
+    if (dgate) {
 #pragma unroll
-    for (int j = 0; j < NV; j++) {
-      float* pg = dgate + (size_t)b * dmod_stride + (hl + 32 * j) * 4;
-      atomicAdd(pg + 0, ag[j].x); atomicAdd(pg + 1, ag[j].y); atomicAdd(pg + 2, ag[j].z); atomicAdd(pg + 3, ag[j].w);
-      ag[j] = make_float4(0, 0, 0, 0);
+      for (int j = 0; j < NV; j++) {
+        float* pg = dgate + (size_t)b * dmod_stride + (hl + 32 * j) * 4;
+        atomicAdd(pg + 0, ag[j].x); atomicAdd(pg + 1, ag[j].y); atomicAdd(pg + 2, ag[j].z); atomicAdd(pg + 3, ag[j].w);
+        ag[j] = make_float4(0, 0, 0, 0);
+      }
+    }
+    if (dbias) {   // partial slot b % PXA_COLSUM_SLOTS: bounds same-address atomic contention exactly like the per-sample dgate
+#pragma unroll
+      for (int j = 0; j < NV; j++) {
+        float* pb = dbias + (size_t)(b % PXA_COLSUM_SLOTS) * dbias_stride + (hl + 32 * j) * 4;
+        atomicAdd(pb + 0, ab[j].x); atomicAdd(pb + 1, ab[j].y); atomicAdd(pb + 2, ab[j].z); atomicAdd(pb + 3, ab[j].w);
+        ab[j] = make_float4(0, 0, 0, 0);
+      }
     }
   };
   for (int row = r_beg; row < r_end; row++) {
@@ -186,6 +195,7 @@ __global__ __launch_bounds__(256) void gate_bwd_kernel(
         o = make_float4(g.x * gt.x, g.y * gt.y, g.z * gt.z, g.w * gt.w);
       }
       if (du) *reinterpret_cast<uint2*>(du + base + c) = pack_bf16x4(o.x, o.y, o.z, o.w);
+      ab[j].x += o.x; ab[j].y += o.y; ab[j].z += o.z; ab[j].w += o.w;
     }
   }
   flush(cur_b);
@@ -262,13 +272,30 @@ extern "C" int pxa_ln_mod_bwd(const void* dy_bf16, const float* x, const float* 
 }
 
 extern "C" int pxa_gate_bwd(const float* dx, const void* add_bf16, const void* u_bf16, const float* gate, int mod_stride,
-                            float* dx_out, void* du_bf16, float* dgate, int dmod_stride, int R, int D, int rows_per_batch,
-                            hipStream_t stream) {
+                            float* dx_out, void* du_bf16, float* dgate, int dmod_stride, float* dbias, long dbias_stride, int R, int D,
+                            int rows_per_batch, hipStream_t stream) {
   PXA_CHECK(dx && R > 0 && D % 128 == 0 && rows_per_batch > 0, "pxa_gate_bwd: bad args");
   PXA_CHECK(!gate || (u_bf16 && dgate), "pxa_gate_bwd: gate needs u and dgate");
   const int chunks = (R + BWD_ROWS - 1) / BWD_ROWS;
   DISPATCH_NV(D, hipLaunchKernelGGL(gate_bwd_kernel<NV>, dim3((chunks + 7) / 8), dim3(256), 0, stream, dx, (const bf16_t*)add_bf16,
-                                     (const bf16_t*)u_bf16, gate, mod_stride, dx_out, (bf16_t*)du_bf16, dgate, dmod_stride, R, D, rows_per_batch));
+                                     (const bf16_t*)u_bf16, gate, mod_stride, dx_out, (bf16_t*)du_bf16, dgate, dmod_stride, dbias, dbias_stride, R, D, rows_per_batch));
+  PXA_LAUNCH_CHECK();
+  return 0;
+}
+
+namespace {
+__global__ __launch_bounds__(256) void colsum_reduce_kernel(const float* __restrict__ part, long stride, float* __restrict__ out, long n) {
+  const long i = blockIdx.x * 256L + threadIdx.x;
+  if (i >= n) return;
+  float s = out[i];
+#pragma unroll
+  for (int p = 0; p < PXA_COLSUM_SLOTS; p++) s += part[p * stride + i];
+  out[i] = s;
+}
+}  // namespace
+extern "C" int pxa_colsum_reduce(const float* part, long stride, float* out, long n, hipStream_t stream) {
+  PXA_CHECK(part && out && n > 0 && stride >= n, "pxa_colsum_reduce: bad args");
+  hipLaunchKernelGGL(colsum_reduce_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, part, stride, out, n);
   PXA_LAUNCH_CHECK();
   return 0;
 }

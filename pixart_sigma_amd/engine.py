@@ -103,6 +103,14 @@ class ParamStore:
         end = self.offset[last] + (self.numel[last] + self.ALIGN - 1) // self.ALIGN * self.ALIGN
         return self.offset[self.names[idx[0]]], end
 
+    def bias_range(self, prefix):
+        """[start, end) of the contiguous run of '*.bias' parameters under `prefix` (the model orders a block's weights first,
+        then its biases, so that fused bias-gradient partials can be folded into the gradient buffer with one launch)."""
+        idx = [i for i, n in enumerate(self.names) if n.startswith(prefix) and n.endswith(".bias")]
+        assert idx and idx == list(range(idx[0], idx[-1] + 1)), f"biases under {prefix} are not contiguous in the flat store"
+        last = self.names[idx[-1]]
+        return self.offset[self.names[idx[0]]], self.offset[last] + (self.numel[last] + self.ALIGN - 1) // self.ALIGN * self.ALIGN
+
     def owns(self, p, name):
         return p.data_ptr() == self.master.data_ptr() + 4 * self.offset[name] and p.device == self.master.device
 
@@ -157,12 +165,13 @@ class Engine:
     def _lin(self, x, name, **kw):
         return ops.gemm(x, self.S.w(name + ".weight"), NT, bias=self.S.f(name + ".bias"), **kw)
 
-    def _lin_bwd(self, dy, x, name, need_dx=True, dx_kw=None):
-        """dW += dy^T x ; db += colsum(dy) ; returns dx = dy W (bf16) if need_dx."""
+    def _lin_bwd(self, dy, x, name, need_dx=True, dx_kw=None, bias_done=False):
+        """dW += dy^T x ; db += colsum(dy) (unless the kernel that produced dy already accumulated it) ; returns dx = dy W (bf16)."""
         S = self.S
         M, N = S.shape[name + ".weight"]
         ops.gemm(dy, x, TN, out_f32=S.g(name + ".weight"), accumulate=True, split_k=0)
-        ops.colsum(dy, S.g(name + ".bias"))
+        if not bias_done:
+            ops.colsum(dy, S.g(name + ".bias"))
         if need_dx:
             return ops.gemm(dy, S.w(name + ".weight"), NN, **(dx_kw or {}))
         return None
@@ -259,11 +268,20 @@ class Engine:
         mod, dmod = ctx["mod"][l], ctx["dmod"][l]
         st = 6 * D
         dev = G.device
+        # bias gradients ride along with the kernels that produce the output gradients (no separate column-sum passes); they add
+        # into PXA_COLSUM_SLOTS partial rows laid out like this block's bias range of the flat gradient buffer
+        bs, be = S.bias_range(p)
+        part = torch.zeros((ops.COLSUM_SLOTS, be - bs), dtype=F32, device=dev)
+
+        def pb(name, lo=0, hi=None):
+            o = S.offset[p + name] - bs
+            return part[:, o + lo:o + (S.numel[p + name] if hi is None else hi)]
         # ---- MLP branch: x3 = x2 + gate_mlp * u3
         du = torch.empty((R, D), dtype=BF16, device=dev)
-        ops.gate_bwd(G, u=sv["u3"], gate=mod[:, 5], mod_stride=st, du=du, dgate=dmod[:, 5], dmod_stride=st, rows_per_batch=N)
-        dh = self._lin_bwd(du, sv["h"], p + "mlp.fc2", dx_kw=dict(act=ops.ACT_GELU_GRAD, aux=sv["hpre"]))
-        dxn = self._lin_bwd(dh, sv["xn2"], p + "mlp.fc1")
+        ops.gate_bwd(G, u=sv["u3"], gate=mod[:, 5], mod_stride=st, du=du, dgate=dmod[:, 5], dmod_stride=st, rows_per_batch=N,
+                     dbias=pb("mlp.fc2.bias"))
+        dh = self._lin_bwd(du, sv["h"], p + "mlp.fc2", dx_kw=dict(act=ops.ACT_GELU_GRAD, aux=sv["hpre"], colsum=pb("mlp.fc1.bias")), bias_done=True)
+        dxn = self._lin_bwd(dh, sv["xn2"], p + "mlp.fc1", bias_done=True)
         del dh
         # ---- cross attention: x2 = x1 + u2 (no gate, no norm): du2 = bf16(G2) comes out of the LN backward pass itself
         ops.ln_mod_bwd(dxn, sv["x2"], sv["mean2"], sv["rstd2"], mod[:, 4], st, G, G, dmod[:, 3], dmod[:, 4], st, N, dx_bf16=du)
@@ -278,8 +296,9 @@ class Engine:
         gq = self._lin_bwd(dqc, sv["x1b"], p + "cross_attn.q_linear")
         self._lin_bwd(dkvc, ctx["ye"], p + "cross_attn.kv_linear", dx_kw=dict(out_f32=ctx["dye"], accumulate=True))
         # ---- self attention: x1 = x_in + gate_msa * u1 ; G1 = G + gq
-        ops.gate_bwd(G, add=gq, u=sv["u1"], gate=mod[:, 2], mod_stride=st, dx_out=G, du=du, dgate=dmod[:, 2], dmod_stride=st, rows_per_batch=N)
-        da = self._lin_bwd(du, sv["a"], p + "attn.proj")
+        ops.gate_bwd(G, add=gq, u=sv["u1"], gate=mod[:, 2], mod_stride=st, dx_out=G, du=du, dgate=dmod[:, 2], dmod_stride=st, rows_per_batch=N,
+                     dbias=pb("attn.proj.bias"))
+        da = self._lin_bwd(du, sv["a"], p + "attn.proj", bias_done=True)
         qkv = sv["qkv"]
         s3 = (N * 3 * D, 3 * D, 72)
         so = (N * D, D, 72)
@@ -313,8 +332,11 @@ class Engine:
             else:
                 ops.kv_pick(dkc, dqkv[:, D:2 * D], N * 3 * D, 3 * D, B, hh, ww, D, sr, backward=True)
                 ops.kv_pick(dvc, dqkv[:, 2 * D:], N * 3 * D, 3 * D, B, hh, ww, D, sr, backward=True)
+        # the attention kernels can also emit the q/k/v bias-gradient sums (pxa_attn_args.d*_colsum), but the cross-lane row
+        # reductions cost them more (~0.5 ms/block) than one streaming column-sum pass over dqkv (~0.2 ms/block): measured, not used
         dxn = self._lin_bwd(dqkv, sv["xn1"], p + "attn.qkv")
         ops.ln_mod_bwd(dxn, sv["x_in"], sv["mean1"], sv["rstd1"], mod[:, 1], st, G, G, dmod[:, 0], dmod[:, 1], st, N)
+        ops.colsum_reduce(part, S.grad[bs:be])
         if self.grad_ready_hook:
             self.grad_ready_hook(f"blocks.{l}")
         return G

@@ -19,7 +19,7 @@ class GemmArgs(C.Structure):
                 ("bias", c_void_p), ("act", c_int), ("aux", c_void_p), ("ldaux", c_int),
                 ("out_bf16", c_void_p), ("out2_bf16", c_void_p), ("ld_out", c_int),
                 ("out_f32", c_void_p), ("ld_f32", c_int), ("accumulate", c_int), ("split_k", c_int),
-                ("splitk_ws", c_void_p), ("splitk_ws_elems", c_long)]
+                ("splitk_ws", c_void_p), ("splitk_ws_elems", c_long), ("colsum", c_void_p), ("colsum_stride", c_long)]
 
 
 class AttnArgs(C.Structure):
@@ -32,7 +32,8 @@ class AttnArgs(C.Structure):
                 ("dq_bs", c_long), ("dq_ts", c_long), ("dk_bs", c_long), ("dk_ts", c_long), ("dv_bs", c_long), ("dv_ts", c_long),
                 ("dq_hs", c_int), ("dk_hs", c_int), ("dv_hs", c_int),
                 ("B", c_int), ("H", c_int), ("Nq", c_int), ("Nk", c_int), ("head_dim", c_int),
-                ("kv_start", c_void_p), ("kv_len", c_void_p), ("max_kv_len", c_int), ("scale", c_float)]
+                ("kv_start", c_void_p), ("kv_len", c_void_p), ("max_kv_len", c_int), ("scale", c_float),
+                ("dq_colsum", c_void_p), ("dk_colsum", c_void_p), ("dv_colsum", c_void_p), ("colsum_stride", c_long)]
 
 
 # name -> argtypes (all return int); must list every symbol include/pixart_hip.h declares
@@ -41,7 +42,8 @@ SIGNATURES = {
     "pxa_gemm": [C.POINTER(GemmArgs), _P],
     "pxa_ln_mod_fwd": [_P, _P, _P, _I, _P, _P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _F, _P],
     "pxa_ln_mod_bwd": [_P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
-    "pxa_gate_bwd": [_P, _P, _P, _P, _I, _P, _P, _P, _I, _I, _I, _I, _P],
+    "pxa_gate_bwd": [_P, _P, _P, _P, _I, _P, _P, _P, _I, _P, _L, _I, _I, _I, _P],
+    "pxa_colsum_reduce": [_P, _L, _P, _L, _P],
     "pxa_colsum_bf16": [_P, _I, _P, _I, _I, _P],
     "pxa_attn_fwd": [C.POINTER(AttnArgs), _P],
     "pxa_attn_bwd": [C.POINTER(AttnArgs), _P],

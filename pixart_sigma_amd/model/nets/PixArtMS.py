@@ -199,6 +199,7 @@ class PixArtMSBlock(nn.Module):
         dev = self.scale_shift_table.device
         if self._standalone is None or self._standalone.S.device != dev:
             named = [("blocks.0." + n, p) for n, p in self.named_parameters()]
+            named = [t for t in named if not t[0].endswith(".bias")] + [t for t in named if t[0].endswith(".bias")]
             store = ParamStore(named, dev)
             a = self.attn
             cfg = dict(hidden_size=self.hidden_size, num_heads=self.num_heads, depth=1, kv_sampling=a.sampling,
@@ -308,8 +309,9 @@ class PixArtMS(nn.Module):
         groups = ["x_embedder.", "t_embedder.", "t_block.", "y_embedder.", "csize_embedder.", "ar_embedder."]
         order = [n for g in groups for n in named if n.startswith(g)]
         order += [n for n in named if n.endswith("scale_shift_table")]
-        for i in range(self.depth):
-            order += [n for n in named if n.startswith(f"blocks.{i}.") and not n.endswith("scale_shift_table")]
+        for i in range(self.depth):      # a block's weights first, then its biases (one contiguous bias range per block)
+            blk = [n for n in named if n.startswith(f"blocks.{i}.") and not n.endswith("scale_shift_table")]
+            order += [n for n in blk if not n.endswith(".bias")] + [n for n in blk if n.endswith(".bias")]
         order += [n for n in named if n.startswith("final_layer.") and not n.endswith("scale_shift_table")]
         assert len(order) == len(named) == len(set(order))
         return [(n, named[n]) for n in order]

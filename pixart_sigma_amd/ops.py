@@ -19,7 +19,7 @@ def _chk(t, dtype, name):
 
 
 def gemm(a, b, layout=NT, bias=None, act=ACT_NONE, aux=None, out=None, out2=None, out_f32=None, accumulate=False,
-         split_k=1, out_dtype=BF16):
+         split_k=1, out_dtype=BF16, colsum=None):
     """C = op(A) op(B) (see include/pixart_hip.h).  a, b: 2-D bf16 (row stride arbitrary multiple of 8).
     Returns the bf16 output (or fp32 when out_dtype is float32 / out_f32 is given)."""
     _chk(a, BF16, "A")
@@ -61,6 +61,8 @@ def gemm(a, b, layout=NT, bias=None, act=ACT_NONE, aux=None, out=None, out2=None
         assert out is not None and out2.stride(0) == out.stride(0)
         g.out2_bf16 = ptr(out2)
     g.accumulate, g.split_k = int(accumulate), split_k
+    if colsum is not None:               # (PXA_COLSUM_SLOTS, stride) partial buffer view: row 0 of the slice to accumulate
+        g.colsum, g.colsum_stride = ptr(colsum), colsum.stride(0)
     if accumulate and split_k != 1:       # split-K partial slabs: caller-owned workspace, cached per device (max 16 slabs)
         need = 16 * M * N
         ws = _SPLITK_WS.get(a.device)
@@ -96,10 +98,18 @@ def ln_mod_bwd(dy, x, mean, rstd, scale, mod_stride, dx_in, dx_out, dshift, dsca
     return dx_out
 
 
-def gate_bwd(dx, add=None, u=None, gate=None, mod_stride=0, dx_out=None, du=None, dgate=None, dmod_stride=0, rows_per_batch=None):
+def gate_bwd(dx, add=None, u=None, gate=None, mod_stride=0, dx_out=None, du=None, dgate=None, dmod_stride=0, rows_per_batch=None, dbias=None):
     R, D = dx.shape
-    call("pxa_gate_bwd", ptr(dx), ptr(add), ptr(u), ptr(gate), mod_stride, ptr(dx_out), ptr(du), ptr(dgate), dmod_stride,
-         R, D, rows_per_batch or R)
+    call("pxa_gate_bwd", ptr(dx), ptr(add), ptr(u), ptr(gate), mod_stride, ptr(dx_out), ptr(du), ptr(dgate), dmod_stride, ptr(dbias),
+         dbias.stride(0) if dbias is not None else 0, R, D, rows_per_batch or R)
+
+
+COLSUM_SLOTS = 16
+
+
+def colsum_reduce(part, out):
+    """out (n,) += part (COLSUM_SLOTS, >= n).sum(0)"""
+    call("pxa_colsum_reduce", ptr(part), part.stride(0), ptr(out), out.numel())
 
 
 def colsum(dy, out):
@@ -127,8 +137,11 @@ def attention_fwd(q, k, v, o, lse, B, H, Nq, Nk, strides, **kw):
     return o
 
 
-def attention_bwd(q, k, v, o, d_o, lse, delta, dq, dk, dv, B, H, Nq, Nk, strides, dstrides, **kw):
+def attention_bwd(q, k, v, o, d_o, lse, delta, dq, dk, dv, B, H, Nq, Nk, strides, dstrides, colsums=(None, None, None), **kw):
+    """colsums: optional fp32 (H*72,) accumulators receiving the column sums of dq / dk / dv (bias gradients)."""
     a = _attn_args(q, k, v, o, B, H, Nq, Nk, strides, **kw)
+    a.dq_colsum, a.dk_colsum, a.dv_colsum = (ptr(t) for t in colsums)
+    a.colsum_stride = next((t.stride(0) for t in colsums if t is not None), 0)
     a.lse, a.delta, a.d_o, a.dq, a.dk, a.dv = ptr(lse), ptr(delta), ptr(d_o), ptr(dq), ptr(dk), ptr(dv)
     (a.dq_bs, a.dq_ts, a.dq_hs), (a.dk_bs, a.dk_ts, a.dk_hs), (a.dv_bs, a.dv_ts, a.dv_hs) = dstrides
     call("pxa_attn_bwd", a)

@@ -61,8 +61,15 @@ def test_gemm_nn_gelu_grad(ops):
     pre = bf(rnd(M, N, seed=5))
     x = pre.float().clone().requires_grad_(True)
     F.gelu(x, approximate="tanh").backward(torch.ones_like(x))
-    out = ops.gemm(dy, w, ops.NN, act=ops.ACT_GELU_GRAD, aux=pre)
+    part = torch.zeros(ops.COLSUM_SLOTS, N + 64, device="cuda")    # slotted partials, then folded into the gradient
+    out = ops.gemm(dy, w, ops.NN, act=ops.ACT_GELU_GRAD, aux=pre, colsum=part[:, 64:])
     assert rel_l2(out.float(), ref * x.grad) < BF16_TOL
+    cs = torch.ones(N, device="cuda")
+    ops.colsum_reduce(part[:, 64:], cs)
+    assert rel_l2(cs, 1 + (ref * x.grad).sum(0)) < 1e-4          # fused bias-gradient column sums (staged epilogue)
+    part.zero_()
+    ops.gemm(dy[:, :72], w[:72], ops.NN, colsum=part)                # K=72: register-staged fallback kernel + separate column-sum pass
+    assert rel_l2(part.sum(0)[:N], (dy[:, :72].float() @ w[:72].float()).to(torch.bfloat16).float().sum(0)) < 1e-4
 
 
 @pytest.mark.parametrize("K,split", [(512, 1), (1000, 3), (4096, 8)])
@@ -140,8 +147,10 @@ def test_gate_bwd_and_colsum(ops):
     g = dx + add.float()
     dgate = torch.zeros(B, 6, D, device="cuda")
     dxo, du = torch.empty_like(dx), torch.empty(R, D, dtype=torch.bfloat16, device="cuda")
-    ops.gate_bwd(dx, add=add, u=u, gate=gate, mod_stride=6 * D, dx_out=dxo, du=du, dgate=dgate[:, 2], dmod_stride=6 * D, rows_per_batch=N)
+    dbias = torch.zeros(ops.COLSUM_SLOTS, D, device="cuda")
+    ops.gate_bwd(dx, add=add, u=u, gate=gate, mod_stride=6 * D, dx_out=dxo, du=du, dgate=dgate[:, 2], dmod_stride=6 * D, rows_per_batch=N, dbias=dbias)
     assert rel_l2(dxo, g) < 1e-6
+    assert rel_l2(dbias.sum(0), (g * gate.repeat_interleave(N, 0)).sum(0)) < 1e-5
     assert rel_l2(du.float(), g * gate.repeat_interleave(N, 0)) < BF16_TOL
     assert rel_l2(dgate[:, 2], (g * u.float()).view(B, N, D).sum(1)) < 1e-5
     du2 = torch.empty(R, D, dtype=torch.bfloat16, device="cuda")
@@ -177,7 +186,12 @@ def test_attention_fwd_bwd_dense(ops, B, H, Nq, Nk):
     oref.backward(do.float().view(B, Nq, H, 72))
     dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
     delta = torch.empty(B, H, Nq, device="cuda")
-    ops.attention_bwd(q, k, v, o, do, lse, delta, dq, dk, dv, B, H, Nq, Nk, st, (st[0], st[1], st[2]))
+    part = torch.zeros(ops.COLSUM_SLOTS, 3 * C, device="cuda")
+    ops.attention_bwd(q, k, v, o, do, lse, delta, dq, dk, dv, B, H, Nq, Nk, st, (st[0], st[1], st[2]),
+                      colsums=(part[:, :C], part[:, C:2 * C], part[:, 2 * C:]))
+    for i, ref in enumerate((qr.grad, kr.grad, vr.grad)):           # fused bias-gradient column sums (dK sums are ~0 by the softmax Jacobian)
+        got, want = part.sum(0)[i * C:(i + 1) * C], ref.sum((0, 1)).reshape(-1)
+        assert (got - want).norm() < 5e-3 * ref.norm(), i
     assert rel_l2(dv.float().view_as(vr), vr.grad) < 2 * BF16_TOL
     assert rel_l2(dq.float().view_as(qr), qr.grad) < 2 * BF16_TOL
     assert rel_l2(dk.float().view_as(kr), kr.grad) < 2 * BF16_TOL
