@@ -507,168 +507,216 @@ __device__ __forceinline__ bf16x8 frag_p(const char* lds, int rbase, int ks, int
 }
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-template <int LAYOUT, int TBM, int TBN, int WM, int WN, int BKT, int NST>
-__global__ __launch_bounds__(WM * WN * 64) void gemm_pipe_kernel(GemmParams p) {
-  constexpr bool A_KC = (LAYOUT != 2), B_KC = (LAYOUT == 0);
-  constexpr int NW = WM * WN, TM = TBM / WM / 32, TN = TBN / WN / 32;
-  constexpr int A_BYTES = TBM * BKT * 2, B_BYTES = TBN * BKT * 2, STAGE = A_BYTES + B_BYTES;
-  constexpr int PER_TILE = STAGE / 1024 / NW;          // DMA instructions per wave per k-tile
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), wm = wave / WN, wn = wave % WN, hi = lane >> 5;
-  int tm_, tn_, z_;
-  tile_coords(blockIdx.x, (p.M + TBM - 1) / TBM, (p.N + TBN - 1) / TBN, p.split, tm_, tn_, z_);
-  const int m0 = tm_ * TBM, n0 = tn_ * TBN;
-  const int kbeg = z_ * p.k_per_split;
-  const int kend = min(p.K, kbeg + p.k_per_split);
-  const int nk = (kend - kbeg) / BKT;
-
-  f32x16 acc[TM][TN];
-#pragma unroll
-  for (int i = 0; i < TM; i++)
-#pragma unroll
-    for (int j = 0; j < TN; j++)
-#pragma unroll
-      for (int g = 0; g < 16; g++) acc[i][j][g] = 0.f;
-
-  auto issue = [&](int kt) {
-    char* st = smem + (kt % NST) * STAGE;
-    dma_tile_p<A_KC, TBM, NW, BKT>(st, p.A, p.lda, m0, p.M, kbeg + kt * BKT, wave, lane);
-    dma_tile_p<B_KC, TBN, NW, BKT>(st + A_BYTES, p.B, p.ldb, n0, p.N, kbeg + kt * BKT, wave, lane);
-  };
-#pragma unroll
-  for (int s0 = 0; s0 < NST - 1; s0++)
-    if (s0 < nk) issue(s0);
-  for (int kt = 0; kt < nk; kt++) {
-    // tile kt must have landed; up to NST-2 younger tiles may stay in flight (fewer near the end of the k range)
-    const int younger = min(NST - 2, nk - 1 - kt);
-    if (younger >= NST - 2) wait_vmcnt<(NST - 2) * PER_TILE>();
-    else if (NST > 3 && younger == NST - 3) wait_vmcnt<(NST > 3 ? NST - 3 : 0) * PER_TILE>();
-    else wait_vmcnt<0>();
-    __builtin_amdgcn_s_barrier();                      // every wave finished tile kt-1: its stage may be refilled
-    if (kt + NST - 1 < nk) issue(kt + NST - 1);
-    const char* sA = smem + (kt % NST) * STAGE;
-    const char* sB = sA + A_BYTES;
-#pragma unroll
-    for (int ks = 0; ks < BKT / 16; ks++) {
-      bf16x8 af[TM], bf[TN];
-#pragma unroll
-      for (int i = 0; i < TM; i++) af[i] = frag_p<A_KC, TBM, BKT>(sA, wm * (TM * 32) + i * 32, ks, lane);
-#pragma unroll
-      for (int j = 0; j < TN; j++) bf[j] = frag_p<B_KC, TBN, BKT>(sB, wn * (TN * 32) + j * 32, ks, lane);
-#pragma unroll
-      for (int i = 0; i < TM; i++)
-#pragma unroll
-        for (int j = 0; j < TN; j++) acc[i][j] = mfma32(bf[j], af[i], acc[i][j]);
-    }
-  }
-  epilogue_t<TM, TN>(p, acc, m0 + wm * (TM * 32), n0 + wn * (TN * 32), lane, hi, z_);
+__device__ __forceinline__ void wait_vm_upto(int n) {      // n (wave-uniform) in {0, 2, 4, 6}: LDS-DMA instructions that may stay in flight
+  if (n >= 6) wait_vmcnt<6>();
+  else if (n == 4) wait_vmcnt<4>();
+  else if (n == 2) wait_vmcnt<2>();
+  else wait_vmcnt<0>();
 }
+#define PXA_SB() __builtin_amdgcn_sched_barrier(0)
 
 // =====================================================================================================================
-// Phase-staggered variant (guide T3/T5, "8-phase"): with one 512-thread workgroup per CU all 8 waves leave every barrier in
-// lockstep, so their LDS-read / DMA-issue phases coincide and the matrix pipe idles.  Here each k-step is split into an R phase
-// (ds_reads of the step's fragments, DMA issue) and an M phase (8 MFMAs under s_setprio 1), each closed by a raw s_barrier, and
-// the second wave of every SIMD (waves NW/2..NW-1) runs one barrier late: in every interval one wave of a SIMD is in M while
-// the other is in R.  2 LDS stages; the DMA of tile t+1 is issued in R1 (early group) / R0 (late group) — at least two
-// barriers after the last read of that stage — and drained (vmcnt(0)) by both groups in the interval before the early group's
-// first read of tile t+1.
-template <int LAYOUT, int TBM, int TBN, int WM, int WN>
-__global__ __launch_bounds__(WM * WN * 64) void gemm_phase_kernel(GemmParams p) {
+// Persistent ping-pong kernel for the big token GEMMs with bf16 outputs (NT forward, NN dX): one 512-thread workgroup per CU
+// walks the XCD-aware tile order; 256x256 tile, 8 waves (2 x 4, 128x64 each), k-units of 32 in a 4-deep LDS ring (4 x 32 KiB)
+// plus a 32 KiB epilogue staging area (8 x 4 KiB wave-private) = the CU's whole 160 KiB.
+// Main loop.  A 512-thread workgroup puts two waves on every SIMD; left alone they leave each barrier in lockstep, so their
+// LDS-read phases coincide and the matrix pipe idles while fragments arrive.  Every k-unit is two phases
+//   [R: ds_reads of this phase's fragments + 2 LDS-DMA instructions] barrier [M: 8 MFMAs under s_setprio 1] barrier
+// and the second wave of each SIMD (waves 4-7, the wm = 1 row) runs ONE barrier late: in every barrier interval one wave of a
+// SIMD is in M while its partner is in R (guide "8-phase" / T3-T5 schedule).
+// DMA bookkeeping (per wave, in issue order): unit u = A part (2 instructions, issued in R of phase b of unit u-3) then B part
+// (2, issued in R of phase a of unit u-2).  The only in-loop wait is a COUNTED vmcnt in phase b of unit t: everything up to unit
+// t+1 has landed while unit t+2 and half of t+3 (6 instructions) stay in flight across the barriers; two barriers separate it
+// from the first read of unit t+1, for both wave groups.  A ring slot is refilled at the earliest three barriers after the late
+// group's last read of it.
+// Tile hand-over.  With K = 1152 a tile's main loop is only ~30 us, and an epilogue that drains 128 KiB of stores before the
+// workgroup retires (then a fresh workgroup waits ~2 us for its first operands) costs 13-40 % of the GEMM.  Here, after the
+// last k-unit, a wave first issues the NEXT tile's first 2.5 k-units of DMA (the ring is idle), then converts its accumulators
+// 32 rows at a time through its private staging slice into full-row 16-byte stores - which are fire-and-forget - and waits once
+// (vmcnt(0): its stores and the prefetched units) before the next main loop.  Store drain and operand latency of consecutive
+// tiles overlap; bias / GELU / GELU' / second (pre-activation) output / bias-gradient column sums all ride in that epilogue.
+template <int LAYOUT>
+__global__ __launch_bounds__(512) void gemm_pers_kernel(GemmParams p) {
   constexpr bool A_KC = (LAYOUT != 2), B_KC = (LAYOUT == 0);
-  constexpr int NW = WM * WN, TM = TBM / WM / 32, TN = TBN / WN / 32;
-  constexpr int A_BYTES = TBM * 128, B_BYTES = TBN * 128, STAGE = A_BYTES + B_BYTES;
+  constexpr int TBM = 256, TBN = 256, WN = 4, NW = 8, TM = 4, TN = 2, BKT = 32;
+  constexpr int A_BYTES = TBM * BKT * 2, B_BYTES = TBN * BKT * 2, UNIT = A_BYTES + B_BYTES;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), wm = wave / WN, wn = wave % WN, hi = lane >> 5;
-  const bool late = wave >= NW / 2;                    // wave-uniform (SGPR)
-  int tm_, tn_, z_;
-  tile_coords(blockIdx.x, (p.M + TBM - 1) / TBM, (p.N + TBN - 1) / TBN, p.split, tm_, tn_, z_);
-  const int m0 = tm_ * TBM, n0 = tn_ * TBN;
-  const int kbeg = z_ * p.k_per_split;
-  const int kend = min(p.K, kbeg + p.k_per_split);
-  const int nk = (kend - kbeg) / BK;
+  const bool late = wave >= NW / 2;
+  char* stg = smem + 4 * UNIT + wave * 4096;           // this wave's 32 rows x 128 B staging slice
+  const int mt = (p.M + TBM - 1) / TBM, nt = (p.N + TBN - 1) / TBN, T = mt * nt;
+  const int nk = p.K / BKT;                            // >= 2 (K is a multiple of 64 on this path)
 
-  f32x16 acc[TM][TN];
+  int tm_, tn_, z_;
+  int L = blockIdx.x;
+  tile_coords(L, mt, nt, 1, tm_, tn_, z_);
+  int m0 = tm_ * TBM, n0 = tn_ * TBN;
+  auto issueA = [&](int u) { dma_tile_p<A_KC, TBM, NW, BKT>(smem + (u & 3) * UNIT, p.A, p.lda, m0, p.M, u * BKT, wave, lane); };
+  auto issueB = [&](int u) { dma_tile_p<B_KC, TBN, NW, BKT>(smem + (u & 3) * UNIT + A_BYTES, p.B, p.ldb, n0, p.N, u * BKT, wave, lane); };
+  issueA(0); issueB(0); issueA(1); issueB(1);
+  if (nk > 2) issueA(2);
+
+  while (true) {
+    f32x16 acc[TM][TN];
 #pragma unroll
-  for (int i = 0; i < TM; i++)
+    for (int i = 0; i < TM; i++)
+#pragma unroll
+      for (int j = 0; j < TN; j++)
+#pragma unroll
+        for (int g = 0; g < 16; g++) acc[i][j][g] = 0.f;
+    wait_vmcnt<0>();                                   // this tile's first units have landed; last tile's stores are out
+    __builtin_amdgcn_s_barrier();
+    if (late) __builtin_amdgcn_s_barrier();            // stagger the second wave of each SIMD by one barrier interval
+    for (int t = 0; t < nk; t++) {
+      const char* sA = smem + (t & 3) * UNIT;
+      const char* sB = sA + A_BYTES;
+      bf16x8 af[2][2], bf[2][TN];
+      // ---- phase a: rows 0..63 of the wave's 128 x all 64 columns
+#pragma unroll
+      for (int ks = 0; ks < 2; ks++)
+#pragma unroll
+        for (int j = 0; j < TN; j++) bf[ks][j] = frag_p<B_KC, TBN, BKT>(sB, wn * 64 + j * 32, ks, lane);
+#pragma unroll
+      for (int ks = 0; ks < 2; ks++)
+#pragma unroll
+        for (int i = 0; i < 2; i++) af[ks][i] = frag_p<A_KC, TBM, BKT>(sA, wm * 128 + i * 32, ks, lane);
+      if (t + 2 < nk) issueB(t + 2);
+      PXA_SB(); __builtin_amdgcn_s_barrier(); PXA_SB();
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int ks = 0; ks < 2; ks++)
+#pragma unroll
+        for (int i = 0; i < 2; i++)
+#pragma unroll
+          for (int j = 0; j < TN; j++) acc[i][j] = mfma32(bf[ks][j], af[ks][i], acc[i][j]);
+      __builtin_amdgcn_s_setprio(0);
+      PXA_SB(); __builtin_amdgcn_s_barrier(); PXA_SB();
+      // ---- phase b: rows 64..127 (the B fragments stay in registers)
+#pragma unroll
+      for (int ks = 0; ks < 2; ks++)
+#pragma unroll
+        for (int i = 0; i < 2; i++) af[ks][i] = frag_p<A_KC, TBM, BKT>(sA, wm * 128 + 64 + i * 32, ks, lane);
+      if (t + 3 < nk) issueA(t + 3);
+      if (t + 1 < nk) wait_vm_upto((t + 2 < nk ? 4 : 0) + (t + 3 < nk ? 2 : 0));
+      PXA_SB(); __builtin_amdgcn_s_barrier(); PXA_SB();
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int ks = 0; ks < 2; ks++)
+#pragma unroll
+        for (int i = 0; i < 2; i++)
+#pragma unroll
+          for (int j = 0; j < TN; j++) acc[2 + i][j] = mfma32(bf[ks][j], af[ks][i], acc[2 + i][j]);
+      __builtin_amdgcn_s_setprio(0);
+      PXA_SB(); __builtin_amdgcn_s_barrier(); PXA_SB();
+    }
+    if (!late) __builtin_amdgcn_s_barrier();           // every wave has executed the same number of barriers; the ring is idle
+
+    // ---- hand-over: prefetch the next tile's first units, then this tile's epilogue
+    const int mw = m0 + wm * 128, nw = n0 + wn * 64;   // this wave's output origin (current tile)
+    L += gridDim.x;
+    const bool more = L < T;
+    if (more) {
+      tile_coords(L, mt, nt, 1, tm_, tn_, z_);
+      m0 = tm_ * TBM; n0 = tn_ * TBN;
+      issueA(0); issueB(0); issueA(1); issueB(1);
+      if (nk > 2) issueA(2);
+    }
+    const bool dual = (p.act == 1 && p.out2 != nullptr);
+    float4 bq[TN][4];                                  // bias for this lane's 4-column groups
 #pragma unroll
     for (int j = 0; j < TN; j++)
 #pragma unroll
-      for (int g = 0; g < 16; g++) acc[i][j][g] = 0.f;
-
-  if (nk > 0) {
-    dma_tile<A_KC, TBM, NW>(smem, p.A, p.lda, m0, p.M, kbeg, wave, lane);
-    dma_tile<B_KC, TBN, NW>(smem + A_BYTES, p.B, p.ldb, n0, p.N, kbeg, wave, lane);
-  }
-  wait_vmcnt<0>();
-  __builtin_amdgcn_s_barrier();
-  if (late) __builtin_amdgcn_s_barrier();              // stagger the second wave of each SIMD by one phase
-  for (int kt = 0; kt < nk; kt++) {
-    const int cur = kt & 1;
-    const char* sA = smem + cur * STAGE;
-    const char* sB = sA + A_BYTES;
-    const bool more = kt + 1 < nk;
-#pragma unroll
-    for (int ks = 0; ks < BK / 16; ks++) {
-      // ---- R phase
-      bf16x8 af[TM], bf[TN];
-#pragma unroll
-      for (int i = 0; i < TM; i++) af[i] = frag_g<A_KC, TBM>(sA, wm * (TM * 32) + i * 32, ks, lane);
-#pragma unroll
-      for (int j = 0; j < TN; j++) bf[j] = frag_g<B_KC, TBN>(sB, wn * (TN * 32) + j * 32, ks, lane);
-      if (more && ks == (late ? 0 : 1)) {
-        char* nxt = smem + (cur ^ 1) * STAGE;
-        dma_tile<A_KC, TBM, NW>(nxt, p.A, p.lda, m0, p.M, kbeg + (kt + 1) * BK, wave, lane);
-        dma_tile<B_KC, TBN, NW>(nxt + A_BYTES, p.B, p.ldb, n0, p.N, kbeg + (kt + 1) * BK, wave, lane);
+      for (int q = 0; q < 4; q++) {
+        const int n = nw + j * 32 + 8 * q + 4 * hi;
+        bq[j][q] = (p.bias && n < p.N) ? *reinterpret_cast<const float4*>(p.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
       }
-      if (ks == BK / 16 - 1 && late) wait_vmcnt<0>();
-      __builtin_amdgcn_sched_barrier(0);
-      __builtin_amdgcn_s_barrier();
-      __builtin_amdgcn_sched_barrier(0);
-      // ---- M phase
-      __builtin_amdgcn_s_setprio(1);
+    float cs[TN][16];
 #pragma unroll
-      for (int i = 0; i < TM; i++)
+    for (int j = 0; j < TN; j++)
 #pragma unroll
-        for (int j = 0; j < TN; j++) acc[i][j] = mfma32(bf[j], af[i], acc[i][j]);
-      __builtin_amdgcn_s_setprio(0);
-      if (ks == BK / 16 - 1 && !late) wait_vmcnt<0>();
-      __builtin_amdgcn_sched_barrier(0);
-      __builtin_amdgcn_s_barrier();
-      __builtin_amdgcn_sched_barrier(0);
+      for (int g = 0; g < 16; g++) cs[j][g] = 0.f;
+#pragma unroll
+    for (int i = 0; i < TM; i++) {
+      const int m = mw + i * 32 + (lane & 31);
+      uint2 ax[TN][4];
+      if (p.act == 2) {                                // GELU' needs the saved pre-activation: fetch the slice's values up front
+#pragma unroll
+        for (int j = 0; j < TN; j++)
+#pragma unroll
+          for (int q = 0; q < 4; q++) {
+            const int n = nw + j * 32 + 8 * q + 4 * hi;
+            ax[j][q] = (m < p.M && n < p.N) ? *reinterpret_cast<const uint2*>(p.aux + (size_t)m * p.ldaux + n) : make_uint2(0u, 0u);
+          }
+      }
+#pragma unroll
+      for (int pass = 0; pass < 2; pass++) {           // pass 0: pre-activation copy (dual output only); pass 1: final values
+        if (pass == 0 && !dual) continue;
+#pragma unroll
+        for (int j = 0; j < TN; j++)
+#pragma unroll
+          for (int q = 0; q < 4; q++) {
+            float v[4] = {acc[i][j][q * 4] + bq[j][q].x, acc[i][j][q * 4 + 1] + bq[j][q].y, acc[i][j][q * 4 + 2] + bq[j][q].z, acc[i][j][q * 4 + 3] + bq[j][q].w};
+            if (pass == 1) {
+              if (p.act == 1) {
+#pragma unroll
+                for (int e = 0; e < 4; e++) v[e] = gelu_tanh(v[e]);
+              } else if (p.act == 2) {
+                float a0, a1, a2, a3;
+                unpack_bf16x2(ax[j][q].x, a0, a1); unpack_bf16x2(ax[j][q].y, a2, a3);
+                v[0] *= gelu_tanh_grad(a0); v[1] *= gelu_tanh_grad(a1); v[2] *= gelu_tanh_grad(a2); v[3] *= gelu_tanh_grad(a3);
+              }
+              if (p.colsum && m < p.M) {
+#pragma unroll
+                for (int e = 0; e < 4; e++) cs[j][q * 4 + e] += v[e];
+              }
+            }
+            const int col = j * 32 + 8 * q + 4 * hi;
+            *reinterpret_cast<uint2*>(stg + (lane & 31) * 128 + (((col >> 3) ^ (lane & 7)) << 4) + (col & 4) * 2) = pack_bf16x4(v[0], v[1], v[2], v[3]);
+          }
+        __builtin_amdgcn_s_waitcnt(0xc07f);            // lgkmcnt(0): the slice is private to this wave
+        bf16_t* dst = pass == 0 ? p.out2 : p.out;
+#pragma unroll
+        for (int t4 = 0; t4 < 4; t4++) {               // 8 rows x 128 B per store instruction
+          const int row = t4 * 8 + (lane >> 3), ch = lane & 7;
+          const uint4 v4 = *reinterpret_cast<const uint4*>(stg + row * 128 + ((ch ^ (row & 7)) << 4));
+          const int mm = mw + i * 32 + row, nn = nw + ch * 8;
+          if (mm < p.M && nn < p.N) *reinterpret_cast<uint4*>(dst + (size_t)mm * p.ldo + nn) = v4;
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);            // reads returned before the slice is overwritten
+      }
     }
+    if (p.colsum) {                                    // column sums over this wave's rows: lane tree, one atomic per column and slot
+#pragma unroll
+      for (int j = 0; j < TN; j++)
+#pragma unroll
+        for (int g = 0; g < 16; g++) {
+          float v = cs[j][g];
+          v += __shfl_xor(v, 16); v += __shfl_xor(v, 8); v += __shfl_xor(v, 4); v += __shfl_xor(v, 2); v += __shfl_xor(v, 1);
+          const int n = nw + j * 32 + 8 * (g >> 2) + 4 * hi + (g & 3);
+          if ((lane & 31) == 0 && n < p.N) atomicAdd(p.colsum + (size_t)((mw >> 7) % PXA_COLSUM_SLOTS) * p.colsum_stride + n, v);
+        }
+    }
+    if (!more) break;
   }
-  if (!late) __builtin_amdgcn_s_barrier();             // every wave executes the same number of barriers
-  epilogue_t<TM, TN>(p, acc, m0 + wm * (TM * 32), n0 + wn * (TN * 32), lane, hi, z_);
 }
 
-template <int LAYOUT, int TBM, int TBN, int WM, int WN>
-int launch_phase(GemmParams p, int split, hipStream_t s) {
-  p.split = split;
-  constexpr int LDSG = 2 * (TBM + TBN) * 128;
-  static bool attr_set_ph = false;
-  if (!attr_set_ph) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_phase_kernel<LAYOUT, TBM, TBN, WM, WN>), hipFuncAttributeMaxDynamicSharedMemorySize, LDSG);
-    if (e != hipSuccess) { pxa_set_error("hipFuncSetAttribute(gemm_phase<%d,%d,%d>): %s", LAYOUT, TBM, TBN, hipGetErrorString(e)); return -3; }
-    attr_set_ph = true;
+template <int LAYOUT>
+int launch_pers(GemmParams p, hipStream_t s) {
+  p.split = 1;
+  constexpr int LDSP = 4 * 32768 + 8 * 4096;           // 160 KiB: one workgroup per CU
+  static bool attr_set_pp = false;
+  static int n_cu = 0;
+  if (!attr_set_pp) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_pers_kernel<LAYOUT>), hipFuncAttributeMaxDynamicSharedMemorySize, LDSP);
+    if (e != hipSuccess) { pxa_set_error("hipFuncSetAttribute(gemm_pers<%d>): %s", LAYOUT, hipGetErrorString(e)); return -3; }
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) { pxa_set_error("gemm_pers: device query failed"); return -3; }
+    n_cu = prop.multiProcessorCount;
+    attr_set_pp = true;
   }
-  dim3 grid(((p.M + TBM - 1) / TBM) * ((p.N + TBN - 1) / TBN) * split, 1, 1);
-  hipLaunchKernelGGL((gemm_phase_kernel<LAYOUT, TBM, TBN, WM, WN>), grid, dim3(WM * WN * 64), LDSG, s, p);
-  PXA_LAUNCH_CHECK();
-  return 0;
-}
-
-template <int LAYOUT, int TBM, int TBN, int WM, int WN, int BKT, int NST>
-int launch_pipe(GemmParams p, int split, hipStream_t s) {
-  p.split = split;
-  constexpr int LDSP = NST * (TBM + TBN) * BKT * 2;
-  static bool attr_set_p = false;
-  if (!attr_set_p) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_pipe_kernel<LAYOUT, TBM, TBN, WM, WN, BKT, NST>), hipFuncAttributeMaxDynamicSharedMemorySize, LDSP);
-    if (e != hipSuccess) { pxa_set_error("hipFuncSetAttribute(gemm_pipe<%d,%d,%d>): %s", LAYOUT, TBM, TBN, hipGetErrorString(e)); return -3; }
-    attr_set_p = true;
-  }
-  dim3 grid(((p.M + TBM - 1) / TBM) * ((p.N + TBN - 1) / TBN) * split, 1, 1);
-  hipLaunchKernelGGL((gemm_pipe_kernel<LAYOUT, TBM, TBN, WM, WN, BKT, NST>), grid, dim3(WM * WN * 64), LDSP, s, p);
+  const int tiles = ((p.M + 255) / 256) * ((p.N + 255) / 256);
+  hipLaunchKernelGGL((gemm_pers_kernel<LAYOUT>), dim3(tiles < n_cu ? tiles : n_cu), dim3(512), LDSP, s, p);
   PXA_LAUNCH_CHECK();
   return 0;
 }
@@ -695,6 +743,8 @@ int launch_glds(GemmParams p, int split, hipStream_t s) {
   // neither epilogue's registers burden the other)
   static const bool no_stage = getenv("PXA_GEMM_NO_STAGED_EPILOGUE") != nullptr;
   const bool dual = (p.act == 1 && p.out2 != nullptr);   // two LDS trips: measured slower than the direct epilogue
+  static const bool no_pers = getenv("PXA_GEMM_NO_PERSISTENT") != nullptr;
+  if (LAYOUT != 2 && TBM == 256 && TBN == 256 && split == 1 && p.out && !p.outf && !no_pers) return launch_pers<LAYOUT == 2 ? 0 : LAYOUT>(p, s);
   if (LAYOUT != 2 && p.out && !p.outf && !dual && !no_stage) return launch_glds_e<LAYOUT, TBM, TBN, WM, WN, 1>(p, split, s);
   if (p.colsum) {                                         // not fused on this path: separate column-sum pass over the output
     float* cs = p.colsum;
@@ -719,15 +769,6 @@ int launch(GemmParams p, int split, hipStream_t s) {
   dim3 grid(((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN) * split, 1, 1);
   const bool fast = (p.K % BK == 0) && (p.k_per_split % BK == 0) && !getenv("PXA_GEMM_NO_GLDS");
   if (fast) {
-    static const char* pipe = getenv("PXA_GEMM_PIPE");    // A/B: deep-pipelined variants
-    if (pipe && p.k_per_split % 64 == 0) {
-      if (!strcmp(pipe, "phase256")) return launch_phase<LAYOUT, 256, 256, 2, 4>(p, split, s);
-      if (!strcmp(pipe, "phase256x128")) return launch_phase<LAYOUT, 256, 128, 4, 2>(p, split, s);
-      if (!strcmp(pipe, "256x32x4")) return launch_pipe<LAYOUT, 256, 256, 2, 4, 32, 4>(p, split, s);
-      if (!strcmp(pipe, "256x128x64x3")) return launch_pipe<LAYOUT, 256, 128, 4, 2, 64, 3>(p, split, s);
-      if (!strcmp(pipe, "128x64x3")) return launch_pipe<LAYOUT, 128, 128, 2, 2, 64, 3>(p, split, s);
-      if (!strcmp(pipe, "128x64x4")) return launch_pipe<LAYOUT, 128, 128, 2, 2, 64, 4>(p, split, s);
-    }
     static const char* force = getenv("PXA_GEMM_TILE");   // "128" | "256x128" | "256" : A/B experiments
     int tile = force ? atoi(force) * (strstr(force, "x128") ? -1 : 1) : 0;
     if (!tile) tile = p.tile_hint;

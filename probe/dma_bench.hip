@@ -1,0 +1,286 @@
+// LDS-DMA (global_load_lds_dwordx4) throughput probe for the GEMM operand stream on gfx950.  Test infrastructure, not product.
+// A 256x256-tile GEMM moves 32 KiB per k-unit of 32 per workgroup; this kernel performs exactly that stream (same tile order,
+// same ring of 4 LDS slots, counted vmcnt + one barrier per unit) with NO fragment reads and an optional MFMA filler, for
+// different global-side shapes of the 1 KiB a wave instruction fetches:
+//   SEG = 64   : 16 rows x 64 B      (k-unit 32, row-major operand)
+//   SEG = 128  :  8 rows x 128 B     (k-unit 64)
+//   SEG = 256  :  4 rows x 256 B
+//   SEG = 1024 : one contiguous KiB  (operand pre-tiled in the LDS image order)
+// Build: hipcc --offload-arch=gfx950 -O3 dma_bench.hip -o dma_bench
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1);} } while (0)
+typedef __bf16 bf8 __attribute__((ext_vector_type(8)));
+typedef float f16v __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ void tile_coords(int bid, int mt, int nt, int& tm, int& tn) {
+  const int T = mt * nt, q = T / 8, r = T % 8, x = bid % 8, idx = bid / 8;
+  const int t = x * q + min(x, r) + idx;
+  const int per_group = 8 * nt, g = t / per_group, first_m = g * 8, gsz = min(mt - first_m, 8), in_g = t - g * per_group;
+  tm = first_m + in_g % gsz;
+  tn = in_g / gsz;
+}
+__global__ void fill(unsigned short* p, size_t n) {       // pseudo-random bf16 in about [-2, 2): realistic MFMA toggle power
+  for (size_t i = blockIdx.x * 256ul + threadIdx.x; i < n; i += gridDim.x * 256ul) {
+    unsigned h = (unsigned)i * 2654435761u; h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
+    p[i] = (unsigned short)((h & 0x807f) | (0x3f00 + ((h >> 8) & 0x80)));
+  }
+}
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+template <int SEG>
+__device__ __forceinline__ const char* src_addr(const char* X, long ldb, int r0, int u, int q, int lane, int units) {
+  if (SEG == 1024) return X + ((((long)(r0 >> 8) * units + u) * 16 + q) << 10) + lane * 16;
+  constexpr int LPR = SEG / 16, RPP = 64 / LPR, SUB = SEG / 64;       // lanes per row, rows per piece, units sharing one k-chunk
+  const int row = (u % SUB) * (256 / SUB) + q * RPP + lane / LPR;
+  return X + (long)(r0 + row) * ldb + (long)(u / SUB) * SEG + (lane % LPR) * 16;
+}
+
+template <int SEG, int NW, int MM>
+__global__ __launch_bounds__(NW * 64) void dma_kernel(const char* A, const char* B, long lda, long ldb, int mt, int nt, int units, float* sink) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  int tm, tn;
+  tile_coords(blockIdx.x, mt, nt, tm, tn);
+  constexpr int PER = 32 / NW;                                         // instructions per wave per unit
+  auto issue = [&](int u) {
+#pragma unroll
+    for (int i = 0; i < PER; i++) {
+      const int piece = i * NW + wave;                                 // 0..31: 16 of A then 16 of B
+      const char* s = piece < 16 ? src_addr<SEG>(A, lda, tm * 256, u, piece, lane, units) : src_addr<SEG>(B, ldb, tn * 256, u, piece - 16, lane, units);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)s,
+                                       (__attribute__((address_space(3))) void*)(smem + (u & 3) * 32768 + piece * 1024), 16, 0, 0);
+    }
+  };
+  f16v acc[4] = {};
+  bf8 a, b;
+#pragma unroll
+  for (int j = 0; j < 8; j++) { a[j] = (__bf16)(0.37f + lane * 0.01f + j); b[j] = (__bf16)(1.3f - lane * 0.02f + j); }
+  issue(0); issue(1); issue(2);
+  for (int u = 0; u < units; u++) {
+    if (u + 3 < units) { issue(u + 3); wait_vmcnt<2 * PER>(); }
+    else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    if (MM) {
+#pragma unroll
+      for (int i = 0; i < MM; i++) acc[i & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[i & 3], 0, 0, 0);
+    }
+  }
+  if (MM) {
+    float s = 0;
+    for (int i = 0; i < 4; i++) for (int g = 0; g < 16; g++) s += acc[i][g];
+    if (s == 12345.678f) sink[0] = s;
+  }
+  if (smem[threadIdx.x * 4] == 77 && sink[1] == 3.f) sink[2] = 1.f;   // keep the LDS writes observable
+}
+
+template <int SEG, int NW, int MM>
+void run(const char* A, const char* B, int M, int N, int K, float* sink) {
+  const int mt = M / 256, nt = N / 256, units = K / 32;
+  CK(hipFuncSetAttribute(reinterpret_cast<const void*>(dma_kernel<SEG, NW, MM>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
+  hipEvent_t e0, e1;
+  CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  for (int it = 0; it < 2; it++) hipLaunchKernelGGL((dma_kernel<SEG, NW, MM>), dim3(mt * nt), dim3(NW * 64), 131072, 0, A, B, (long)K * 2, (long)K * 2, mt, nt, units, sink);
+  CK(hipEventRecord(e0));
+  const int iters = 5;
+  for (int it = 0; it < iters; it++) hipLaunchKernelGGL((dma_kernel<SEG, NW, MM>), dim3(mt * nt), dim3(NW * 64), 131072, 0, A, B, (long)K * 2, (long)K * 2, mt, nt, units, sink);
+  CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+  float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= iters;
+  const double bytes = (double)mt * nt * units * 32768.0, flops = 2.0 * M * N * K;
+  printf("M=%d N=%d K=%d SEG=%4d waves=%d mfma/unit/wave=%2d : %7.3f ms  %6.2f TB/s into LDS  %5.1f B/ns/CU  (GEMM-equivalent %7.1f TF/s)\n",
+         M, N, K, SEG, NW, MM, ms, bytes / ms / 1e9, bytes / 256 / ms / 1e6, flops / ms / 1e9);
+}
+
+
+// ---- schedule study: the same stream + the real fragment reads (12 ds_read_b128 per unit per wave) + 16 MFMAs per unit per wave,
+// arranged in different ways.  Results are meaningless numbers; only the time matters.
+//   MODE 1: one barrier per unit, lockstep:  issue DMA, wait, barrier, 12 reads, 16 MFMAs
+//   MODE 2: MODE 1 with the reads of k-sub-step 1 issued before the MFMAs of k-sub-step 0 (register double buffering)
+//   MODE 3: ping-pong, 4 barriers per unit (two 8-MFMA phases), late group one barrier behind
+//   MODE 4: ping-pong, 2 barriers per unit (one 16-MFMA phase), late group one barrier behind
+//   MODE 5: MODE 4 without s_setprio
+//   MODE 6: MODE 3 without reads (DMA + MFMA + barriers only)
+__device__ __forceinline__ bf8 frag(const char* lds, int rbase, int ks, int lane) {
+  const int row = rbase + (lane & 31), c = ks * 2 + (lane >> 5);
+  return *reinterpret_cast<const bf8*>(lds + row * 64 + ((c ^ ((row >> 2) & 3)) << 4));
+}
+#define SB() __builtin_amdgcn_sched_barrier(0)
+#define BAR() do { SB(); __builtin_amdgcn_s_barrier(); SB(); } while (0)
+template <int MODE>
+__global__ __launch_bounds__(512) void sched_kernel(const char* A, const char* B, long lda, long ldb, int mt, int nt, int units, float* sink) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), wm = wave >> 2, wn = wave & 3;
+  const bool late = wave >= 4;
+  int tm, tn;
+  tile_coords(blockIdx.x, mt, nt, tm, tn);
+  auto issue = [&](int u, int lo, int hi) {          // pieces [lo, hi) of this wave's 4 per unit
+#pragma unroll
+    for (int i = lo; i < hi; i++) {
+      const int piece = i * 8 + wave;
+      const char* s = piece < 16 ? src_addr<64>(A, lda, tm * 256, u, piece, lane, units) : src_addr<64>(B, ldb, tn * 256, u, piece - 16, lane, units);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)s,
+                                       (__attribute__((address_space(3))) void*)(smem + (u & 3) * 32768 + piece * 1024), 16, 0, 0);
+    }
+  };
+  f16v acc[4][2] = {};
+  issue(0, 0, 4); issue(1, 0, 4); issue(2, 0, 4);
+  wait_vmcnt<8>();
+  __builtin_amdgcn_s_barrier();
+  if (MODE >= 3 && late) __builtin_amdgcn_s_barrier();
+  bf8 af[2][4], bfr[2][2];
+  if (MODE == 6) {
+    for (int ks = 0; ks < 2; ks++) { for (int i = 0; i < 4; i++) af[ks][i] = frag(smem, wm * 128 + i * 32, ks, lane); for (int j = 0; j < 2; j++) bfr[ks][j] = frag(smem + 16384, wn * 64 + j * 32, ks, lane); }
+  }
+  for (int u = 0; u < units; u++) {
+    const char* sA = smem + (u & 3) * 32768;
+    const char* sB = sA + 16384;
+    if (MODE == 1 || MODE == 2) {
+      if (u + 3 < units) issue(u + 3, 0, 4);
+      if (MODE == 1) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ks++) {
+#pragma unroll
+          for (int i = 0; i < 4; i++) af[ks][i] = frag(sA, wm * 128 + i * 32, ks, lane);
+#pragma unroll
+          for (int j = 0; j < 2; j++) bfr[ks][j] = frag(sB, wn * 64 + j * 32, ks, lane);
+        }
+#pragma unroll
+        for (int ks = 0; ks < 2; ks++)
+#pragma unroll
+          for (int i = 0; i < 4; i++)
+#pragma unroll
+            for (int j = 0; j < 2; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[ks][j], af[ks][i], acc[i][j], 0, 0, 0);
+      } else {
+#pragma unroll
+        for (int i = 0; i < 4; i++) af[0][i] = frag(sA, wm * 128 + i * 32, 0, lane);
+#pragma unroll
+        for (int j = 0; j < 2; j++) bfr[0][j] = frag(sB, wn * 64 + j * 32, 0, lane);
+        SB();
+#pragma unroll
+        for (int i = 0; i < 4; i++) af[1][i] = frag(sA, wm * 128 + i * 32, 1, lane);
+#pragma unroll
+        for (int j = 0; j < 2; j++) bfr[1][j] = frag(sB, wn * 64 + j * 32, 1, lane);
+        asm volatile("s_waitcnt lgkmcnt(6)" ::: "memory");
+        SB();
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+#pragma unroll
+          for (int j = 0; j < 2; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[0][j], af[0][i], acc[i][j], 0, 0, 0);
+        SB();
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+#pragma unroll
+          for (int j = 0; j < 2; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[1][j], af[1][i], acc[i][j], 0, 0, 0);
+      }
+      if (u + 3 < units) wait_vmcnt<8>(); else wait_vmcnt<0>();
+      BAR();
+    } else if (MODE == 3 || MODE == 6) {
+      // phase a
+      if (MODE == 3) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ks++) {
+#pragma unroll
+          for (int j = 0; j < 2; j++) bfr[ks][j] = frag(sB, wn * 64 + j * 32, ks, lane);
+#pragma unroll
+          for (int i = 0; i < 2; i++) af[ks][i] = frag(sA, wm * 128 + i * 32, ks, lane);
+        }
+      }
+      if (u + 2 < units) issue(u + 2, 2, 4);
+      BAR();
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int ks = 0; ks < 2; ks++)
+#pragma unroll
+        for (int i = 0; i < 2; i++)
+#pragma unroll
+          for (int j = 0; j < 2; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[ks][j], af[ks][i], acc[i][j], 0, 0, 0);
+      __builtin_amdgcn_s_setprio(0);
+      BAR();
+      if (MODE == 3) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ks++)
+#pragma unroll
+          for (int i = 0; i < 2; i++) af[ks][i] = frag(sA, wm * 128 + 64 + i * 32, ks, lane);
+      }
+      if (u + 3 < units) { issue(u + 3, 0, 2); wait_vmcnt<6>(); } else wait_vmcnt<0>();
+      BAR();
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int ks = 0; ks < 2; ks++)
+#pragma unroll
+        for (int i = 0; i < 2; i++)
+#pragma unroll
+          for (int j = 0; j < 2; j++) acc[2 + i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[ks][j], af[ks][i], acc[2 + i][j], 0, 0, 0);
+      __builtin_amdgcn_s_setprio(0);
+      BAR();
+    } else {                                           // MODE 4 / 5: one R and one M phase per unit
+#pragma unroll
+      for (int ks = 0; ks < 2; ks++) {
+#pragma unroll
+        for (int j = 0; j < 2; j++) bfr[ks][j] = frag(sB, wn * 64 + j * 32, ks, lane);
+#pragma unroll
+        for (int i = 0; i < 4; i++) af[ks][i] = frag(sA, wm * 128 + i * 32, ks, lane);
+      }
+      if (u + 3 < units) { issue(u + 3, 0, 4); wait_vmcnt<8>(); } else wait_vmcnt<0>();
+      BAR();
+      if (MODE == 4) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int ks = 0; ks < 2; ks++)
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+#pragma unroll
+          for (int j = 0; j < 2; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[ks][j], af[ks][i], acc[i][j], 0, 0, 0);
+      if (MODE == 4) __builtin_amdgcn_s_setprio(0);
+      BAR();
+    }
+  }
+  if (MODE >= 3 && !late) __builtin_amdgcn_s_barrier();
+  float s = 0;
+  for (int i = 0; i < 4; i++) for (int j = 0; j < 2; j++) for (int g = 0; g < 16; g++) s += acc[i][j][g];
+  if (s == 12345.678f) sink[0] = s;
+}
+static int g_iters = 5;
+template <int MODE>
+void run_sched(const char* A, const char* B, int M, int N, int K, float* sink) {
+  const int mt = M / 256, nt = N / 256, units = K / 32;
+  CK(hipFuncSetAttribute(reinterpret_cast<const void*>(sched_kernel<MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
+  hipEvent_t e0, e1;
+  CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  for (int it = 0; it < 2; it++) hipLaunchKernelGGL((sched_kernel<MODE>), dim3(mt * nt), dim3(512), 131072, 0, A, B, (long)K * 2, (long)K * 2, mt, nt, units, sink);
+  CK(hipEventRecord(e0));
+  const int iters = g_iters;
+  for (int it = 0; it < iters; it++) hipLaunchKernelGGL((sched_kernel<MODE>), dim3(mt * nt), dim3(512), 131072, 0, A, B, (long)K * 2, (long)K * 2, mt, nt, units, sink);
+  CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+  float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= iters;
+  printf("M=%d N=%d K=%d schedule MODE=%d : %7.3f ms  GEMM-equivalent %7.1f TF/s\n", M, N, K, MODE, ms, 2.0 * M * N * K / ms / 1e9);
+}
+
+int main(int argc, char** argv) {
+  if (argc > 1) g_iters = atoi(argv[1]);
+  const bool sched_only = argc > 2;
+  const int shapes[3][3] = {{65536, 1024, 4096}, {8192, 8192, 8192}, {65536, 4608, 1152}};
+  float* sink; CK(hipMalloc(&sink, 64)); CK(hipMemset(sink, 0, 64));
+  for (auto& sh : shapes) {
+    const int M = sh[0], N = sh[1], K = sh[2];
+    char *A, *B;
+    CK(hipMalloc(&A, (size_t)M * K * 2)); CK(hipMalloc(&B, (size_t)N * K * 2));
+    fill<<<4096, 256>>>((unsigned short*)A, (size_t)M * K); fill<<<4096, 256>>>((unsigned short*)B, (size_t)N * K);
+    if (!sched_only) {
+    run<64, 8, 0>(A, B, M, N, K, sink);
+    run<128, 8, 0>(A, B, M, N, K, sink);
+    run<256, 8, 0>(A, B, M, N, K, sink);
+    run<1024, 8, 0>(A, B, M, N, K, sink);
+    run<128, 4, 0>(A, B, M, N, K, sink);
+    run<1024, 4, 0>(A, B, M, N, K, sink);
+    run<64, 8, 16>(A, B, M, N, K, sink);
+    run<128, 8, 16>(A, B, M, N, K, sink);
+    run<1024, 8, 16>(A, B, M, N, K, sink);
+    run<128, 8, 32>(A, B, M, N, K, sink);
+    }
+    run_sched<1>(A, B, M, N, K, sink); run_sched<2>(A, B, M, N, K, sink); run_sched<3>(A, B, M, N, K, sink);
+    run_sched<4>(A, B, M, N, K, sink); run_sched<5>(A, B, M, N, K, sink); run_sched<6>(A, B, M, N, K, sink);
+    CK(hipFree(A)); CK(hipFree(B));
+  }
+  return 0;
+}

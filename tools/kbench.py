@@ -11,7 +11,7 @@ R = B * N
 dev = "cuda"
 
 
-def timed(fn, iters=5, warm=2):
+def timed(fn, iters=50, warm=5):      # short runs under-read by up to 20 % (clock ramp): keep >= 50 launches
     for _ in range(warm):
         fn()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -21,6 +21,9 @@ def timed(fn, iters=5, warm=2):
     e1.record()
     e1.synchronize()
     return e0.elapsed_time(e1) / iters * 1e-3
+
+
+LIBREF = bool(int(os.environ.get("KBENCH_LIBREF", "0")))
 
 
 def rb(*s):
@@ -38,6 +41,10 @@ def gemm():
         fl = 2.0 * R * n_out * k
         print(f"gemm NT {name:5s} M={R} N={n_out} K={k}: {t*1e3:7.3f} ms {fl/t/1e12:7.1f} TF/s")
         dy = rb(R, n_out)
+        if LIBREF:          # the vendor library (hipBLASLt through torch) on the same shapes: a yardstick for the report, never the product path
+            tl = [timed(lambda: torch.matmul(a, w.t(), out=out)), timed(lambda: torch.matmul(dy, w, out=torch.empty(R, k, dtype=torch.bfloat16, device=dev))),
+                  timed(lambda: torch.matmul(dy.t(), a))]
+            print("   hipBLASLt NT/NN/TN: " + " ".join(f"{fl/x/1e12:7.1f}" for x in tl) + " TF/s")
         dx = torch.empty(R, k, dtype=torch.bfloat16, device=dev)
         t = timed(lambda: ops.gemm(dy, w, ops.NN, out=dx))
         print(f"gemm NN {name:5s} (dX)                      : {t*1e3:7.3f} ms {fl/t/1e12:7.1f} TF/s")
@@ -58,8 +65,20 @@ def attn():
     print(f"attn fwd self : {t*1e3:7.3f} ms {fl/t/1e12:7.1f} TF/s")
     da, dqkv, delta = rb(R, D), torch.empty_like(qkv), torch.empty(B, H, N, device=dev)
     t = timed(lambda: ops.attention_bwd(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], a, da, lse, delta, dqkv[:, :D], dqkv[:, D:2 * D],
-                                        dqkv[:, 2 * D:], B, H, N, N, st, (s3, s3, s3)), iters=3)
+                                        dqkv[:, 2 * D:], B, H, N, N, st, (s3, s3, s3)))
     print(f"attn bwd self : {t*1e3:7.3f} ms {2.5*fl/t/1e12:7.1f} TF/s (algorithmic 2.5x fwd)")
+    if LIBREF:
+        import torch.nn.functional as F
+        q4, k4, v4 = (qkv[:, i * D:(i + 1) * D].reshape(B, N, H, 72).transpose(1, 2).contiguous().requires_grad_() for i in range(3))
+        try:
+            t = timed(lambda: F.scaled_dot_product_attention(q4, k4, v4))
+            print(f"   torch SDPA fwd: {t*1e3:7.3f} ms {fl/t/1e12:7.1f} TF/s")
+            o = F.scaled_dot_product_attention(q4, k4, v4)
+            g = torch.randn_like(o)
+            t = timed(lambda: torch.autograd.grad(o, (q4, k4, v4), g, retain_graph=True))
+            print(f"   torch SDPA bwd: {t*1e3:7.3f} ms {2.5*fl/t/1e12:7.1f} TF/s")
+        except Exception as e:
+            print("   torch SDPA unavailable:", repr(e)[:200])
     lens = [L] * B
     q = rb(R, D)
     kv = rb(sum(lens), 2 * D)
@@ -71,7 +90,7 @@ def attn():
     print(f"attn fwd cross: {t*1e3:7.3f} ms {flc/t/1e12:7.1f} TF/s")
     dq, dkv = torch.empty_like(q), torch.empty_like(kv)
     t = timed(lambda: ops.attention_bwd(q, kv[:, :D], kv[:, D:], a, da, lse, delta, dq, dkv[:, :D], dkv[:, D:], B, H, N, L, sc,
-                                        ((N * D, D, 72), (0, 2 * D, 72), (0, 2 * D, 72)), kv_start=ks, kv_len=kl, max_kv_len=L), iters=3)
+                                        ((N * D, D, 72), (0, 2 * D, 72), (0, 2 * D, 72)), kv_start=ks, kv_len=kl, max_kv_len=L))
     print(f"attn bwd cross: {t*1e3:7.3f} ms {2.5*flc/t/1e12:7.1f} TF/s")
 
 

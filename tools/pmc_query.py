@@ -1,20 +1,29 @@
-"""Summarise a rocprofv3 --pmc sqlite database: per-kernel mean of each counter."""
+"""Summarise a rocprofv3 --pmc sqlite database: per-kernel mean of each counter (+ launch geometry / registers / LDS).
+Usage: python tools/pmc_query.py <results.db> [name-regex]"""
 import re, sqlite3, sys
 db = sqlite3.connect(sys.argv[1])
+pat = re.compile(sys.argv[2] if len(sys.argv) > 2 else r"gemm|attn|ln_mod|gate|colsum|Cijk")
 cur = db.cursor()
 tabs = [r[0] for r in cur.execute("select name from sqlite_master where type in ('table','view')")]
 if "counters_collection" not in tabs:
     print("no counters_collection view; tables:", [t for t in tabs if "pmc" in t.lower() or "counter" in t.lower()])
     sys.exit(0)
-cols = [d[1] for d in cur.execute("pragma table_info(counters_collection)")]
 rows = cur.execute("select kernel_name, counter_name, avg(value), count(*) from counters_collection group by kernel_name, counter_name").fetchall()
+info = {}
+try:
+    for r in cur.execute("select name, avg(end-start), max(vgpr_count), max(accum_vgpr_count), max(lds_size), max(workgroup_size_x), max(grid_size_x), count(*) from kernels group by name"):
+        info[r[0]] = r[1:]
+except sqlite3.Error as e:
+    print("kernel info unavailable:", e)
 by = {}
 for k, c, v, n in rows:
-    k = re.sub(r"\(anonymous namespace\)::", "", k)[:70]
     by.setdefault(k, {})[c] = (v, n)
 for k, d in by.items():
-    if not any(s in k for s in ("gemm", "attn", "ln_mod", "gate", "colsum")):
+    if not pat.search(k):
         continue
-    print(k)
+    print(re.sub(r"\(anonymous namespace\)::", "", k)[:160])
+    if k in info:
+        i = info[k]
+        print(f"    avg_us={i[0]/1e3:.1f} vgpr={i[1]} agpr={i[2]} lds={i[3]} wg={i[4]} grid={i[5]} launches={i[6]}")
     for c, (v, n) in sorted(d.items()):
         print(f"    {c:32s} {v:16.1f}  (n={n})")
