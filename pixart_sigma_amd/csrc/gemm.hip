@@ -494,6 +494,35 @@ __device__ __forceinline__ void dma_tile_p(char* lds, const bf16_t* __restrict__
                                      (__attribute__((address_space(3))) void*)(lds + (i * NW + wave) * 1024), 16, 0, 0);
   }
 }
+// Same stream with running per-lane source pointers (the persistent kernel): dma_ptrs() gives the addresses of k-unit 0, every
+// issue afterwards costs one 64-bit add per instruction instead of re-deriving row * ld + k.
+template <bool KC, int ROWS, int NW, int BKT>
+__device__ __forceinline__ void dma_ptrs(const bf16_t* __restrict__ X, int ld, int r0, int R, int wave, int lane, const bf16_t* (&ptr)[ROWS * BKT * 2 / 1024 / NW]) {
+  constexpr int CPRK = BKT / 8, CPR = ROWS / 8, NINST = ROWS * BKT * 2 / 1024 / NW;
+#pragma unroll
+  for (int i = 0; i < NINST; i++) {
+    const int p = (i * NW + wave) * 64 + lane;
+    if (KC) {
+      const int row = p / CPRK, cl = p % CPRK;
+      const int c = CPRK == 8 ? (cl ^ ((row >> 1) & 7)) : (cl ^ ((row >> 2) & 3));
+      ptr[i] = X + (size_t)min(r0 + row, R - 1) * ld + c * 8;
+    } else {
+      const int kr = p / CPR, cl = p % CPR, c = ((((cl >> 2) ^ (kr & 3)) << 2) | (cl & 3));
+      int gc = r0 + c * 8;
+      gc = gc < R ? gc : 0;
+      ptr[i] = X + (size_t)kr * ld + gc;
+    }
+  }
+}
+template <int NW, int NINST>
+__device__ __forceinline__ void dma_issue(char* lds, const bf16_t* (&ptr)[NINST], long step, int wave) {
+#pragma unroll
+  for (int i = 0; i < NINST; i++) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)ptr[i],
+                                     (__attribute__((address_space(3))) void*)(lds + (i * NW + wave) * 1024), 16, 0, 0);
+    ptr[i] += step;
+  }
+}
 template <bool KC, int ROWS, int BKT>
 __device__ __forceinline__ bf16x8 frag_p(const char* lds, int rbase, int ks, int lane) {
   if (KC) {
@@ -505,6 +534,7 @@ __device__ __forceinline__ bf16x8 frag_p(const char* lds, int rbase, int ks, int
     return frag_g<false, ROWS>(lds, rbase, ks, lane);
   }
 }
+template <int V> struct IntC { static constexpr int value = V; };
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 __device__ __forceinline__ void wait_vm_upto(int n) {      // n (wave-uniform) in {0, 2, 4, 6}: LDS-DMA instructions that may stay in flight
@@ -551,10 +581,21 @@ __global__ __launch_bounds__(512) void gemm_pers_kernel(GemmParams p) {
   int L = blockIdx.x;
   tile_coords(L, mt, nt, 1, tm_, tn_, z_);
   int m0 = tm_ * TBM, n0 = tn_ * TBN;
-  auto issueA = [&](int u) { dma_tile_p<A_KC, TBM, NW, BKT>(smem + (u & 3) * UNIT, p.A, p.lda, m0, p.M, u * BKT, wave, lane); };
-  auto issueB = [&](int u) { dma_tile_p<B_KC, TBN, NW, BKT>(smem + (u & 3) * UNIT + A_BYTES, p.B, p.ldb, n0, p.N, u * BKT, wave, lane); };
-  issueA(0); issueB(0); issueA(1); issueB(1);
-  if (nk > 2) issueA(2);
+  // running source pointers of this wave's 2 + 2 DMA instructions per k-unit, and their per-unit stride (elements)
+  const bf16_t* pa[2];
+  const bf16_t* pb[2];
+  const long stepA = A_KC ? BKT : (long)BKT * p.lda, stepB = B_KC ? BKT : (long)BKT * p.ldb;
+  int ia = 0, ib = 0;                                  // ring slots of the next A / B part to issue
+  auto issueA = [&]() { dma_issue<NW, 2>(smem + ia * UNIT, pa, stepA, wave); ia = (ia + 1) & 3; };
+  auto issueB = [&]() { dma_issue<NW, 2>(smem + ib * UNIT + A_BYTES, pb, stepB, wave); ib = (ib + 1) & 3; };
+  auto prefetch = [&]() {                              // units 0, 1 and the A part of unit 2 of the tile at (m0, n0)
+    dma_ptrs<A_KC, TBM, NW, BKT>(p.A, p.lda, m0, p.M, wave, lane, pa);
+    dma_ptrs<B_KC, TBN, NW, BKT>(p.B, p.ldb, n0, p.N, wave, lane, pb);
+    ia = ib = 0;
+    issueA(); issueB(); issueA(); issueB();
+    if (nk > 2) issueA();
+  };
+  prefetch();
 
   while (true) {
     f32x16 acc[TM][TN];
@@ -567,7 +608,9 @@ __global__ __launch_bounds__(512) void gemm_pers_kernel(GemmParams p) {
     wait_vmcnt<0>();                                   // this tile's first units have landed; last tile's stores are out
     __builtin_amdgcn_s_barrier();
     if (late) __builtin_amdgcn_s_barrier();            // stagger the second wave of each SIMD by one barrier interval
-    for (int t = 0; t < nk; t++) {
+    // one k-unit; REM = units that follow it (3 = steady state: both DMA halves issued, 6 instructions left in flight)
+    auto unit = [&](int t, auto rem_c) {
+      constexpr int REM = decltype(rem_c)::value;
       const char* sA = smem + (t & 3) * UNIT;
       const char* sB = sA + A_BYTES;
       bf16x8 af[2][2], bf[2][TN];
@@ -580,7 +623,7 @@ __global__ __launch_bounds__(512) void gemm_pers_kernel(GemmParams p) {
       for (int ks = 0; ks < 2; ks++)
 #pragma unroll
         for (int i = 0; i < 2; i++) af[ks][i] = frag_p<A_KC, TBM, BKT>(sA, wm * 128 + i * 32, ks, lane);
-      if (t + 2 < nk) issueB(t + 2);
+      if (REM >= 2) issueB();                          // B part of unit t+2
       PXA_SB(); __builtin_amdgcn_s_barrier(); PXA_SB();
       __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -596,8 +639,10 @@ __global__ __launch_bounds__(512) void gemm_pers_kernel(GemmParams p) {
       for (int ks = 0; ks < 2; ks++)
 #pragma unroll
         for (int i = 0; i < 2; i++) af[ks][i] = frag_p<A_KC, TBM, BKT>(sA, wm * 128 + 64 + i * 32, ks, lane);
-      if (t + 3 < nk) issueA(t + 3);
-      if (t + 1 < nk) wait_vm_upto((t + 2 < nk ? 4 : 0) + (t + 3 < nk ? 2 : 0));
+      if (REM >= 3) issueA();                          // A part of unit t+3
+      if (REM >= 3) wait_vmcnt<6>();                   // unit t+1 landed; t+2 and half of t+3 stay in flight
+      else if (REM == 2) wait_vmcnt<4>();
+      else if (REM == 1) wait_vmcnt<0>();
       PXA_SB(); __builtin_amdgcn_s_barrier(); PXA_SB();
       __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -608,7 +653,12 @@ __global__ __launch_bounds__(512) void gemm_pers_kernel(GemmParams p) {
           for (int j = 0; j < TN; j++) acc[2 + i][j] = mfma32(bf[ks][j], af[ks][i], acc[2 + i][j]);
       __builtin_amdgcn_s_setprio(0);
       PXA_SB(); __builtin_amdgcn_s_barrier(); PXA_SB();
-    }
+    };
+    int t = 0;
+    for (; t < nk - 3; t++) unit(t, IntC<3>{});
+    if (nk >= 3) unit(t++, IntC<2>{});
+    unit(t++, IntC<1>{});
+    unit(t++, IntC<0>{});
     if (!late) __builtin_amdgcn_s_barrier();           // every wave has executed the same number of barriers; the ring is idle
 
     // ---- hand-over: prefetch the next tile's first units, then this tile's epilogue
@@ -618,8 +668,7 @@ __global__ __launch_bounds__(512) void gemm_pers_kernel(GemmParams p) {
     if (more) {
       tile_coords(L, mt, nt, 1, tm_, tn_, z_);
       m0 = tm_ * TBM; n0 = tn_ * TBN;
-      issueA(0); issueB(0); issueA(1); issueB(1);
-      if (nk > 2) issueA(2);
+      prefetch();
     }
     const bool dual = (p.act == 1 && p.out2 != nullptr);
     float4 bq[TN][4];                                  // bias for this lane's 4-column groups

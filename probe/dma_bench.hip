@@ -261,7 +261,10 @@ int main(int argc, char** argv) {
   const bool sched_only = argc > 2;
   const int shapes[3][3] = {{65536, 1024, 4096}, {8192, 8192, 8192}, {65536, 4608, 1152}};
   float* sink; CK(hipMalloc(&sink, 64)); CK(hipMemset(sink, 0, 64));
+  const int only = argc > 3 ? atoi(argv[3]) : -1;
+  int si = -1;
   for (auto& sh : shapes) {
+    if (++si != only && only >= 0) continue;
     const int M = sh[0], N = sh[1], K = sh[2];
     char *A, *B;
     CK(hipMalloc(&A, (size_t)M * K * 2)); CK(hipMalloc(&B, (size_t)N * K * 2));
