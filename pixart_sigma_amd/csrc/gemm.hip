@@ -565,15 +565,43 @@ __device__ __forceinline__ void wait_vm_upto(int n) {      // n (wave-uniform) i
 // 32 rows at a time through its private staging slice into full-row 16-byte stores - which are fire-and-forget - and waits once
 // (vmcnt(0): its stores and the prefetched units) before the next main loop.  Store drain and operand latency of consecutive
 // tiles overlap; bias / GELU / GELU' / second (pre-activation) output / bias-gradient column sums all ride in that epilogue.
-template <int LAYOUT>
+// Geometry: TBM x TBN block tile (TBM / 64 even), 8 waves as 2 (m) x 4 (n), wave tile (TBM/2) x (TBN/4); instantiated at 256 x 256.
+// (A 192 x 384 tile - same 128 FLOP per operand byte, divides every DiT width so N = 1152 would not waste 10 % of a 256-wide
+// tiling - was measured 5-20 % SLOWER: 144 accumulators leave the epilogue spilling and its phases must split k, not rows.)
+// A k-unit is (TBM + TBN) / 16 one-KiB DMA pieces (A rows first, then B); wave w owns pieces w, w + 8, ...: the first two are
+// issued in phase b of unit u - 3, the rest in phase a of unit u - 2.
+template <bool KC, int ROWS, int BKT>
+__device__ __forceinline__ const bf16_t* piece_ptr(const bf16_t* __restrict__ X, int ld, int r0, int R, int q) {   // q: 16-byte chunk index in the LDS image
+  if constexpr (KC) {
+    static_assert(BKT == 32, "k-contiguous image: 64-byte rows");
+    const int row = q >> 2, c = (q & 3) ^ ((row >> 2) & 3);
+    return X + (size_t)min(r0 + row, R - 1) * ld + c * 8;
+  } else {
+    constexpr int CPR = ROWS / 8;
+    static_assert(ROWS % 128 == 0, "k-strided image: the 64-byte block XOR needs 4 | blocks per row");
+    const int kr = q / CPR, cl = q % CPR, c = ((((cl >> 2) ^ (kr & 3)) << 2) | (cl & 3));
+    int gc = r0 + c * 8;
+    gc = gc < R ? gc : 0;
+    return X + (size_t)kr * ld + gc;
+  }
+}
+
+template <int LAYOUT, int TBM, int TBN>
 __global__ __launch_bounds__(512) void gemm_pers_kernel(GemmParams p) {
   constexpr bool A_KC = (LAYOUT != 2), B_KC = (LAYOUT == 0);
-  constexpr int TBM = 256, TBN = 256, WN = 4, NW = 8, TM = 4, TN = 2, BKT = 32;
-  constexpr int A_BYTES = TBM * BKT * 2, B_BYTES = TBN * BKT * 2, UNIT = A_BYTES + B_BYTES;
+  constexpr int WN = 4, NW = 8, TM = TBM / 64, TN = TBN / 128, BKT = 32;
+  static_assert(TM % 2 == 0, "the two phases of a k-unit split the wave's row tiles");
+  constexpr int PA = TBM / 16, PB = TBN / 16, NPIECE = PA + PB;      // 1 KiB DMA pieces per k-unit
+  constexpr int NP_LO = NPIECE / NW, NP_X = NPIECE % NW, NPMAX = NP_LO + (NP_X ? 1 : 0), H1 = 2;
+  constexpr int A_BYTES = PA * 1024, UNIT = NPIECE * 1024;
+  static_assert(NP_LO > H1, "piece split");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), wm = wave / WN, wn = wave % WN, hi = lane >> 5;
-  const bool late = wave >= NW / 2;
-  char* stg = smem + 4 * UNIT + wave * 4096;           // this wave's 32 rows x 128 B staging slice
+  const bool late = wave >= NW / 2, extra = wave < NP_X;
+  // epilogue staging: 4 KiB per wave inside ring slot 3, which the next tile's prefetch (slots 0, 1 and part of 2) leaves alone
+  // until every wave has passed the barrier that opens the next main loop
+  char* stg = smem + 3 * UNIT + wave * 4096;
+  static_assert(8 * 4096 <= UNIT, "staging must fit one ring slot");
   const int mt = (p.M + TBM - 1) / TBM, nt = (p.N + TBN - 1) / TBN, T = mt * nt;
   const int nk = p.K / BKT;                            // >= 2 (K is a multiple of 64 on this path)
 
@@ -581,19 +609,39 @@ __global__ __launch_bounds__(512) void gemm_pers_kernel(GemmParams p) {
   int L = blockIdx.x;
   tile_coords(L, mt, nt, 1, tm_, tn_, z_);
   int m0 = tm_ * TBM, n0 = tn_ * TBN;
-  // running source pointers of this wave's 2 + 2 DMA instructions per k-unit, and their per-unit stride (elements)
-  const bf16_t* pa[2];
-  const bf16_t* pb[2];
+  // running source pointers of this wave's DMA pieces and their per-unit strides (elements)
+  const bf16_t* pp[NPMAX];
+  long st[NPMAX];
   const long stepA = A_KC ? BKT : (long)BKT * p.lda, stepB = B_KC ? BKT : (long)BKT * p.ldb;
-  int ia = 0, ib = 0;                                  // ring slots of the next A / B part to issue
-  auto issueA = [&]() { dma_issue<NW, 2>(smem + ia * UNIT, pa, stepA, wave); ia = (ia + 1) & 3; };
-  auto issueB = [&]() { dma_issue<NW, 2>(smem + ib * UNIT + A_BYTES, pb, stepB, wave); ib = (ib + 1) & 3; };
-  auto prefetch = [&]() {                              // units 0, 1 and the A part of unit 2 of the tile at (m0, n0)
-    dma_ptrs<A_KC, TBM, NW, BKT>(p.A, p.lda, m0, p.M, wave, lane, pa);
-    dma_ptrs<B_KC, TBN, NW, BKT>(p.B, p.ldb, n0, p.N, wave, lane, pb);
-    ia = ib = 0;
-    issueA(); issueB(); issueA(); issueB();
-    if (nk > 2) issueA();
+#pragma unroll
+  for (int i = 0; i < NPMAX; i++) st[i] = (wave + NW * i < PA) ? stepA : stepB;
+  int s_lo = 0, s_hi = 0;                              // ring slots of the next first-half / second-half issue
+  auto piece = [&](int i, int slot) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)pp[i],
+                                     (__attribute__((address_space(3))) void*)(smem + slot * UNIT + (wave + NW * i) * 1024), 16, 0, 0);
+    pp[i] += st[i];
+  };
+  auto issue_lo = [&]() {
+#pragma unroll
+    for (int i = 0; i < H1; i++) piece(i, s_lo);
+    s_lo = (s_lo + 1) & 3;
+  };
+  auto issue_hi = [&]() {
+#pragma unroll
+    for (int i = H1; i < NP_LO; i++) piece(i, s_hi);
+    if (NP_X && extra) piece(NPMAX - 1, s_hi);
+    s_hi = (s_hi + 1) & 3;
+  };
+  auto prefetch = [&]() {                              // units 0, 1 and the first half of unit 2 of the tile at (m0, n0)
+#pragma unroll
+    for (int i = 0; i < NPMAX; i++) {
+      const int pc = wave + NW * i;
+      if (pc < PA) pp[i] = piece_ptr<A_KC, TBM, BKT>(p.A, p.lda, m0, p.M, pc * 64 + lane);
+      else if (pc < NPIECE) pp[i] = piece_ptr<B_KC, TBN, BKT>(p.B, p.ldb, n0, p.N, (pc - PA) * 64 + lane);
+    }
+    s_lo = s_hi = 0;
+    issue_lo(); issue_hi(); issue_lo(); issue_hi();
+    if (nk > 2) issue_lo();
   };
   prefetch();
 
@@ -608,51 +656,45 @@ __global__ __launch_bounds__(512) void gemm_pers_kernel(GemmParams p) {
     wait_vmcnt<0>();                                   // this tile's first units have landed; last tile's stores are out
     __builtin_amdgcn_s_barrier();
     if (late) __builtin_amdgcn_s_barrier();            // stagger the second wave of each SIMD by one barrier interval
-    // one k-unit; REM = units that follow it (3 = steady state: both DMA halves issued, 6 instructions left in flight)
+    // one k-unit = two phases (k-sub-steps); REM = units that follow it (3 = steady state)
     auto unit = [&](int t, auto rem_c) {
       constexpr int REM = decltype(rem_c)::value;
       const char* sA = smem + (t & 3) * UNIT;
       const char* sB = sA + A_BYTES;
-      bf16x8 af[2][2], bf[2][TN];
-      // ---- phase a: rows 0..63 of the wave's 128 x all 64 columns
+      auto rest_a = [&]() { if (REM >= 2) issue_hi(); };           // phase a: rest of unit t+2
+      auto rest_b = [&]() {                                          // phase b: first pieces of unit t+3, then the counted wait
+        if (REM >= 3) issue_lo();
+        if (REM >= 3) { if (NP_X && extra) wait_vmcnt<NP_LO + 1 + H1>(); else wait_vmcnt<NP_LO + H1>(); }   // unit t+1 landed
+        else if (REM == 2) { if (NP_X && extra) wait_vmcnt<NP_LO + 1>(); else wait_vmcnt<NP_LO>(); }
+        else if (REM == 1) wait_vmcnt<0>();
+      };
+      {
+        // phases split the wave's rows: a = upper half x all columns (B fragments stay in registers for b = lower half)
+        constexpr int TH = TM / 2;
+        bf16x8 af[2][TH], bf[2][TN];
 #pragma unroll
-      for (int ks = 0; ks < 2; ks++)
+        for (int ks = 0; ks < 2; ks++)
 #pragma unroll
-        for (int j = 0; j < TN; j++) bf[ks][j] = frag_p<B_KC, TBN, BKT>(sB, wn * 64 + j * 32, ks, lane);
+          for (int j = 0; j < TN; j++) bf[ks][j] = frag_p<B_KC, TBN, BKT>(sB, wn * (TN * 32) + j * 32, ks, lane);
 #pragma unroll
-      for (int ks = 0; ks < 2; ks++)
+        for (int h = 0; h < 2; h++) {
 #pragma unroll
-        for (int i = 0; i < 2; i++) af[ks][i] = frag_p<A_KC, TBM, BKT>(sA, wm * 128 + i * 32, ks, lane);
-      if (REM >= 2) issueB();                          // B part of unit t+2
-      PXA_SB(); __builtin_amdgcn_s_barrier(); PXA_SB();
-      __builtin_amdgcn_s_setprio(1);
+          for (int ks = 0; ks < 2; ks++)
 #pragma unroll
-      for (int ks = 0; ks < 2; ks++)
+            for (int i = 0; i < TH; i++) af[ks][i] = frag_p<A_KC, TBM, BKT>(sA, wm * (TM * 32) + (h * TH + i) * 32, ks, lane);
+          if (h == 0) rest_a(); else rest_b();
+          PXA_SB(); __builtin_amdgcn_s_barrier(); PXA_SB();
+          __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-        for (int i = 0; i < 2; i++)
+          for (int ks = 0; ks < 2; ks++)
 #pragma unroll
-          for (int j = 0; j < TN; j++) acc[i][j] = mfma32(bf[ks][j], af[ks][i], acc[i][j]);
-      __builtin_amdgcn_s_setprio(0);
-      PXA_SB(); __builtin_amdgcn_s_barrier(); PXA_SB();
-      // ---- phase b: rows 64..127 (the B fragments stay in registers)
+            for (int i = 0; i < TH; i++)
 #pragma unroll
-      for (int ks = 0; ks < 2; ks++)
-#pragma unroll
-        for (int i = 0; i < 2; i++) af[ks][i] = frag_p<A_KC, TBM, BKT>(sA, wm * 128 + 64 + i * 32, ks, lane);
-      if (REM >= 3) issueA();                          // A part of unit t+3
-      if (REM >= 3) wait_vmcnt<6>();                   // unit t+1 landed; t+2 and half of t+3 stay in flight
-      else if (REM == 2) wait_vmcnt<4>();
-      else if (REM == 1) wait_vmcnt<0>();
-      PXA_SB(); __builtin_amdgcn_s_barrier(); PXA_SB();
-      __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-      for (int ks = 0; ks < 2; ks++)
-#pragma unroll
-        for (int i = 0; i < 2; i++)
-#pragma unroll
-          for (int j = 0; j < TN; j++) acc[2 + i][j] = mfma32(bf[ks][j], af[ks][i], acc[2 + i][j]);
-      __builtin_amdgcn_s_setprio(0);
-      PXA_SB(); __builtin_amdgcn_s_barrier(); PXA_SB();
+              for (int j = 0; j < TN; j++) acc[h * TH + i][j] = mfma32(bf[ks][j], af[ks][i], acc[h * TH + i][j]);
+          __builtin_amdgcn_s_setprio(0);
+          PXA_SB(); __builtin_amdgcn_s_barrier(); PXA_SB();
+        }
+      }
     };
     int t = 0;
     for (; t < nk - 3; t++) unit(t, IntC<3>{});
@@ -662,7 +704,7 @@ __global__ __launch_bounds__(512) void gemm_pers_kernel(GemmParams p) {
     if (!late) __builtin_amdgcn_s_barrier();           // every wave has executed the same number of barriers; the ring is idle
 
     // ---- hand-over: prefetch the next tile's first units, then this tile's epilogue
-    const int mw = m0 + wm * 128, nw = n0 + wn * 64;   // this wave's output origin (current tile)
+    const int mw = m0 + wm * (TM * 32), nw = n0 + wn * (TN * 32);   // this wave's output origin (current tile)
     L += gridDim.x;
     const bool more = L < T;
     if (more) {
@@ -671,101 +713,115 @@ __global__ __launch_bounds__(512) void gemm_pers_kernel(GemmParams p) {
       prefetch();
     }
     const bool dual = (p.act == 1 && p.out2 != nullptr);
-    float4 bq[TN][4];                                  // bias for this lane's 4-column groups
+    const int srow = lane & 31;
+    // one column group of JW 32-wide tiles (JW = 2: 128-byte staging rows, 8 rows per store; JW = 1: 64-byte rows, 16 per store)
+    auto emit = [&](int j0, auto jw_c) {
+      constexpr int JW = decltype(jw_c)::value, RB = JW * 64;
+      // bias goes into the accumulators first, unconditionally (zero when absent), so nothing extra stays live across the row loop
 #pragma unroll
-    for (int j = 0; j < TN; j++)
+      for (int jj = 0; jj < JW; jj++)
 #pragma unroll
-      for (int q = 0; q < 4; q++) {
-        const int n = nw + j * 32 + 8 * q + 4 * hi;
-        bq[j][q] = (p.bias && n < p.N) ? *reinterpret_cast<const float4*>(p.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
-      }
-    float cs[TN][16];
+        for (int q = 0; q < 4; q++) {
+          const int n = nw + (j0 + jj) * 32 + 8 * q + 4 * hi;
+          const float4 b4 = (p.bias && n < p.N) ? *reinterpret_cast<const float4*>(p.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-    for (int j = 0; j < TN; j++)
+          for (int i = 0; i < TM; i++) { acc[i][j0 + jj][q * 4] += b4.x; acc[i][j0 + jj][q * 4 + 1] += b4.y; acc[i][j0 + jj][q * 4 + 2] += b4.z; acc[i][j0 + jj][q * 4 + 3] += b4.w; }
+        }
+      float cs[JW][16];
 #pragma unroll
-      for (int g = 0; g < 16; g++) cs[j][g] = 0.f;
+      for (int jj = 0; jj < JW; jj++)
 #pragma unroll
-    for (int i = 0; i < TM; i++) {
-      const int m = mw + i * 32 + (lane & 31);
-      uint2 ax[TN][4];
-      if (p.act == 2) {                                // GELU' needs the saved pre-activation: fetch the slice's values up front
+        for (int g = 0; g < 16; g++) cs[jj][g] = 0.f;
 #pragma unroll
-        for (int j = 0; j < TN; j++)
+      for (int i = 0; i < TM; i++) {
+        const int m = mw + i * 32 + srow;
+        uint2 ax[JW][4];
+        if (p.act == 2) {                              // GELU' needs the saved pre-activation
 #pragma unroll
-          for (int q = 0; q < 4; q++) {
-            const int n = nw + j * 32 + 8 * q + 4 * hi;
-            ax[j][q] = (m < p.M && n < p.N) ? *reinterpret_cast<const uint2*>(p.aux + (size_t)m * p.ldaux + n) : make_uint2(0u, 0u);
-          }
-      }
+          for (int jj = 0; jj < JW; jj++)
 #pragma unroll
-      for (int pass = 0; pass < 2; pass++) {           // pass 0: pre-activation copy (dual output only); pass 1: final values
-        if (pass == 0 && !dual) continue;
-#pragma unroll
-        for (int j = 0; j < TN; j++)
-#pragma unroll
-          for (int q = 0; q < 4; q++) {
-            float v[4] = {acc[i][j][q * 4] + bq[j][q].x, acc[i][j][q * 4 + 1] + bq[j][q].y, acc[i][j][q * 4 + 2] + bq[j][q].z, acc[i][j][q * 4 + 3] + bq[j][q].w};
-            if (pass == 1) {
-              if (p.act == 1) {
-#pragma unroll
-                for (int e = 0; e < 4; e++) v[e] = gelu_tanh(v[e]);
-              } else if (p.act == 2) {
-                float a0, a1, a2, a3;
-                unpack_bf16x2(ax[j][q].x, a0, a1); unpack_bf16x2(ax[j][q].y, a2, a3);
-                v[0] *= gelu_tanh_grad(a0); v[1] *= gelu_tanh_grad(a1); v[2] *= gelu_tanh_grad(a2); v[3] *= gelu_tanh_grad(a3);
-              }
-              if (p.colsum && m < p.M) {
-#pragma unroll
-                for (int e = 0; e < 4; e++) cs[j][q * 4 + e] += v[e];
-              }
+            for (int q = 0; q < 4; q++) {
+              const int n = nw + (j0 + jj) * 32 + 8 * q + 4 * hi;
+              ax[jj][q] = (m < p.M && n < p.N) ? *reinterpret_cast<const uint2*>(p.aux + (size_t)m * p.ldaux + n) : make_uint2(0u, 0u);
             }
-            const int col = j * 32 + 8 * q + 4 * hi;
-            *reinterpret_cast<uint2*>(stg + (lane & 31) * 128 + (((col >> 3) ^ (lane & 7)) << 4) + (col & 4) * 2) = pack_bf16x4(v[0], v[1], v[2], v[3]);
+        }
+#pragma unroll
+        for (int pass = 0; pass < 2; pass++) {         // pass 0: pre-activation copy (dual output only); pass 1: final values
+          if (pass == 0 && !dual) continue;
+#pragma unroll
+          for (int jj = 0; jj < JW; jj++)
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+              const int j = j0 + jj;
+              float v[4] = {acc[i][j][q * 4], acc[i][j][q * 4 + 1], acc[i][j][q * 4 + 2], acc[i][j][q * 4 + 3]};
+              if (pass == 1) {
+                if (p.act == 1) {
+#pragma unroll
+                  for (int e = 0; e < 4; e++) v[e] = gelu_tanh(v[e]);
+                } else if (p.act == 2) {
+                  float a0, a1, a2, a3;
+                  unpack_bf16x2(ax[jj][q].x, a0, a1); unpack_bf16x2(ax[jj][q].y, a2, a3);
+                  v[0] *= gelu_tanh_grad(a0); v[1] *= gelu_tanh_grad(a1); v[2] *= gelu_tanh_grad(a2); v[3] *= gelu_tanh_grad(a3);
+                }
+                if (p.colsum && m < p.M) {
+#pragma unroll
+                  for (int e = 0; e < 4; e++) cs[jj][q * 4 + e] += v[e];
+                }
+              }
+              const int ch = jj * 4 + q;               // 16-byte chunk of the staging row
+              const int sw = JW == 2 ? (srow & 7) : ((srow >> 1) & 3);
+              *reinterpret_cast<uint2*>(stg + srow * RB + ((ch ^ sw) << 4) + hi * 8) = pack_bf16x4(v[0], v[1], v[2], v[3]);
+            }
+          __builtin_amdgcn_s_waitcnt(0xc07f);          // lgkmcnt(0): the slice is private to this wave
+          bf16_t* dst = pass == 0 ? p.out2 : p.out;
+#pragma unroll
+          for (int t4 = 0; t4 < 4 / (3 - JW) ; t4++) {  // JW = 2: 4 x (8 rows x 128 B); JW = 1: 2 x (16 rows x 64 B)
+            constexpr int LPR = JW * 4, RPI = 64 / LPR;
+            const int row = t4 * RPI + lane / LPR, ch = lane % LPR;
+            const int sw = JW == 2 ? (row & 7) : ((row >> 1) & 3);
+            const uint4 v4 = *reinterpret_cast<const uint4*>(stg + row * RB + ((ch ^ sw) << 4));
+            const int mm = mw + i * 32 + row, nn = nw + j0 * 32 + ch * 8;
+            if (mm < p.M && nn < p.N) *reinterpret_cast<uint4*>(dst + (size_t)mm * p.ldo + nn) = v4;
           }
-        __builtin_amdgcn_s_waitcnt(0xc07f);            // lgkmcnt(0): the slice is private to this wave
-        bf16_t* dst = pass == 0 ? p.out2 : p.out;
-#pragma unroll
-        for (int t4 = 0; t4 < 4; t4++) {               // 8 rows x 128 B per store instruction
-          const int row = t4 * 8 + (lane >> 3), ch = lane & 7;
-          const uint4 v4 = *reinterpret_cast<const uint4*>(stg + row * 128 + ((ch ^ (row & 7)) << 4));
-          const int mm = mw + i * 32 + row, nn = nw + ch * 8;
-          if (mm < p.M && nn < p.N) *reinterpret_cast<uint4*>(dst + (size_t)mm * p.ldo + nn) = v4;
+          __builtin_amdgcn_s_waitcnt(0xc07f);          // reads returned before the slice is overwritten
         }
-        __builtin_amdgcn_s_waitcnt(0xc07f);            // reads returned before the slice is overwritten
       }
-    }
-    if (p.colsum) {                                    // column sums over this wave's rows: lane tree, one atomic per column and slot
+      if (p.colsum) {                                  // column sums over this wave's rows: lane tree, one atomic per column and slot
 #pragma unroll
-      for (int j = 0; j < TN; j++)
+        for (int jj = 0; jj < JW; jj++)
 #pragma unroll
-        for (int g = 0; g < 16; g++) {
-          float v = cs[j][g];
-          v += __shfl_xor(v, 16); v += __shfl_xor(v, 8); v += __shfl_xor(v, 4); v += __shfl_xor(v, 2); v += __shfl_xor(v, 1);
-          const int n = nw + j * 32 + 8 * (g >> 2) + 4 * hi + (g & 3);
-          if ((lane & 31) == 0 && n < p.N) atomicAdd(p.colsum + (size_t)((mw >> 7) % PXA_COLSUM_SLOTS) * p.colsum_stride + n, v);
-        }
-    }
+          for (int g = 0; g < 16; g++) {
+            float v = cs[jj][g];
+            v += __shfl_xor(v, 16); v += __shfl_xor(v, 8); v += __shfl_xor(v, 4); v += __shfl_xor(v, 2); v += __shfl_xor(v, 1);
+            const int n = nw + (j0 + jj) * 32 + 8 * (g >> 2) + 4 * hi + (g & 3);
+            if (srow == 0 && n < p.N) atomicAdd(p.colsum + (size_t)((mw >> 7) % PXA_COLSUM_SLOTS) * p.colsum_stride + n, v);
+          }
+      }
+    };
+#pragma unroll
+    for (int j0 = 0; j0 + 1 < TN; j0 += 2) emit(j0, IntC<2>{});
+    if (TN % 2) emit(TN - 1, IntC<1>{});
     if (!more) break;
   }
 }
 
-template <int LAYOUT>
+template <int LAYOUT, int TBM, int TBN>
 int launch_pers(GemmParams p, hipStream_t s) {
   p.split = 1;
-  constexpr int LDSP = 4 * 32768 + 8 * 4096;           // 160 KiB: one workgroup per CU
+  constexpr int LDSP = 4 * (TBM + TBN) * 64;           // the ring: 128 KiB (256 x 256) / 144 KiB (192 x 384): one workgroup per CU
   static bool attr_set_pp = false;
   static int n_cu = 0;
   if (!attr_set_pp) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_pers_kernel<LAYOUT>), hipFuncAttributeMaxDynamicSharedMemorySize, LDSP);
-    if (e != hipSuccess) { pxa_set_error("hipFuncSetAttribute(gemm_pers<%d>): %s", LAYOUT, hipGetErrorString(e)); return -3; }
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_pers_kernel<LAYOUT, TBM, TBN>), hipFuncAttributeMaxDynamicSharedMemorySize, LDSP);
+    if (e != hipSuccess) { pxa_set_error("hipFuncSetAttribute(gemm_pers<%d,%d,%d>): %s", LAYOUT, TBM, TBN, hipGetErrorString(e)); return -3; }
     int dev = 0;
     hipDeviceProp_t prop;
     if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) { pxa_set_error("gemm_pers: device query failed"); return -3; }
     n_cu = prop.multiProcessorCount;
     attr_set_pp = true;
   }
-  const int tiles = ((p.M + 255) / 256) * ((p.N + 255) / 256);
-  hipLaunchKernelGGL((gemm_pers_kernel<LAYOUT>), dim3(tiles < n_cu ? tiles : n_cu), dim3(512), LDSP, s, p);
+  const int tiles = ((p.M + TBM - 1) / TBM) * ((p.N + TBN - 1) / TBN);
+  hipLaunchKernelGGL((gemm_pers_kernel<LAYOUT, TBM, TBN>), dim3(tiles < n_cu ? tiles : n_cu), dim3(512), LDSP, s, p);
   PXA_LAUNCH_CHECK();
   return 0;
 }
@@ -793,7 +849,9 @@ int launch_glds(GemmParams p, int split, hipStream_t s) {
   static const bool no_stage = getenv("PXA_GEMM_NO_STAGED_EPILOGUE") != nullptr;
   const bool dual = (p.act == 1 && p.out2 != nullptr);   // two LDS trips: measured slower than the direct epilogue
   static const bool no_pers = getenv("PXA_GEMM_NO_PERSISTENT") != nullptr;
-  if (LAYOUT != 2 && TBM == 256 && TBN == 256 && split == 1 && p.out && !p.outf && !no_pers) return launch_pers<LAYOUT == 2 ? 0 : LAYOUT>(p, s);
+  if (LAYOUT != 2 && TBM == 256 && TBN == 256 && split == 1 && p.out && !p.outf && !no_pers) {
+    return launch_pers<LAYOUT == 2 ? 0 : LAYOUT, 256, 256>(p, s);
+  }
   if (LAYOUT != 2 && p.out && !p.outf && !dual && !no_stage) return launch_glds_e<LAYOUT, TBM, TBN, WM, WN, 1>(p, split, s);
   if (p.colsum) {                                         // not fused on this path: separate column-sum pass over the output
     float* cs = p.colsum;
