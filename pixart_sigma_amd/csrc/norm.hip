@@ -81,10 +81,20 @@ __global__ __launch_bounds__(256) void ln_mod_bwd_kernel(
     const bf16_t* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ rstd,
     const float* __restrict__ scale, int mod_stride, const float* dx_in, float* dx_out, bf16_t* __restrict__ dx_bf16,
     float* __restrict__ dshift, float* __restrict__ dscale, int dmod_stride, int R, int D, int rows_per_batch) {
+  // Per-sample column sums (dshift / dscale): every 16-row chunk used to fire 72 global atomics per lane at the SAME 2 x D words
+  // of its sample - ~1000 serialised read-modify-writes per cache line and call.  When the block's 128 rows belong to one sample
+  // (always, unless a sample's token count is not a multiple of 128) the 8 half-waves first combine in LDS, then the block adds
+  // once: 8x fewer, fully coalesced atomics.
+  extern __shared__ float red[];                       // [2][D]
   const int hl = threadIdx.x & 31;
   const int chunk = blockIdx.x * 8 + (threadIdx.x >> 5);
   const int r_beg = chunk * BWD_ROWS, r_end = min(R, r_beg + BWD_ROWS);
-  if (r_beg >= R) return;
+  const int blk_first = blockIdx.x * 8 * BWD_ROWS, blk_last = min(R, blk_first + 8 * BWD_ROWS) - 1;
+  const bool one_sample = (blk_first / rows_per_batch) == (blk_last / rows_per_batch);   // block-uniform
+  if (one_sample) {
+    for (int i = threadIdx.x; i < 2 * D; i += 256) red[i] = 0.f;
+    __syncthreads();
+  }
   float4 ash[NV], asc[NV];
 #pragma unroll
   for (int j = 0; j < NV; j++) { ash[j] = make_float4(0, 0, 0, 0); asc[j] = make_float4(0, 0, 0, 0); }
@@ -93,8 +103,8 @@ __global__ __launch_bounds__(256) void ln_mod_bwd_kernel(
 #pragma unroll
     for (int j = 0; j < NV; j++) {
       const int c = (hl + 32 * j) * 4;
-      float* ps = dshift + (size_t)b * dmod_stride + c;
-      float* pc = dscale + (size_t)b * dmod_stride + c;
+      float* ps = one_sample ? red + c : dshift + (size_t)b * dmod_stride + c;
+      float* pc = one_sample ? red + D + c : dscale + (size_t)b * dmod_stride + c;
       atomicAdd(ps + 0, ash[j].x); atomicAdd(ps + 1, ash[j].y); atomicAdd(ps + 2, ash[j].z); atomicAdd(ps + 3, ash[j].w);
       atomicAdd(pc + 0, asc[j].x); atomicAdd(pc + 1, asc[j].y); atomicAdd(pc + 2, asc[j].z); atomicAdd(pc + 3, asc[j].w);
       ash[j] = make_float4(0, 0, 0, 0); asc[j] = make_float4(0, 0, 0, 0);
@@ -136,7 +146,15 @@ __global__ __launch_bounds__(256) void ln_mod_bwd_kernel(
       if (dx_bf16) *reinterpret_cast<uint2*>(dx_bf16 + base + c) = pack_bf16x4(o.x, o.y, o.z, o.w);
     }
   }
-  flush(cur_b);
+  if (r_beg < R) flush(cur_b);
+  if (one_sample) {
+    __syncthreads();
+    const int b = blk_first / rows_per_batch;
+    for (int i = threadIdx.x; i < D; i += 256) {
+      atomicAdd(dshift + (size_t)b * dmod_stride + i, red[i]);
+      atomicAdd(dscale + (size_t)b * dmod_stride + i, red[D + i]);
+    }
+  }
 }
 
 template <int NV>
@@ -144,10 +162,16 @@ __global__ __launch_bounds__(256) void gate_bwd_kernel(
     const float* dx, const bf16_t* __restrict__ add, const bf16_t* __restrict__ u, const float* __restrict__ gate,
     int mod_stride, float* dx_out, bf16_t* __restrict__ du, float* __restrict__ dgate, int dmod_stride, float* __restrict__ dbias,
     long dbias_stride, int R, int D, int rows_per_batch) {
+  extern __shared__ float red[];                       // [2][D]: block-level combine of the column sums (see ln_mod_bwd_kernel)
   const int hl = threadIdx.x & 31;
   const int chunk = blockIdx.x * 8 + (threadIdx.x >> 5);
   const int r_beg = chunk * BWD_ROWS, r_end = min(R, r_beg + BWD_ROWS);
-  if (r_beg >= R) return;
+  const int blk_first = blockIdx.x * 8 * BWD_ROWS, blk_last = min(R, blk_first + 8 * BWD_ROWS) - 1;
+  const bool one_sample = (blk_first / rows_per_batch) == (blk_last / rows_per_batch);   // block-uniform
+  if (one_sample) {
+    for (int i = threadIdx.x; i < 2 * D; i += 256) red[i] = 0.f;
+    __syncthreads();
+  }
   float4 ag[NV], ab[NV];
 #pragma unroll
   for (int j = 0; j < NV; j++) { ag[j] = make_float4(0, 0, 0, 0); ab[j] = make_float4(0, 0, 0, 0); }
@@ -156,7 +180,7 @@ __global__ __launch_bounds__(256) void gate_bwd_kernel(
     if (dgate) {
 #pragma unroll
       for (int j = 0; j < NV; j++) {
-        float* pg = dgate + (size_t)b * dmod_stride + (hl + 32 * j) * 4;
+        float* pg = one_sample ? red + (hl + 32 * j) * 4 : dgate + (size_t)b * dmod_stride + (hl + 32 * j) * 4;
         atomicAdd(pg + 0, ag[j].x); atomicAdd(pg + 1, ag[j].y); atomicAdd(pg + 2, ag[j].z); atomicAdd(pg + 3, ag[j].w);
         ag[j] = make_float4(0, 0, 0, 0);
       }
@@ -164,7 +188,7 @@ __global__ __launch_bounds__(256) void gate_bwd_kernel(
     if (dbias) {   // partial slot b % PXA_COLSUM_SLOTS: bounds same-address atomic contention exactly like the per-sample dgate
 #pragma unroll
       for (int j = 0; j < NV; j++) {
-        float* pb = dbias + (size_t)(b % PXA_COLSUM_SLOTS) * dbias_stride + (hl + 32 * j) * 4;
+        float* pb = one_sample ? red + D + (hl + 32 * j) * 4 : dbias + (size_t)(b % PXA_COLSUM_SLOTS) * dbias_stride + (hl + 32 * j) * 4;
         atomicAdd(pb + 0, ab[j].x); atomicAdd(pb + 1, ab[j].y); atomicAdd(pb + 2, ab[j].z); atomicAdd(pb + 3, ab[j].w);
         ab[j] = make_float4(0, 0, 0, 0);
       }
@@ -198,7 +222,15 @@ __global__ __launch_bounds__(256) void gate_bwd_kernel(
       ab[j].x += o.x; ab[j].y += o.y; ab[j].z += o.z; ab[j].w += o.w;
     }
   }
-  flush(cur_b);
+  if (r_beg < R) flush(cur_b);
+  if (one_sample) {
+    __syncthreads();
+    const int b = blk_first / rows_per_batch;
+    for (int i = threadIdx.x; i < D; i += 256) {
+      if (dgate) atomicAdd(dgate + (size_t)b * dmod_stride + i, red[i]);
+      if (dbias) atomicAdd(dbias + (size_t)(b % PXA_COLSUM_SLOTS) * dbias_stride + i, red[D + i]);
+    }
+  }
 }
 
 // db[n] += sum_r dY[r][n].  Block = 64 column-threads (8 columns = one 16-byte load each, 512 columns) x 4 row-lanes over
@@ -265,7 +297,7 @@ extern "C" int pxa_ln_mod_bwd(const void* dy_bf16, const float* x, const float* 
   PXA_CHECK(dy_bf16 && x && mean && rstd && scale && dx_out && dshift && dscale, "pxa_ln_mod_bwd: null pointer");
   PXA_CHECK(R > 0 && D % 128 == 0 && rows_per_batch > 0, "pxa_ln_mod_bwd: bad shape");
   const int chunks = (R + BWD_ROWS - 1) / BWD_ROWS;
-  DISPATCH_NV(D, hipLaunchKernelGGL(ln_mod_bwd_kernel<NV>, dim3((chunks + 7) / 8), dim3(256), 0, stream, (const bf16_t*)dy_bf16, x, mean, rstd,
+  DISPATCH_NV(D, hipLaunchKernelGGL(ln_mod_bwd_kernel<NV>, dim3((chunks + 7) / 8), dim3(256), 2 * D * sizeof(float), stream, (const bf16_t*)dy_bf16, x, mean, rstd,
                                      scale, mod_stride, dx_in, dx_out, (bf16_t*)dx_bf16, dshift, dscale, dmod_stride, R, D, rows_per_batch));
   PXA_LAUNCH_CHECK();
   return 0;
@@ -277,7 +309,7 @@ extern "C" int pxa_gate_bwd(const float* dx, const void* add_bf16, const void* u
   PXA_CHECK(dx && R > 0 && D % 128 == 0 && rows_per_batch > 0, "pxa_gate_bwd: bad args");
   PXA_CHECK(!gate || (u_bf16 && dgate), "pxa_gate_bwd: gate needs u and dgate");
   const int chunks = (R + BWD_ROWS - 1) / BWD_ROWS;
-  DISPATCH_NV(D, hipLaunchKernelGGL(gate_bwd_kernel<NV>, dim3((chunks + 7) / 8), dim3(256), 0, stream, dx, (const bf16_t*)add_bf16,
+  DISPATCH_NV(D, hipLaunchKernelGGL(gate_bwd_kernel<NV>, dim3((chunks + 7) / 8), dim3(256), 2 * D * sizeof(float), stream, dx, (const bf16_t*)add_bf16,
                                      (const bf16_t*)u_bf16, gate, mod_stride, dx_out, (bf16_t*)du_bf16, dgate, dmod_stride, dbias, dbias_stride, R, D, rows_per_batch));
   PXA_LAUNCH_CHECK();
   return 0;

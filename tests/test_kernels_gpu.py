@@ -121,8 +121,9 @@ def test_ln_mod_fwd_variants(ops):
     assert rel_l2(x2, x + u.float()) < 1e-6 and r["xn"] is None
 
 
-def test_ln_mod_bwd(ops):
-    B, N, D = 2, 40, 1152  # 40 rows/sample: chunks of 16 rows straddle the sample boundary
+@pytest.mark.parametrize("B,N", [(2, 40), (2, 256), (3, 128)])   # 40: 16-row chunks straddle samples (direct atomics); others: LDS block combine
+def test_ln_mod_bwd(ops, B, N):
+    D = 1152
     R = B * N
     x, mod, dy, dxin = rnd(R, D, seed=1), _mod(B, D, 2), bf(rnd(R, D, seed=3)), rnd(R, D, seed=4)
     shift, scale = mod[:, 0], mod[:, 1]
@@ -139,8 +140,9 @@ def test_ln_mod_bwd(ops):
     assert dmod[:, 2:].abs().max() == 0
 
 
-def test_gate_bwd_and_colsum(ops):
-    B, N, D = 2, 40, 1152
+@pytest.mark.parametrize("B,N", [(2, 40), (2, 256), (3, 128)])
+def test_gate_bwd_and_colsum(ops, B, N):
+    D = 1152
     R = B * N
     dx, add, u, mod = rnd(R, D, seed=1), bf(rnd(R, D, seed=2)), bf(rnd(R, D, seed=3)), _mod(B, D, 4)
     gate = mod[:, 2]
