@@ -602,13 +602,14 @@ __global__ __launch_bounds__(512) void gemm_pers_kernel(GemmParams p) {
   // until every wave has passed the barrier that opens the next main loop
   char* stg = smem + 3 * UNIT + wave * 4096;
   static_assert(8 * 4096 <= UNIT, "staging must fit one ring slot");
-  const int mt = (p.M + TBM - 1) / TBM, nt = (p.N + TBN - 1) / TBN, T = mt * nt;
-  const int nk = p.K / BKT;                            // >= 2 (K is a multiple of 64 on this path)
+  // work items: output tile x k-slice (split-K only for the fp32 weight-gradient layout), walked in the XCD-aware order
+  const int mt = (p.M + TBM - 1) / TBM, nt = (p.N + TBN - 1) / TBN, T = mt * nt * p.split;
+  auto units_of = [&](int z) { return (min(p.K, (z + 1) * p.k_per_split) - z * p.k_per_split) / BKT; };   // >= 2: k ranges are multiples of 64
 
   int tm_, tn_, z_;
   int L = blockIdx.x;
-  tile_coords(L, mt, nt, 1, tm_, tn_, z_);
-  int m0 = tm_ * TBM, n0 = tn_ * TBN;
+  tile_coords(L, mt, nt, p.split, tm_, tn_, z_);
+  int m0 = tm_ * TBM, n0 = tn_ * TBN, nk = units_of(z_), nk_pf = nk;   // nk_pf: units of the item being prefetched
   // running source pointers of this wave's DMA pieces and their per-unit strides (elements)
   const bf16_t* pp[NPMAX];
   long st[NPMAX];
@@ -636,12 +637,13 @@ __global__ __launch_bounds__(512) void gemm_pers_kernel(GemmParams p) {
 #pragma unroll
     for (int i = 0; i < NPMAX; i++) {
       const int pc = wave + NW * i;
-      if (pc < PA) pp[i] = piece_ptr<A_KC, TBM, BKT>(p.A, p.lda, m0, p.M, pc * 64 + lane);
-      else if (pc < NPIECE) pp[i] = piece_ptr<B_KC, TBN, BKT>(p.B, p.ldb, n0, p.N, (pc - PA) * 64 + lane);
+      const long k0 = (long)z_ * p.k_per_split;
+      if (pc < PA) pp[i] = piece_ptr<A_KC, TBM, BKT>(p.A, p.lda, m0, p.M, pc * 64 + lane) + (A_KC ? k0 : k0 * p.lda);
+      else if (pc < NPIECE) pp[i] = piece_ptr<B_KC, TBN, BKT>(p.B, p.ldb, n0, p.N, (pc - PA) * 64 + lane) + (B_KC ? k0 : k0 * p.ldb);
     }
     s_lo = s_hi = 0;
     issue_lo(); issue_hi(); issue_lo(); issue_hi();
-    if (nk > 2) issue_lo();
+    if (nk_pf > 2) issue_lo();
   };
   prefetch();
 
@@ -705,15 +707,50 @@ __global__ __launch_bounds__(512) void gemm_pers_kernel(GemmParams p) {
 
     // ---- hand-over: prefetch the next tile's first units, then this tile's epilogue
     const int mw = m0 + wm * (TM * 32), nw = n0 + wn * (TN * 32);   // this wave's output origin (current tile)
+    const int zw = z_;                                  // this item's k-slice (fp32 slab index)
     L += gridDim.x;
     const bool more = L < T;
     if (more) {
-      tile_coords(L, mt, nt, 1, tm_, tn_, z_);
-      m0 = tm_ * TBM; n0 = tn_ * TBN;
+      tile_coords(L, mt, nt, p.split, tm_, tn_, z_);
+      m0 = tm_ * TBM; n0 = tn_ * TBN; nk_pf = units_of(z_);
       prefetch();
     }
-    const bool dual = (p.act == 1 && p.out2 != nullptr);
     const int srow = lane & 31;
+    if constexpr (LAYOUT == 2) {
+      // fp32 weight-gradient tile: each 32 x 32 accumulator tile is parked in the wave's staging slice (128-byte rows, 16-byte
+      // chunk XOR (row & 7)) and leaves as full 128-byte row segments: split-K slab store, read-modify-write into the gradient
+      // (single k-slice: this workgroup owns the element) or plain store
+#pragma unroll
+      for (int i = 0; i < TM; i++)
+#pragma unroll
+        for (int j = 0; j < TN; j++) {
+#pragma unroll
+          for (int q = 0; q < 4; q++)
+            *reinterpret_cast<float4*>(stg + srow * 128 + (((q * 2 + hi) ^ (srow & 7)) << 4)) =
+                make_float4(acc[i][j][q * 4], acc[i][j][q * 4 + 1], acc[i][j][q * 4 + 2], acc[i][j][q * 4 + 3]);
+          __builtin_amdgcn_s_waitcnt(0xc07f);
+#pragma unroll
+          for (int t4 = 0; t4 < 4; t4++) {
+            const int row = t4 * 8 + (lane >> 3), ch = lane & 7;
+            float4 v = *reinterpret_cast<const float4*>(stg + row * 128 + ((ch ^ (row & 7)) << 4));
+            const int mm = mw + i * 32 + row, nn = nw + j * 32 + ch * 4;
+            if (mm < p.M && nn < p.N) {
+              if (p.accumulate == 3) {
+                *reinterpret_cast<float4*>(p.slab + ((size_t)zw * p.M + mm) * p.N + nn) = v;
+              } else {
+                float* dst = p.outf + (size_t)mm * p.ldf + nn;
+                if (p.accumulate) { const float4 o = *reinterpret_cast<const float4*>(dst); v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
+                *reinterpret_cast<float4*>(dst) = v;
+              }
+            }
+          }
+          __builtin_amdgcn_s_waitcnt(0xc07f);
+        }
+      nk = nk_pf;
+      if (!more) break;
+      continue;
+    }
+    const bool dual = (p.act == 1 && p.out2 != nullptr);
     // one column group of JW 32-wide tiles (JW = 2: 128-byte staging rows, 8 rows per store; JW = 1: 64-byte rows, 16 per store)
     auto emit = [&](int j0, auto jw_c) {
       constexpr int JW = decltype(jw_c)::value, RB = JW * 64;
@@ -801,13 +838,14 @@ __global__ __launch_bounds__(512) void gemm_pers_kernel(GemmParams p) {
 #pragma unroll
     for (int j0 = 0; j0 + 1 < TN; j0 += 2) emit(j0, IntC<2>{});
     if (TN % 2) emit(TN - 1, IntC<1>{});
+    nk = nk_pf;
     if (!more) break;
   }
 }
 
 template <int LAYOUT, int TBM, int TBN>
-int launch_pers(GemmParams p, hipStream_t s) {
-  p.split = 1;
+int launch_pers(GemmParams p, int split, hipStream_t s) {
+  p.split = split;
   constexpr int LDSP = 4 * (TBM + TBN) * 64;           // the ring: 128 KiB (256 x 256) / 144 KiB (192 x 384): one workgroup per CU
   static bool attr_set_pp = false;
   static int n_cu = 0;
@@ -820,7 +858,7 @@ int launch_pers(GemmParams p, hipStream_t s) {
     n_cu = prop.multiProcessorCount;
     attr_set_pp = true;
   }
-  const int tiles = ((p.M + TBM - 1) / TBM) * ((p.N + TBN - 1) / TBN);
+  const int tiles = ((p.M + TBM - 1) / TBM) * ((p.N + TBN - 1) / TBN) * split;
   hipLaunchKernelGGL((gemm_pers_kernel<LAYOUT, TBM, TBN>), dim3(tiles < n_cu ? tiles : n_cu), dim3(512), LDSP, s, p);
   PXA_LAUNCH_CHECK();
   return 0;
@@ -850,8 +888,11 @@ int launch_glds(GemmParams p, int split, hipStream_t s) {
   const bool dual = (p.act == 1 && p.out2 != nullptr);   // two LDS trips: measured slower than the direct epilogue
   static const bool no_pers = getenv("PXA_GEMM_NO_PERSISTENT") != nullptr;
   if (LAYOUT != 2 && TBM == 256 && TBN == 256 && split == 1 && p.out && !p.outf && !no_pers) {
-    return launch_pers<LAYOUT == 2 ? 0 : LAYOUT, 256, 256>(p, s);
+    return launch_pers<LAYOUT == 2 ? 0 : LAYOUT, 256, 256>(p, 1, s);
   }
+  // fp32 weight gradients (TN, split-K slabs / single-slice read-modify-write / plain store): the same persistent kernel
+  if (LAYOUT == 2 && TBM == 256 && TBN == 256 && p.outf && !p.out && !p.bias && p.act == 0 && p.accumulate != 1 && !p.colsum && !no_pers)
+    return launch_pers<2, 256, 256>(p, split, s);
   if (LAYOUT != 2 && p.out && !p.outf && !dual && !no_stage) return launch_glds_e<LAYOUT, TBM, TBN, WM, WN, 1>(p, split, s);
   if (p.colsum) {                                         // not fused on this path: separate column-sum pass over the output
     float* cs = p.colsum;
@@ -935,17 +976,19 @@ extern "C" int pxa_gemm(const pxa_gemm_args* a, hipStream_t stream) {
   if (a->split_k == 0 && a->out_f32 && a->accumulate && !a->out_bf16 && a->act == 0 && !a->bias && a->K % BK == 0) {
     // Split-K weight-gradient GEMMs (K = tokens, 65536): a handful of long-running workgroups, so wave quantisation against the
     // 256 CUs decides the time.  Pick (tile, split) minimising  rounds x k-tiles x tile cost  + atomic epilogue traffic.
-    struct Cfg { int tile, bm, bn, slots; double eff; };
-    const Cfg cfgs[3] = {{128, 128, 128, 512, 1.0}, {-256, 256, 128, 256, 1.0}, {256, 256, 256, 256, 1.15}};
+    // Candidates: 128 x 128 tiles, two workgroups per CU (512 slots, ~800 TF/s when full) and the persistent 256 x 256 kernel
+    // (256 slots, ~1000 TF/s when full).  time = rounds x k-range x tile FLOPs / per-slot rate  +  slab write + read + reduce.
+    struct Cfg { int tile, bm, bn, slots; double rate; };
+    const Cfg cfgs[2] = {{128, 128, 128, 512, 800e12}, {256, 256, 256, 256, 1000e12}};
     double best = 1e30;
     for (const Cfg& c : cfgs) {
+      if (c.tile == 256 && (a->M < 256 || a->N < 256)) continue;
       const long tiles = (long)((a->M + c.bm - 1) / c.bm) * ((a->N + c.bn - 1) / c.bn);
       for (int sp = 1; sp <= 16; sp++) {
         const int kp = ((a->K + sp - 1) / sp + BK - 1) / BK * BK;
         if ((long)kp * (sp - 1) >= a->K) continue;               // would leave an empty split
         const long rounds = (tiles * sp + c.slots - 1) / c.slots;
-        const double per_cu = (double)c.bm * c.bn * (512.0 / c.slots) / c.eff;   // work a CU carries per k-step and round
-        const double t = rounds * (double)kp * per_cu * 2.0 / (750e12 / 256.0) + (double)sp * a->M * a->N / 300e9;
+        const double t = rounds * (double)kp * c.bm * c.bn * 2.0 / (c.rate / c.slots) + (sp > 1 ? 2.0 * sp * a->M * a->N * 4.0 / 3.5e12 + 4e-6 : 0.0);
         if (t < best) { best = t; split = sp; p.tile_hint = c.tile; }
       }
     }
