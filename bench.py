@@ -52,7 +52,8 @@ def timed(fn, iters, warm=2):
 
 
 def kernel_rooflines(B, N):
-    """Live per-kernel measurements (events on the stream the kernels are launched on = torch's current stream)."""
+    """Live per-kernel measurements (events on the stream the kernels are launched on = torch's current stream).
+    >= 15-40 launches each: runs of a few launches under-read by up to 20 % on this part (clock ramp)."""
     from pixart_sigma_amd import ops
     dev = "cuda"
     R = B * N
@@ -61,26 +62,30 @@ def kernel_rooflines(B, N):
     b1 = torch.zeros(DFF, device=dev)
     out, out2 = torch.empty(R, DFF, dtype=torch.bfloat16, device=dev), torch.empty(R, DFF, dtype=torch.bfloat16, device=dev)
     res = {}
-    t = timed(lambda: ops.gemm(x, w1, ops.NT, bias=b1, act=ops.ACT_GELU, out=out, out2=out2), 10)
+    t = timed(lambda: ops.gemm(x, w1, ops.NT, bias=b1, act=ops.ACT_GELU, out=out, out2=out2), 40, warm=5)
     res["gemm_nt_fc1_gelu"] = dict(flops=2.0 * R * DFF * D, seconds=t)
     dy = torch.randn(R, DFF, device=dev).to(torch.bfloat16)
     dxo = torch.empty(R, D, dtype=torch.bfloat16, device=dev)
-    t = timed(lambda: ops.gemm(dy, w1, ops.NN, out=dxo), 10)
+    t = timed(lambda: ops.gemm(dy, w1, ops.NN, out=dxo), 40, warm=5)
     res["gemm_nn_fc1_dx"] = dict(flops=2.0 * R * DFF * D, seconds=t)
     dw = torch.zeros(DFF, D, device=dev)
-    t = timed(lambda: ops.gemm(dy, x, ops.TN, out_f32=dw, accumulate=True, split_k=2), 5)
+    t = timed(lambda: ops.gemm(dy, x, ops.TN, out_f32=dw, accumulate=True, split_k=0), 40, warm=5)
     res["gemm_tn_fc1_dw"] = dict(flops=2.0 * R * DFF * D, seconds=t)
     qkv = torch.randn(R, 3 * D, device=dev).to(torch.bfloat16)
     a = torch.empty(R, D, dtype=torch.bfloat16, device=dev)
     lse = torch.empty(B, H, N, device=dev)
     s3 = (N * 3 * D, 3 * D, 72)
     st = (s3, s3, s3, (N * D, D, 72))
-    t = timed(lambda: ops.attention_fwd(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], a, lse, B, H, N, N, st), 5)
+    t = timed(lambda: ops.attention_fwd(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], a, lse, B, H, N, N, st), 30, warm=5)
     res["attn_fwd_self"] = dict(flops=4.0 * B * N * N * D, seconds=t)
     da, dqkv, delta = torch.randn(R, D, device=dev).to(torch.bfloat16), torch.empty_like(qkv), torch.empty(B, H, N, device=dev)
     t = timed(lambda: ops.attention_bwd(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], a, da, lse, delta, dqkv[:, :D], dqkv[:, D:2 * D],
-                                        dqkv[:, 2 * D:], B, H, N, N, st, (s3, s3, s3)), 3)
-    res["attn_bwd_self"] = dict(flops=10.0 * B * N * N * D, seconds=t)
+                                        dqkv[:, 2 * D:], B, H, N, N, st, (s3, s3, s3)), 15, warm=3)
+    res["attn_bwd_self"] = dict(flops=10.0 * B * N * N * D, seconds=t)     # delta + dQ + dK/dV kernels, algorithmic 2.5x forward
+    t_dq = timed(lambda: ops.attention_bwd(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], a, da, lse, delta, dqkv[:, :D], None, None,
+                                           B, H, N, N, st, (s3, s3, s3)), 15, warm=3)
+    # the dK/dV kernel alone (full backward minus the delta + dQ launches): its contract needs S, dP, dV, dK = 4 of the 2 N^2 d products
+    res["attn_bwd_dkv_kernel"] = dict(flops=8.0 * B * N * N * D, seconds=t - t_dq)
     for k, v in res.items():
         v["tflops"] = v["flops"] / v["seconds"] / 1e12
         v["frac"] = v["flops"] / v["seconds"] / MFMA_PEAK
@@ -203,9 +208,13 @@ def main():
                 "frac": flops_step / sec_per_step / MFMA_PEAK, "traffic": None, "scope": "whole training step (algorithmic FLOPs / wall time)"}
         if not a.no_kernel_roofline and a.image_size == 1024:
             ks = kernel_rooflines(B, N)
-            dom = max(ks, key=lambda k: ks[k]["seconds"] * {"gemm_nt_fc1_gelu": 1, "gemm_nn_fc1_dx": 1, "gemm_tn_fc1_dw": 1, "attn_fwd_self": 1, "attn_bwd_self": 1}[k])
-            roof["kernels"] = {k: {"TFLOP/s": round(v["tflops"], 1), "frac": round(v["frac"], 4), "ms": round(v["seconds"] * 1e3, 3)} for k, v in ks.items()}
-            roof["dominant_kernel"] = dom
+            # dominant kernel of the step by total time (profiles/: attn_bwd_dkv_kernel, 56 launches, ~17 % of the step)
+            dom = ks["attn_bwd_dkv_kernel"]
+            roof = {"bound": "mfma", "kernel": "attn_bwd_dkv_kernel (self-attention, B16 H16 N4096 d72)", "achieved": dom["tflops"], "peak": MFMA_PEAK / 1e12,
+                    "unit": "TFLOP/s", "frac": dom["frac"], "traffic": None, "flops_per_launch": dom["flops"], "ms_per_launch": dom["seconds"] * 1e3,
+                    "step": {"achieved": flops_step / sec_per_step / 1e12, "frac": flops_step / sec_per_step / MFMA_PEAK,
+                             "scope": "whole training step (algorithmic FLOPs / wall time)"},
+                    "kernels": {k: {"TFLOP/s": round(v["tflops"], 1), "frac": round(v["frac"], 4), "ms": round(v["seconds"] * 1e3, 3)} for k, v in ks.items()}}
         out["roofline"] = roof
         if not a.no_cpu_baseline:
             cdt, cflops, cores, desc = cpu_baseline()

@@ -109,6 +109,7 @@ typedef struct {
   long colsum_stride;
 } pxa_attn_args;
 int pxa_attn_fwd(const pxa_attn_args* args, hipStream_t stream);
+/* backward: delta pre-pass, then the dQ kernel (skipped when dq == NULL) and the dK/dV kernel (skipped when dk == dv == NULL) */
 int pxa_attn_bwd(const pxa_attn_args* args, hipStream_t stream);
 
 /* ---------------------------------------------------------------------------------------------- token boundary

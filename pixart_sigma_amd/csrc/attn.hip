@@ -532,17 +532,22 @@ extern "C" int pxa_attn_fwd(const pxa_attn_args* a, hipStream_t stream) {
 extern "C" int pxa_attn_bwd(const pxa_attn_args* a, hipStream_t stream) {
   AttnParams p;
   if (int rc = fill(p, a)) return rc;
-  PXA_CHECK(p.Q && p.K && p.V && p.O && p.dO && p.dQ && p.dK && p.dV && p.LSE && a->delta, "pxa_attn_bwd: null tensor");
+  PXA_CHECK(p.Q && p.K && p.V && p.O && p.dO && p.LSE && a->delta, "pxa_attn_bwd: null tensor");
+  PXA_CHECK((p.dQ || p.dK) && (!p.dK == !p.dV), "pxa_attn_bwd: need dq and/or both of dk, dv (a NULL gradient skips the kernel that produces it)");
   for (long s : {p.dq_ts, p.dk_ts, p.dv_ts, (long)p.dq_hs, (long)p.dk_hs, (long)p.dv_hs, p.dq_bs, p.dk_bs, p.dv_bs})
     PXA_CHECK(s % 4 == 0, "pxa_attn_bwd: gradient strides must be multiples of 4 elements");
   const long total = (long)p.B * p.Nq * p.H;
   hipLaunchKernelGGL(attn_delta_kernel, dim3((total + 255) / 256), dim3(256), 0, stream, p.O, p.dO, a->delta,
                      p.o_bs, p.o_ts, p.o_hs, p.o_bs, p.o_ts, p.o_hs, p.B, p.H, p.Nq);
   PXA_LAUNCH_CHECK();
-  hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3((p.Nq + 127) / 128, p.H, p.B), dim3(256), 0, stream, p);
-  PXA_LAUNCH_CHECK();
-  const int max_k = a->max_kv_len > 0 ? a->max_kv_len : p.Nk;
-  hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3((max_k + 127) / 128, p.H, p.B), dim3(256), 0, stream, p);
-  PXA_LAUNCH_CHECK();
+  if (p.dQ) {
+    hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3((p.Nq + 127) / 128, p.H, p.B), dim3(256), 0, stream, p);
+    PXA_LAUNCH_CHECK();
+  }
+  if (p.dK) {
+    const int max_k = a->max_kv_len > 0 ? a->max_kv_len : p.Nk;
+    hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3((max_k + 127) / 128, p.H, p.B), dim3(256), 0, stream, p);
+    PXA_LAUNCH_CHECK();
+  }
   return 0;
 }

@@ -586,7 +586,10 @@ __device__ __forceinline__ const bf16_t* piece_ptr(const bf16_t* __restrict__ X,
   }
 }
 
-template <int LAYOUT, int TBM, int TBN>
+// EPI (bf16 epilogue flavour, compiled separately so that none carries the others' registers - the epilogue runs with all
+// 128 accumulators live and spills at the slightest extra state): 0 = (+bias), 1 = bias + GELU with the pre-activation as a
+// second output, 2 = x GELU'(aux) + bias-gradient column sums, 3 = everything decided at run time.
+template <int LAYOUT, int TBM, int TBN, int EPI>
 __global__ __launch_bounds__(512) void gemm_pers_kernel(GemmParams p) {
   constexpr bool A_KC = (LAYOUT != 2), B_KC = (LAYOUT == 0);
   constexpr int WN = 4, NW = 8, TM = TBM / 64, TN = TBN / 128, BKT = 32;
@@ -750,7 +753,9 @@ __global__ __launch_bounds__(512) void gemm_pers_kernel(GemmParams p) {
       if (!more) break;
       continue;
     }
-    const bool dual = (p.act == 1 && p.out2 != nullptr);
+    const int act = EPI == 0 ? 0 : EPI == 1 ? 1 : EPI == 2 ? 2 : p.act;
+    const bool dual = EPI == 1 || (EPI == 3 && p.act == 1 && p.out2 != nullptr);
+    const bool want_cs = EPI == 2 || (EPI == 3 && p.colsum != nullptr);
     // one column group of JW 32-wide tiles (JW = 2: 128-byte staging rows, 8 rows per store; JW = 1: 64-byte rows, 16 per store)
     auto emit = [&](int j0, auto jw_c) {
       constexpr int JW = decltype(jw_c)::value, RB = JW * 64;
@@ -773,7 +778,7 @@ __global__ __launch_bounds__(512) void gemm_pers_kernel(GemmParams p) {
       for (int i = 0; i < TM; i++) {
         const int m = mw + i * 32 + srow;
         uint2 ax[JW][4];
-        if (p.act == 2) {                              // GELU' needs the saved pre-activation
+        if (act == 2) {                                // GELU' needs the saved pre-activation
 #pragma unroll
           for (int jj = 0; jj < JW; jj++)
 #pragma unroll
@@ -792,15 +797,15 @@ __global__ __launch_bounds__(512) void gemm_pers_kernel(GemmParams p) {
               const int j = j0 + jj;
               float v[4] = {acc[i][j][q * 4], acc[i][j][q * 4 + 1], acc[i][j][q * 4 + 2], acc[i][j][q * 4 + 3]};
               if (pass == 1) {
-                if (p.act == 1) {
+                if (act == 1) {
 #pragma unroll
                   for (int e = 0; e < 4; e++) v[e] = gelu_tanh(v[e]);
-                } else if (p.act == 2) {
+                } else if (act == 2) {
                   float a0, a1, a2, a3;
                   unpack_bf16x2(ax[jj][q].x, a0, a1); unpack_bf16x2(ax[jj][q].y, a2, a3);
                   v[0] *= gelu_tanh_grad(a0); v[1] *= gelu_tanh_grad(a1); v[2] *= gelu_tanh_grad(a2); v[3] *= gelu_tanh_grad(a3);
                 }
-                if (p.colsum && m < p.M) {
+                if (want_cs && m < p.M) {
 #pragma unroll
                   for (int e = 0; e < 4; e++) cs[jj][q * 4 + e] += v[e];
                 }
@@ -823,7 +828,7 @@ __global__ __launch_bounds__(512) void gemm_pers_kernel(GemmParams p) {
           __builtin_amdgcn_s_waitcnt(0xc07f);          // reads returned before the slice is overwritten
         }
       }
-      if (p.colsum) {                                  // column sums over this wave's rows: lane tree, one atomic per column and slot
+      if (want_cs) {                                   // column sums over this wave's rows: lane tree, one atomic per column and slot
 #pragma unroll
         for (int jj = 0; jj < JW; jj++)
 #pragma unroll
@@ -843,14 +848,14 @@ __global__ __launch_bounds__(512) void gemm_pers_kernel(GemmParams p) {
   }
 }
 
-template <int LAYOUT, int TBM, int TBN>
+template <int LAYOUT, int TBM, int TBN, int EPI>
 int launch_pers(GemmParams p, int split, hipStream_t s) {
   p.split = split;
   constexpr int LDSP = 4 * (TBM + TBN) * 64;           // the ring: 128 KiB (256 x 256) / 144 KiB (192 x 384): one workgroup per CU
   static bool attr_set_pp = false;
   static int n_cu = 0;
   if (!attr_set_pp) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_pers_kernel<LAYOUT, TBM, TBN>), hipFuncAttributeMaxDynamicSharedMemorySize, LDSP);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_pers_kernel<LAYOUT, TBM, TBN, EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, LDSP);
     if (e != hipSuccess) { pxa_set_error("hipFuncSetAttribute(gemm_pers<%d,%d,%d>): %s", LAYOUT, TBM, TBN, hipGetErrorString(e)); return -3; }
     int dev = 0;
     hipDeviceProp_t prop;
@@ -859,7 +864,7 @@ int launch_pers(GemmParams p, int split, hipStream_t s) {
     attr_set_pp = true;
   }
   const int tiles = ((p.M + TBM - 1) / TBM) * ((p.N + TBN - 1) / TBN) * split;
-  hipLaunchKernelGGL((gemm_pers_kernel<LAYOUT, TBM, TBN>), dim3(tiles < n_cu ? tiles : n_cu), dim3(512), LDSP, s, p);
+  hipLaunchKernelGGL((gemm_pers_kernel<LAYOUT, TBM, TBN, EPI>), dim3(tiles < n_cu ? tiles : n_cu), dim3(512), LDSP, s, p);
   PXA_LAUNCH_CHECK();
   return 0;
 }
@@ -888,11 +893,15 @@ int launch_glds(GemmParams p, int split, hipStream_t s) {
   const bool dual = (p.act == 1 && p.out2 != nullptr);   // two LDS trips: measured slower than the direct epilogue
   static const bool no_pers = getenv("PXA_GEMM_NO_PERSISTENT") != nullptr;
   if (LAYOUT != 2 && TBM == 256 && TBN == 256 && split == 1 && p.out && !p.outf && !no_pers) {
-    return launch_pers<LAYOUT == 2 ? 0 : LAYOUT, 256, 256>(p, 1, s);
+    constexpr int LY = LAYOUT == 2 ? 0 : LAYOUT;
+    if (p.act == 0 && !p.colsum) return launch_pers<LY, 256, 256, 0>(p, 1, s);
+    if (p.act == 1 && p.out2 && !p.colsum) return launch_pers<LY, 256, 256, 1>(p, 1, s);
+    if (p.act == 2 && p.colsum) return launch_pers<LY, 256, 256, 2>(p, 1, s);
+    return launch_pers<LY, 256, 256, 3>(p, 1, s);
   }
   // fp32 weight gradients (TN, split-K slabs / single-slice read-modify-write / plain store): the same persistent kernel
   if (LAYOUT == 2 && TBM == 256 && TBN == 256 && p.outf && !p.out && !p.bias && p.act == 0 && p.accumulate != 1 && !p.colsum && !no_pers)
-    return launch_pers<2, 256, 256>(p, split, s);
+    return launch_pers<2, 256, 256, 0>(p, split, s);
   if (LAYOUT != 2 && p.out && !p.outf && !dual && !no_stage) return launch_glds_e<LAYOUT, TBM, TBN, WM, WN, 1>(p, split, s);
   if (p.colsum) {                                         // not fused on this path: separate column-sum pass over the output
     float* cs = p.colsum;

@@ -117,7 +117,10 @@ class ParamStore:
     def refresh_shadow(self, force=False):
         """Re-cast master -> bf16 shadow if any parameter was modified by torch ops since the last cast (the fused AdamW
         kernel refreshes the shadow itself and does not bump versions)."""
-        vers = tuple(p._version for p in self.params.values())
+        try:
+            vers = tuple(p._version for p in self.params.values())
+        except RuntimeError:      # parameters created under torch.inference_mode() carry no version counter: re-cast every call
+            vers, force = None, True
         if force or vers != self._versions:
             ops.cast_bf16(self.master, self.shadow)
             self._versions = vers

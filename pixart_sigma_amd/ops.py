@@ -144,7 +144,7 @@ def attention_bwd(q, k, v, o, d_o, lse, delta, dq, dk, dv, B, H, Nq, Nk, strides
     a.colsum_stride = next((t.stride(0) for t in colsums if t is not None), 0)
     a.lse, a.delta, a.d_o, a.dq, a.dk, a.dv = ptr(lse), ptr(delta), ptr(d_o), ptr(dq), ptr(dk), ptr(dv)
     (a.dq_bs, a.dq_ts, a.dq_hs), (a.dk_bs, a.dk_ts, a.dk_hs), (a.dv_bs, a.dv_ts, a.dv_hs) = dstrides
-    call("pxa_attn_bwd", a)
+    call("pxa_attn_bwd", a)            # dq=None skips the dQ kernel, dk=dv=None the dK/dV kernel
 
 
 def patch_embed_fwd(x, w, bias, pos, out=None):

@@ -256,6 +256,82 @@ void run_sched(const char* A, const char* B, int M, int N, int K, float* sink) {
   printf("M=%d N=%d K=%d schedule MODE=%d : %7.3f ms  GEMM-equivalent %7.1f TF/s\n", M, N, K, MODE, ms, 2.0 * M * N * K / ms / 1e9);
 }
 
+// ---- MODE 7: one wave per SIMD (256 threads, wave tile 128 x 128, 256 accumulator registers), software-pipelined inside the wave:
+// k-sub-step MFMAs interleaved 1:1 with the fragment reads of the next sub-step and the LDS-DMA of unit u+3; one barrier per unit.
+__global__ __launch_bounds__(256) void sched4_kernel(const char* A, const char* B, long lda, long ldb, int mt, int nt, int units, float* sink) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), wm = wave >> 1, wn = wave & 1;
+  int tm, tn;
+  tile_coords(blockIdx.x, mt, nt, tm, tn);
+  const char* src[8];
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    const int piece = i * 4 + wave;
+    src[i] = piece < 16 ? src_addr<64>(A, lda, tm * 256, 0, piece, lane, units) : src_addr<64>(B, ldb, tn * 256, 0, piece - 16, lane, units);
+  }
+  int slot_w = 0;
+  auto glds = [&](int i) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src[i],
+                                     (__attribute__((address_space(3))) void*)(smem + slot_w * 32768 + (i * 4 + wave) * 1024), 16, 0, 0);
+    src[i] += 64;
+  };
+  f16v acc[4][4] = {};
+  for (int u = 0; u < 3; u++) {
+#pragma unroll
+    for (int i = 0; i < 8; i++) glds(i);
+    slot_w = (slot_w + 1) & 3;
+  }
+  wait_vmcnt<16>();
+  __builtin_amdgcn_s_barrier();
+  bf8 af[2][4], bfr[2][4];
+#pragma unroll
+  for (int i = 0; i < 4; i++) { af[0][i] = frag(smem, wm * 128 + i * 32, 0, lane); bfr[0][i] = frag(smem + 16384, wn * 128 + i * 32, 0, lane); }
+  for (int u = 0; u < units; u++) {
+    const char* sA = smem + (u & 3) * 32768;
+    const char* sB = sA + 16384;
+    const char* nA = smem + ((u + 1) & 3) * 32768;
+    const char* nB = nA + 16384;
+    const bool pf = u + 3 < units;
+    // half A: MFMAs of k-sub-step 0  ||  fragment reads of k-sub-step 1  ||  first 4 DMA pieces of unit u+3
+#pragma unroll
+    for (int g = 0; g < 16; g++) {
+      acc[g >> 2][g & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[0][g & 3], af[0][g >> 2], acc[g >> 2][g & 3], 0, 0, 0);
+      if (g < 4) af[1][g] = frag(sA, wm * 128 + g * 32, 1, lane);
+      else if (g < 8) bfr[1][g - 4] = frag(sB, wn * 128 + (g - 4) * 32, 1, lane);
+      else if (g < 12) { if (pf) glds(g - 8); }
+      SB();
+    }
+    if (pf) wait_vmcnt<12>(); else wait_vmcnt<0>();
+    BAR();
+    // half B: MFMAs of k-sub-step 1  ||  fragment reads of the next unit's k-sub-step 0  ||  last 4 DMA pieces of unit u+3
+#pragma unroll
+    for (int g = 0; g < 16; g++) {
+      acc[g >> 2][g & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfr[1][g & 3], af[1][g >> 2], acc[g >> 2][g & 3], 0, 0, 0);
+      if (g < 4) af[0][g] = frag(nA, wm * 128 + g * 32, 0, lane);
+      else if (g < 8) bfr[0][g - 4] = frag(nB, wn * 128 + (g - 4) * 32, 0, lane);
+      else if (g < 12) { if (pf) glds(g - 4); }
+      SB();
+    }
+    if (pf) slot_w = (slot_w + 1) & 3;
+  }
+  float s = 0;
+  for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) for (int g = 0; g < 16; g++) s += acc[i][j][g];
+  if (s == 12345.678f) sink[0] = s;
+}
+void run_sched4(const char* A, const char* B, int M, int N, int K, float* sink) {
+  const int mt = M / 256, nt = N / 256, units = K / 32;
+  CK(hipFuncSetAttribute(reinterpret_cast<const void*>(sched4_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 131072));
+  hipEvent_t e0, e1;
+  CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  for (int it = 0; it < 2; it++) hipLaunchKernelGGL(sched4_kernel, dim3(mt * nt), dim3(256), 131072, 0, A, B, (long)K * 2, (long)K * 2, mt, nt, units, sink);
+  CK(hipEventRecord(e0));
+  const int iters = g_iters;
+  for (int it = 0; it < iters; it++) hipLaunchKernelGGL(sched4_kernel, dim3(mt * nt), dim3(256), 131072, 0, A, B, (long)K * 2, (long)K * 2, mt, nt, units, sink);
+  CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+  float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= iters;
+  printf("M=%d N=%d K=%d schedule MODE=7 (4 waves, 128x128 per wave) : %7.3f ms  GEMM-equivalent %7.1f TF/s\n", M, N, K, ms, 2.0 * M * N * K / ms / 1e9);
+}
+
 int main(int argc, char** argv) {
   if (argc > 1) g_iters = atoi(argv[1]);
   const bool sched_only = argc > 2;
@@ -283,6 +359,7 @@ int main(int argc, char** argv) {
     }
     run_sched<1>(A, B, M, N, K, sink); run_sched<2>(A, B, M, N, K, sink); run_sched<3>(A, B, M, N, K, sink);
     run_sched<4>(A, B, M, N, K, sink); run_sched<5>(A, B, M, N, K, sink); run_sched<6>(A, B, M, N, K, sink);
+    run_sched4(A, B, M, N, K, sink);
     CK(hipFree(A)); CK(hipFree(B));
   }
   return 0;

@@ -56,7 +56,7 @@ def load_captions(args, n, L, dev):
     return torch.cat(feats).to(dev), torch.cat(masks), torch.from_numpy(null["caption_feature"]).float().reshape(1, 1, -1, 4096)[:, :, :L].to(dev)
 
 
-@torch.inference_mode()
+@torch.no_grad()
 def main():
     args = get_args()
     dev = torch.device("cuda")

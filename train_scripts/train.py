@@ -112,6 +112,8 @@ def main():
         if step % cfg["save_model_steps"] == 0 and rank == 0:
             torch.save({"state_dict": model.state_dict(), "optimizer": opt.state_dict(), "step": step},
                        os.path.join(a.work_dir, "checkpoints", f"epoch_1_step_{step}.pth"))
+    if rank == 0:
+        print(f"finished at step {step}: loss {loss.item():.4f} grad_norm {opt.last_norm.item():.4f}", flush=True)
     if world > 1:
         dist.destroy_process_group()
 
