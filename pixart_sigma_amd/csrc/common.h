@@ -53,23 +53,29 @@ __device__ __forceinline__ f32x16 mfma32(bf16x8 a, bf16x8 b, f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
 }
 
-// GELU(approximate="tanh") and its derivative (reference: nn.GELU(approximate="tanh"), PixArtMS.py:66)
-__device__ __forceinline__ float tanh_fast(float u) {
-  // tanh(u) = 1 - 2/(1+exp(2u)); exact limits at +-inf
-  float e = __expf(2.0f * u);
-  return 1.0f - 2.0f / (1.0f + e);
+// GELU(approximate="tanh") and its derivative (reference: nn.GELU(approximate="tanh"), PixArtMS.py:66), written through the
+// identity 0.5 (1 + tanh u) = sigmoid(2u) = 1 / (1 + 2^w),  w = -2 log2(e) k0 x (1 + k1 x^2):
+//   gelu(x)  = x s                                   7 VALU ops, 2 of them transcendental (v_exp_f32, v_rcp_f32)
+//   gelu'(x) = s + x s (1 - s) 2 k0 (1 + 3 k1 x^2)   with 1 - s = 2^w s: 12 ops
+// (the epilogues that apply them run with every accumulator live and are VALU-bound: the textbook tanh form with a true
+// division cost 2.5x more and made the fc2-dX GEMM 65 % slower than its plain twin).  w is clamped so 2^w stays finite.
+__device__ __forceinline__ float gelu_sigmoid_terms(float x, float x2, float& e) {
+  const float c0 = -2.0f * 1.4426950408889634f * 0.7978845608028654f, c1 = c0 * 0.044715f;
+  const float w = fminf(x * fmaf(x2, c1, c0), 126.0f);
+  e = __builtin_amdgcn_exp2f(w);
+  return __builtin_amdgcn_rcpf(1.0f + e);              // s = sigmoid(2u)
 }
 __device__ __forceinline__ float gelu_tanh(float x) {
-  const float k0 = 0.7978845608028654f, k1 = 0.044715f;
-  float u = k0 * (x + k1 * x * x * x);
-  return 0.5f * x * (1.0f + tanh_fast(u));
+  float e;
+  return x * gelu_sigmoid_terms(x, x * x, e);
 }
 __device__ __forceinline__ float gelu_tanh_grad(float x) {
   const float k0 = 0.7978845608028654f, k1 = 0.044715f;
-  float x2 = x * x;
-  float u = k0 * (x + k1 * x * x2);
-  float t = tanh_fast(u);
-  return 0.5f * (1.0f + t) + 0.5f * x * (1.0f - t * t) * k0 * (1.0f + 3.0f * k1 * x2);
+  const float x2 = x * x;
+  float e;
+  const float s = gelu_sigmoid_terms(x, x2, e);
+  const float one_minus_s = e * s;
+  return fmaf(s * one_minus_s, x * fmaf(x2, 6.0f * k0 * k1, 2.0f * k0), s);
 }
 
 __device__ __forceinline__ float half_wave_sum(float v) {  // reduce inside each 32-lane half
