@@ -40,7 +40,11 @@ int pxa_device_info(int* cu_count, int* is_gfx950);
  * layout 1 (NN): C[m][n] = sum_k A[m][k]*B[k][n]   dX = dY W          A:(M,K) B:(K,N)
  * layout 2 (TN): C[m][n] = sum_k A[k][m]*B[k][n]   dW = dY^T X        A:(K,M) B:(K,N)
  * act 0: none; 1: GELU(tanh) applied after bias (pre-activation optionally stored to out2_bf16);
- * act 2: multiply by GELU'(aux[m][n]) (aux = saved pre-activation) — the fc1 backward input gradient. */
+ * act 2: multiply by GELU'(aux[m][n]) (aux = saved pre-activation) — the fc1 backward input gradient;
+ * act 3: GELU(tanh) after bias with GELU'(pre-activation) stored to out2_bf16 (required) — the training forward of fc1:
+ *        the derivative shares the sigmoid of the activation, so saving it costs 5 VALU ops where recomputing it in the
+ *        backward epilogue costs 12 with every accumulator live;
+ * act 4: multiply by aux[m][n] (aux = the derivative saved by act 3) — the fc1 backward input gradient of that path. */
 typedef struct {
   const void* A; const void* B;  /* bf16 */
   int lda, ldb;
@@ -48,7 +52,7 @@ typedef struct {
   int layout;
   const float* bias;             /* [N] or NULL */
   int act;
-  const void* aux; int ldaux;    /* bf16 [M][N], act == 2 */
+  const void* aux; int ldaux;    /* bf16 [M][N], act == 2 or 4 */
   void* out_bf16; void* out2_bf16; int ld_out;
   float* out_f32; int ld_f32;
   int accumulate;                /* out_f32: 0 = store, 1 = atomicAdd (gradient accumulation / split-K) */

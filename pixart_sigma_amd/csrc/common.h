@@ -69,6 +69,14 @@ __device__ __forceinline__ float gelu_tanh(float x) {
   float e;
   return x * gelu_sigmoid_terms(x, x * x, e);
 }
+__device__ __forceinline__ float gelu_tanh_both(float x, float& grad) {   // returns gelu(x), grad = gelu'(x)
+  const float k0 = 0.7978845608028654f, k1 = 0.044715f;
+  const float x2 = x * x;
+  float e;
+  const float s = gelu_sigmoid_terms(x, x2, e);
+  grad = fmaf(s * (e * s), x * fmaf(x2, 6.0f * k0 * k1, 2.0f * k0), s);
+  return x * s;
+}
 __device__ __forceinline__ float gelu_tanh_grad(float x) {
   const float k0 = 0.7978845608028654f, k1 = 0.044715f;
   const float x2 = x * x;

@@ -126,11 +126,17 @@ __device__ __forceinline__ void epilogue(const GemmParams& p, const f32x16 (&acc
           if (p.out2) *reinterpret_cast<uint2*>(p.out2 + (size_t)m * p.ldo + n) = pack_bf16x4(v[0], v[1], v[2], v[3]);
 #pragma unroll
           for (int e = 0; e < 4; e++) v[e] = gelu_tanh(v[e]);
-        } else if (p.act == 2) {
+        } else if (p.act == 3) {
+          float g[4];
+#pragma unroll
+          for (int e = 0; e < 4; e++) v[e] = gelu_tanh_both(v[e], g[e]);
+          *reinterpret_cast<uint2*>(p.out2 + (size_t)m * p.ldo + n) = pack_bf16x4(g[0], g[1], g[2], g[3]);
+        } else if (p.act == 2 || p.act == 4) {
           const uint2 a = *reinterpret_cast<const uint2*>(p.aux + (size_t)m * p.ldaux + n);
           float a0, a1, a2, a3;
           unpack_bf16x2(a.x, a0, a1); unpack_bf16x2(a.y, a2, a3);
-          v[0] *= gelu_tanh_grad(a0); v[1] *= gelu_tanh_grad(a1); v[2] *= gelu_tanh_grad(a2); v[3] *= gelu_tanh_grad(a3);
+          if (p.act == 2) { a0 = gelu_tanh_grad(a0); a1 = gelu_tanh_grad(a1); a2 = gelu_tanh_grad(a2); a3 = gelu_tanh_grad(a3); }
+          v[0] *= a0; v[1] *= a1; v[2] *= a2; v[3] *= a3;
         }
         if (p.out) *reinterpret_cast<uint2*>(p.out + (size_t)m * p.ldo + n) = pack_bf16x4(v[0], v[1], v[2], v[3]);
         if (p.outf) {
@@ -320,13 +326,14 @@ __device__ __forceinline__ void epilogue_staged(const GemmParams& p, f32x16 (&ac
             if (p.act == 1) {
 #pragma unroll
               for (int e = 0; e < 4; e++) v[e] = gelu_tanh(v[e]);
-            } else if (p.act == 2) {
+            } else if (p.act == 2 || p.act == 4) {
               const int m = mw + i * 32 + (lane & 31), n = nw + col;
               if (m < p.M && n < p.N) {
                 const uint2 a = *reinterpret_cast<const uint2*>(p.aux + (size_t)m * p.ldaux + n);
                 float a0, a1, a2, a3;
                 unpack_bf16x2(a.x, a0, a1); unpack_bf16x2(a.y, a2, a3);
-                v[0] *= gelu_tanh_grad(a0); v[1] *= gelu_tanh_grad(a1); v[2] *= gelu_tanh_grad(a2); v[3] *= gelu_tanh_grad(a3);
+                if (p.act == 2) { a0 = gelu_tanh_grad(a0); a1 = gelu_tanh_grad(a1); a2 = gelu_tanh_grad(a2); a3 = gelu_tanh_grad(a3); }
+                v[0] *= a0; v[1] *= a1; v[2] *= a2; v[3] *= a3;
               }
             }
           }
@@ -377,11 +384,17 @@ __device__ __forceinline__ void epilogue_t(const GemmParams& p, const f32x16 (&a
           if (p.out2) *reinterpret_cast<uint2*>(p.out2 + (size_t)m * p.ldo + n) = pack_bf16x4(v[0], v[1], v[2], v[3]);
 #pragma unroll
           for (int e = 0; e < 4; e++) v[e] = gelu_tanh(v[e]);
-        } else if (p.act == 2) {
+        } else if (p.act == 3) {
+          float g[4];
+#pragma unroll
+          for (int e = 0; e < 4; e++) v[e] = gelu_tanh_both(v[e], g[e]);
+          *reinterpret_cast<uint2*>(p.out2 + (size_t)m * p.ldo + n) = pack_bf16x4(g[0], g[1], g[2], g[3]);
+        } else if (p.act == 2 || p.act == 4) {
           const uint2 a = *reinterpret_cast<const uint2*>(p.aux + (size_t)m * p.ldaux + n);
           float a0, a1, a2, a3;
           unpack_bf16x2(a.x, a0, a1); unpack_bf16x2(a.y, a2, a3);
-          v[0] *= gelu_tanh_grad(a0); v[1] *= gelu_tanh_grad(a1); v[2] *= gelu_tanh_grad(a2); v[3] *= gelu_tanh_grad(a3);
+          if (p.act == 2) { a0 = gelu_tanh_grad(a0); a1 = gelu_tanh_grad(a1); a2 = gelu_tanh_grad(a2); a3 = gelu_tanh_grad(a3); }
+          v[0] *= a0; v[1] *= a1; v[2] *= a2; v[3] *= a3;
         }
         if (p.out) *reinterpret_cast<uint2*>(p.out + (size_t)m * p.ldo + n) = pack_bf16x4(v[0], v[1], v[2], v[3]);
         if (p.outf) {
@@ -587,8 +600,8 @@ __device__ __forceinline__ const bf16_t* piece_ptr(const bf16_t* __restrict__ X,
 }
 
 // EPI (bf16 epilogue flavour, compiled separately so that none carries the others' registers - the epilogue runs with all
-// 128 accumulators live and spills at the slightest extra state): 0 = (+bias), 1 = bias + GELU with the pre-activation as a
-// second output, 2 = x GELU'(aux) + bias-gradient column sums, 3 = everything decided at run time.
+// 128 accumulators live and spills at the slightest extra state): 0 = (+bias), 1 = act 3 (bias + GELU, GELU' as the second
+// output), 2 = act 4 (x aux) + bias-gradient column sums, 3 = everything decided at run time (acts 1 / 2 and odd mixes).
 template <int LAYOUT, int TBM, int TBN, int EPI>
 __global__ __launch_bounds__(512) void gemm_pers_kernel(GemmParams p) {
   constexpr bool A_KC = (LAYOUT != 2), B_KC = (LAYOUT == 0);
@@ -753,8 +766,8 @@ __global__ __launch_bounds__(512) void gemm_pers_kernel(GemmParams p) {
       if (!more) break;
       continue;
     }
-    const int act = EPI == 0 ? 0 : EPI == 1 ? 1 : EPI == 2 ? 2 : p.act;
-    const bool dual = EPI == 1 || (EPI == 3 && p.act == 1 && p.out2 != nullptr);
+    const int act = EPI == 0 ? 0 : EPI == 1 ? 3 : EPI == 2 ? 4 : p.act;
+    const bool dual = EPI == 1 || (EPI == 3 && ((p.act == 1 && p.out2 != nullptr) || p.act == 3));
     const bool want_cs = EPI == 2 || (EPI == 3 && p.colsum != nullptr);
     // one column group of JW 32-wide tiles (JW = 2: 128-byte staging rows, 8 rows per store; JW = 1: 64-byte rows, 16 per store)
     auto emit = [&](int j0, auto jw_c) {
@@ -778,7 +791,7 @@ __global__ __launch_bounds__(512) void gemm_pers_kernel(GemmParams p) {
       for (int i = 0; i < TM; i++) {
         const int m = mw + i * 32 + srow;
         uint2 ax[JW][4];
-        if (act == 2) {                                // GELU' needs the saved pre-activation
+        if (act == 2 || act == 4) {                    // saved pre-activation (act 2) or saved GELU' (act 4)
 #pragma unroll
           for (int jj = 0; jj < JW; jj++)
 #pragma unroll
@@ -796,14 +809,20 @@ __global__ __launch_bounds__(512) void gemm_pers_kernel(GemmParams p) {
             for (int q = 0; q < 4; q++) {
               const int j = j0 + jj;
               float v[4] = {acc[i][j][q * 4], acc[i][j][q * 4 + 1], acc[i][j][q * 4 + 2], acc[i][j][q * 4 + 3]};
+              if (pass == 0 && act == 3) {             // second output = GELU'(pre-activation); the activation itself replaces
+                float g[4];                            // the accumulator so that pass 1 only has to park it
+#pragma unroll
+                for (int e = 0; e < 4; e++) { acc[i][j][q * 4 + e] = gelu_tanh_both(v[e], g[e]); v[e] = g[e]; }
+              }
               if (pass == 1) {
                 if (act == 1) {
 #pragma unroll
                   for (int e = 0; e < 4; e++) v[e] = gelu_tanh(v[e]);
-                } else if (act == 2) {
+                } else if (act == 2 || act == 4) {
                   float a0, a1, a2, a3;
                   unpack_bf16x2(ax[jj][q].x, a0, a1); unpack_bf16x2(ax[jj][q].y, a2, a3);
-                  v[0] *= gelu_tanh_grad(a0); v[1] *= gelu_tanh_grad(a1); v[2] *= gelu_tanh_grad(a2); v[3] *= gelu_tanh_grad(a3);
+                  if (act == 2) { a0 = gelu_tanh_grad(a0); a1 = gelu_tanh_grad(a1); a2 = gelu_tanh_grad(a2); a3 = gelu_tanh_grad(a3); }
+                  v[0] *= a0; v[1] *= a1; v[2] *= a2; v[3] *= a3;
                 }
                 if (want_cs && m < p.M) {
 #pragma unroll
@@ -890,13 +909,13 @@ int launch_glds(GemmParams p, int split, hipStream_t s) {
   // bf16-only outputs of the forward / dX GEMMs take the LDS-staged, fully coalesced epilogue (separate kernel instances, so
   // neither epilogue's registers burden the other)
   static const bool no_stage = getenv("PXA_GEMM_NO_STAGED_EPILOGUE") != nullptr;
-  const bool dual = (p.act == 1 && p.out2 != nullptr);   // two LDS trips: measured slower than the direct epilogue
+  const bool dual = (p.act == 1 && p.out2 != nullptr) || p.act == 3;   // two outputs: the direct epilogue
   static const bool no_pers = getenv("PXA_GEMM_NO_PERSISTENT") != nullptr;
   if (LAYOUT != 2 && TBM == 256 && TBN == 256 && split == 1 && p.out && !p.outf && !no_pers) {
     constexpr int LY = LAYOUT == 2 ? 0 : LAYOUT;
     if (p.act == 0 && !p.colsum) return launch_pers<LY, 256, 256, 0>(p, 1, s);
-    if (p.act == 1 && p.out2 && !p.colsum) return launch_pers<LY, 256, 256, 1>(p, 1, s);
-    if (p.act == 2 && p.colsum) return launch_pers<LY, 256, 256, 2>(p, 1, s);
+    if (p.act == 3 && !p.colsum) return launch_pers<LY, 256, 256, 1>(p, 1, s);
+    if (p.act == 4 && p.colsum) return launch_pers<LY, 256, 256, 2>(p, 1, s);
     return launch_pers<LY, 256, 256, 3>(p, 1, s);
   }
   // fp32 weight gradients (TN, split-K slabs / single-slice read-modify-write / plain store): the same persistent kernel
@@ -969,8 +988,9 @@ extern "C" int pxa_gemm(const pxa_gemm_args* a, hipStream_t stream) {
   PXA_CHECK(a->out_bf16 || a->out_f32, "pxa_gemm: no output");
   if (a->out_bf16 || a->out2_bf16) PXA_CHECK(a->ld_out % 4 == 0, "pxa_gemm: ld_out must be a multiple of 4");
   if (a->out_f32) PXA_CHECK(a->ld_f32 % 4 == 0, "pxa_gemm: ld_f32 must be a multiple of 4");
-  PXA_CHECK(a->act >= 0 && a->act <= 2, "pxa_gemm: bad act %d", a->act);
-  if (a->act == 2) PXA_CHECK(a->aux && a->ldaux % 4 == 0, "pxa_gemm: act=2 needs aux");
+  PXA_CHECK(a->act >= 0 && a->act <= 4, "pxa_gemm: bad act %d", a->act);
+  if (a->act == 2 || a->act == 4) PXA_CHECK(a->aux && a->ldaux % 4 == 0, "pxa_gemm: act=%d needs aux", a->act);
+  if (a->act == 3) PXA_CHECK(a->out_bf16 && a->out2_bf16, "pxa_gemm: act=3 needs both bf16 outputs");
   if (a->colsum) PXA_CHECK(a->out_bf16 && !a->out_f32, "pxa_gemm: colsum needs a bf16 output");
   int split = a->split_k < 1 ? 1 : a->split_k;   // 0 = choose here (only for fp32 atomic-accumulate outputs)
   if (split > 1) PXA_CHECK(a->out_f32 && a->accumulate && !a->out_bf16 && a->act == 0 && !a->bias, "pxa_gemm: split_k>1 needs fp32 atomic accumulate output only");

@@ -186,7 +186,7 @@ class Engine:
         S = self.S
         yb = ops.gather_rows_bf16(y, row_idx, L, alt=y_null if drop is not None else None, drop=drop)
         hpre = torch.empty((yb.shape[0], S.shape["y_embedder.y_proj.fc1.weight"][0]), dtype=BF16, device=y.device)
-        h = self._lin(yb, "y_embedder.y_proj.fc1", act=ops.ACT_GELU, out2=hpre)
+        h = self._lin(yb, "y_embedder.y_proj.fc1", act=ops.ACT_GELU_SAVE_GRAD, out2=hpre)   # hpre holds GELU'(pre-activation)
         ye = self._lin(h, "y_embedder.y_proj.fc2")
         return ye, (yb, hpre, h)
 
@@ -194,7 +194,7 @@ class Engine:
         yb, hpre, h = saved
         dye = torch.empty(dye_f32.shape, dtype=BF16, device=dye_f32.device)
         ops.gate_bwd(dye_f32, du=dye, rows_per_batch=dye_f32.shape[0])
-        dh = self._lin_bwd(dye, h, "y_embedder.y_proj.fc2", dx_kw=dict(act=ops.ACT_GELU_GRAD, aux=hpre))
+        dh = self._lin_bwd(dye, h, "y_embedder.y_proj.fc2", dx_kw=dict(act=ops.ACT_MUL_AUX, aux=hpre))
         self._lin_bwd(dh, yb, "y_embedder.y_proj.fc1", need_dx=False)
 
     # ------------------------------------------------------------------ block
@@ -255,7 +255,7 @@ class Engine:
         r = ops.ln_mod_fwd(x1, sl, scl, st, u=u2, x_out=x1, rows_per_batch=N, want_stats=True)
         x2, xn2, mean2, rstd2 = r["x"], r["xn"], r["mean"], r["rstd"]
         hpre = torch.empty((B * N, S.shape[p + "mlp.fc1.weight"][0]), dtype=BF16, device=qkv.device)
-        h = self._lin(xn2, p + "mlp.fc1", act=ops.ACT_GELU, out2=hpre)
+        h = self._lin(xn2, p + "mlp.fc1", act=ops.ACT_GELU_SAVE_GRAD, out2=hpre)   # hpre holds GELU'(pre-activation), bf16
         u3 = self._lin(h, p + "mlp.fc2")
         saved = dict(x_in=x_in, mean1=mean1, rstd1=rstd1, xn1=xn1, qkv=qkv, a=a, lse=lse, u1=u1, x1b=x1b, qc=qc, kvc=kvc,
                      cr=cr, lse_c=lse_c, x2=x2, mean2=mean2, rstd2=rstd2, xn2=xn2, hpre=hpre, h=h, u3=u3, kc=kc, vc=vc, sr=sr)
@@ -283,7 +283,7 @@ class Engine:
         du = torch.empty((R, D), dtype=BF16, device=dev)
         ops.gate_bwd(G, u=sv["u3"], gate=mod[:, 5], mod_stride=st, du=du, dgate=dmod[:, 5], dmod_stride=st, rows_per_batch=N,
                      dbias=pb("mlp.fc2.bias"))
-        dh = self._lin_bwd(du, sv["h"], p + "mlp.fc2", dx_kw=dict(act=ops.ACT_GELU_GRAD, aux=sv["hpre"], colsum=pb("mlp.fc1.bias")), bias_done=True)
+        dh = self._lin_bwd(du, sv["h"], p + "mlp.fc2", dx_kw=dict(act=ops.ACT_MUL_AUX, aux=sv["hpre"], colsum=pb("mlp.fc1.bias")), bias_done=True)
         dxn = self._lin_bwd(dh, sv["xn2"], p + "mlp.fc1", bias_done=True)
         del dh
         # ---- cross attention: x2 = x1 + u2 (no gate, no norm): du2 = bf16(G2) comes out of the LN backward pass itself

@@ -72,6 +72,35 @@ def test_gemm_nn_gelu_grad(ops):
     assert rel_l2(part.sum(0)[:N], (dy[:, :72].float() @ w[:72].float()).to(torch.bfloat16).float().sum(0)) < 1e-4
 
 
+@pytest.mark.parametrize("M,N,K", [(1100, 1152, 256), (2048, 1280, 128), (1024, 4608, 64)])
+def test_gemm_persistent_kernel_epilogues(ops, M, N, K):
+    """M, N >= 1024: the persistent 256x256 kernel (ragged last tiles in both directions) with every epilogue flavour."""
+    a, w, b = bf(rnd(M, K, seed=1)), bf(rnd(N, K, scale=K ** -0.5, seed=2)), rnd(N, seed=3)
+    pre = a.float() @ w.float().t() + b
+    x = pre.clone().requires_grad_(True)
+    F.gelu(x, approximate="tanh").backward(torch.ones_like(x))
+    assert rel_l2(ops.gemm(a, w, ops.NT, bias=b).float(), pre) < BF16_TOL                      # bias only
+    out2 = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
+    out = ops.gemm(a, w, ops.NT, bias=b, act=ops.ACT_GELU_SAVE_GRAD, out2=out2)                # training forward of fc1
+    assert rel_l2(out.float(), F.gelu(pre, approximate="tanh")) < BF16_TOL
+    assert rel_l2(out2.float(), x.grad) < BF16_TOL
+    out = ops.gemm(a, w, ops.NT, bias=b, act=ops.ACT_GELU, out2=out2)                          # run-time generic flavour
+    assert rel_l2(out.float(), F.gelu(pre, approximate="tanh")) < BF16_TOL and rel_l2(out2.float(), pre) < BF16_TOL
+    wt = bf(rnd(K, N, scale=K ** -0.5, seed=4))                                                # NN: dX = dY W
+    ref = a.float() @ wt.float()
+    aux = bf(rnd(M, N, seed=5))
+    part = torch.zeros(ops.COLSUM_SLOTS, N, device="cuda")
+    out = ops.gemm(a, wt, ops.NN, act=ops.ACT_MUL_AUX, aux=aux, colsum=part)                   # backward of that path + bias-gradient sums
+    assert rel_l2(out.float(), ref * aux.float()) < BF16_TOL
+    assert rel_l2(part.sum(0), out.float().sum(0)) < 2e-3       # sums of the fp32 values before the bf16 rounding of `out`
+    assert rel_l2(part.sum(0), (ref * aux.float()).sum(0)) < 1e-3
+    g = bf(pre)
+    out = ops.gemm(a, wt, ops.NN, act=ops.ACT_GELU_GRAD, aux=g)
+    gx = g.float().clone().requires_grad_(True)
+    F.gelu(gx, approximate="tanh").backward(torch.ones_like(gx))
+    assert rel_l2(out.float(), ref * gx.grad) < BF16_TOL
+
+
 @pytest.mark.parametrize("K,split", [(512, 1), (1000, 3), (4096, 8)])
 def test_gemm_tn_splitk_accumulate(ops, K, split):
     M, N = 1152, 3456  # dW[M][N] = sum_k A[k][M] B[k][N]
