@@ -28,6 +28,9 @@ sys.path.insert(0, ROOT)
 
 D, H, DFF, DEPTH, LTXT = 1152, 16, 4608, 28, 300
 MFMA_PEAK = 2.5e15   # dense bf16, MI355X (MI355X_MICROARCH.md)
+# HBM bytes per launch of the dominant kernel (attn_bwd_dkv_kernel, self-attention B16 H16 N4096), from the PMC passes committed under
+# profiles/ (rocprofv3 cannot run inside the benchmark): 2 x 1,088,993 KB fetched + 160,055 KB written
+DKV_HBM_BYTES_PER_LAUNCH = 2 * 1088993.4e3 + 160055.3e3
 
 
 def fwd_flops_per_sample(N, L=LTXT, n_kv=None):
@@ -211,7 +214,9 @@ def main():
             # dominant kernel of the step by total time (profiles/: attn_bwd_dkv_kernel, 56 launches, ~17 % of the step)
             dom = ks["attn_bwd_dkv_kernel"]
             roof = {"bound": "mfma", "kernel": "attn_bwd_dkv_kernel (self-attention, B16 H16 N4096 d72)", "achieved": dom["tflops"], "peak": MFMA_PEAK / 1e12,
-                    "unit": "TFLOP/s", "frac": dom["frac"], "traffic": None, "flops_per_launch": dom["flops"], "ms_per_launch": dom["seconds"] * 1e3,
+                    "unit": "TFLOP/s", "frac": dom["frac"], "traffic": DKV_HBM_BYTES_PER_LAUNCH,
+                    "traffic_source": "profiles/r01_pmc_attention.txt: 2 x FETCH_SIZE (gfx950 correction) + WRITE_SIZE, separate --pmc passes, bytes per launch",
+                    "flops_per_launch": dom["flops"], "ms_per_launch": dom["seconds"] * 1e3,
                     "step": {"achieved": flops_step / sec_per_step / 1e12, "frac": flops_step / sec_per_step / MFMA_PEAK,
                              "scope": "whole training step (algorithmic FLOPs / wall time)"},
                     "kernels": {k: {"TFLOP/s": round(v["tflops"], 1), "frac": round(v["frac"], 4), "ms": round(v["seconds"] * 1e3, 3)} for k, v in ks.items()}}
