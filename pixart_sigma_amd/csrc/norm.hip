@@ -233,21 +233,21 @@ __global__ __launch_bounds__(256) void gate_bwd_kernel(
   }
 }
 
-// db[n] += sum_r dY[r][n].  Block = 64 column-threads (8 columns = one 16-byte load each, 512 columns) x 4 row-lanes over
-// CS_ROWS rows; 8 independent row loads in flight per thread; the row-lanes are combined through LDS, one atomic per column.
-constexpr int CS_ROWS = 128;
-__global__ __launch_bounds__(256) void colsum_kernel(const bf16_t* __restrict__ dy, int ld, float* __restrict__ out, int R, int N) {
-  __shared__ float red[4][64][8];
-  const int ct = threadIdx.x & 63, rl = threadIdx.x >> 6;
-  const int c = (blockIdx.x * 64 + ct) * 8;
-  const int r0 = blockIdx.y * CS_ROWS, r1 = min(R, r0 + CS_ROWS);
+// db[n] += sum_r dY[r][n].  Block = 48 column-threads (8 columns = one 16-byte load each) x 5 row-lanes over rows_per_block rows;
+// 8 independent row loads in flight per thread; the row-lanes are combined through LDS, one atomic per column and block.
+constexpr int CS_CT = 48, CS_RL = 5;                  // 48 column-threads x 8 columns = 384 (divides 1152 / 3456 / 4608), 5 row-lanes
+__global__ __launch_bounds__(CS_CT * CS_RL) void colsum_kernel(const bf16_t* __restrict__ dy, int ld, float* __restrict__ out, int R, int N, int rows_per_block) {
+  __shared__ float red[CS_RL][CS_CT][8];
+  const int ct = threadIdx.x % CS_CT, rl = threadIdx.x / CS_CT;
+  const int c = (blockIdx.x * CS_CT + ct) * 8;
+  const int r0 = blockIdx.y * rows_per_block, r1 = min(R, r0 + rows_per_block);
   float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   if (c < N) {
-    for (int r = r0 + rl; r < r1; r += 32) {
+    for (int r = r0 + rl; r < r1; r += 8 * CS_RL) {
       uint4 v[8];
 #pragma unroll
       for (int u = 0; u < 8; u++) {
-        const int rr = r + 4 * u;
+        const int rr = r + CS_RL * u;
         v[u] = rr < r1 ? *reinterpret_cast<const uint4*>(dy + (size_t)rr * ld + c) : make_uint4(0, 0, 0, 0);
       }
 #pragma unroll
@@ -264,7 +264,12 @@ __global__ __launch_bounds__(256) void colsum_kernel(const bf16_t* __restrict__ 
   __syncthreads();
   if (rl == 0 && c < N) {
 #pragma unroll
-    for (int e = 0; e < 8; e++) atomicAdd(out + c + e, red[0][ct][e] + red[1][ct][e] + red[2][ct][e] + red[3][ct][e]);
+    for (int e = 0; e < 8; e++) {
+      float t = 0.f;
+#pragma unroll
+      for (int k = 0; k < CS_RL; k++) t += red[k][ct][e];
+      atomicAdd(out + c + e, t);
+    }
   }
 }
 
@@ -334,8 +339,12 @@ extern "C" int pxa_colsum_reduce(const float* part, long stride, float* out, lon
 
 extern "C" int pxa_colsum_bf16(const void* dy_bf16, int ld, float* out, int R, int N, hipStream_t stream) {
   PXA_CHECK(dy_bf16 && out && R > 0 && N % 8 == 0 && ld % 8 == 0, "pxa_colsum_bf16: bad args");
-  dim3 grid((N / 8 + 63) / 64, (R + CS_ROWS - 1) / CS_ROWS);
-  hipLaunchKernelGGL(colsum_kernel, grid, dim3(256), 0, stream, (const bf16_t*)dy_bf16, ld, out, R, N);
+  // ~1024 workgroups: enough to fill 256 CUs several times over while every output address sees at most a few hundred atomics
+  const int bx = (N / 8 + CS_CT - 1) / CS_CT;
+  int rpb = (int)(((long)R * bx + 1023) / 1024);
+  rpb = (rpb + 8 * CS_RL - 1) / (8 * CS_RL) * (8 * CS_RL);
+  dim3 grid(bx, (R + rpb - 1) / rpb);
+  hipLaunchKernelGGL(colsum_kernel, grid, dim3(CS_CT * CS_RL), 0, stream, (const bf16_t*)dy_bf16, ld, out, R, N, rpb);
   PXA_LAUNCH_CHECK();
   return 0;
 }
