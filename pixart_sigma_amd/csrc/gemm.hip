@@ -772,6 +772,7 @@ __global__ __launch_bounds__(512) void gemm_pers_kernel(GemmParams p) {
     // one column group of JW 32-wide tiles (JW = 2: 128-byte staging rows, 8 rows per store; JW = 1: 64-byte rows, 16 per store)
     auto emit = [&](int j0, auto jw_c) {
       constexpr int JW = decltype(jw_c)::value, RB = JW * 64;
+      constexpr int LPR = JW * 4, RPI = 64 / LPR, NST = 4 / (3 - JW);   // read-back: JW = 2: 4 x (8 rows x 128 B); JW = 1: 2 x (16 rows x 64 B)
       // bias goes into the accumulators first, unconditionally (zero when absent), so nothing extra stays live across the row loop
 #pragma unroll
       for (int jj = 0; jj < JW; jj++)
@@ -782,26 +783,30 @@ __global__ __launch_bounds__(512) void gemm_pers_kernel(GemmParams p) {
 #pragma unroll
           for (int i = 0; i < TM; i++) { acc[i][j0 + jj][q * 4] += b4.x; acc[i][j0 + jj][q * 4 + 1] += b4.y; acc[i][j0 + jj][q * 4 + 2] += b4.z; acc[i][j0 + jj][q * 4 + 3] += b4.w; }
         }
-      float cs[JW][16];
+      // bias-gradient column sums are taken from the read-back (row-wise) copy of the bf16 output: a lane keeps 8 running sums
+      // for its 8-column chunk over all row slices; one 3-step lane tree at the end
+      float cs[8];
 #pragma unroll
-      for (int jj = 0; jj < JW; jj++)
+      for (int e = 0; e < 8; e++) cs[e] = 0.f;
+      // aux (saved pre-activation / saved GELU') of the NEXT row slice is requested before this slice is processed
+      const bool want_aux = (act == 2 || act == 4);
+      uint2 ax[2][JW][4];
+      auto load_aux = [&](int i, uint2 (&dst)[JW][4]) {
+        const int m = mw + i * 32 + srow;
 #pragma unroll
-        for (int g = 0; g < 16; g++) cs[jj][g] = 0.f;
+        for (int jj = 0; jj < JW; jj++)
+#pragma unroll
+          for (int q = 0; q < 4; q++) {
+            const int n = nw + (j0 + jj) * 32 + 8 * q + 4 * hi;
+            dst[jj][q] = (m < p.M && n < p.N) ? *reinterpret_cast<const uint2*>(p.aux + (size_t)m * p.ldaux + n) : make_uint2(0u, 0u);
+          }
+      };
+      if (want_aux) load_aux(0, ax[0]);
 #pragma unroll
       for (int i = 0; i < TM; i++) {
-        const int m = mw + i * 32 + srow;
-        uint2 ax[JW][4];
-        if (act == 2 || act == 4) {                    // saved pre-activation (act 2) or saved GELU' (act 4)
+        if (want_aux && i + 1 < TM) load_aux(i + 1, ax[(i + 1) & 1]);
 #pragma unroll
-          for (int jj = 0; jj < JW; jj++)
-#pragma unroll
-            for (int q = 0; q < 4; q++) {
-              const int n = nw + (j0 + jj) * 32 + 8 * q + 4 * hi;
-              ax[jj][q] = (m < p.M && n < p.N) ? *reinterpret_cast<const uint2*>(p.aux + (size_t)m * p.ldaux + n) : make_uint2(0u, 0u);
-            }
-        }
-#pragma unroll
-        for (int pass = 0; pass < 2; pass++) {         // pass 0: pre-activation copy (dual output only); pass 1: final values
+        for (int pass = 0; pass < 2; pass++) {         // pass 0: second output (dual-output flavours only); pass 1: final values
           if (pass == 0 && !dual) continue;
 #pragma unroll
           for (int jj = 0; jj < JW; jj++)
@@ -820,13 +825,9 @@ __global__ __launch_bounds__(512) void gemm_pers_kernel(GemmParams p) {
                   for (int e = 0; e < 4; e++) v[e] = gelu_tanh(v[e]);
                 } else if (act == 2 || act == 4) {
                   float a0, a1, a2, a3;
-                  unpack_bf16x2(ax[jj][q].x, a0, a1); unpack_bf16x2(ax[jj][q].y, a2, a3);
+                  unpack_bf16x2(ax[i & 1][jj][q].x, a0, a1); unpack_bf16x2(ax[i & 1][jj][q].y, a2, a3);
                   if (act == 2) { a0 = gelu_tanh_grad(a0); a1 = gelu_tanh_grad(a1); a2 = gelu_tanh_grad(a2); a3 = gelu_tanh_grad(a3); }
                   v[0] *= a0; v[1] *= a1; v[2] *= a2; v[3] *= a3;
-                }
-                if (want_cs && m < p.M) {
-#pragma unroll
-                  for (int e = 0; e < 4; e++) cs[jj][q * 4 + e] += v[e];
                 }
               }
               const int ch = jj * 4 + q;               // 16-byte chunk of the staging row
@@ -836,27 +837,31 @@ __global__ __launch_bounds__(512) void gemm_pers_kernel(GemmParams p) {
           __builtin_amdgcn_s_waitcnt(0xc07f);          // lgkmcnt(0): the slice is private to this wave
           bf16_t* dst = pass == 0 ? p.out2 : p.out;
 #pragma unroll
-          for (int t4 = 0; t4 < 4 / (3 - JW) ; t4++) {  // JW = 2: 4 x (8 rows x 128 B); JW = 1: 2 x (16 rows x 64 B)
-            constexpr int LPR = JW * 4, RPI = 64 / LPR;
+          for (int t4 = 0; t4 < NST; t4++) {
             const int row = t4 * RPI + lane / LPR, ch = lane % LPR;
             const int sw = JW == 2 ? (row & 7) : ((row >> 1) & 3);
             const uint4 v4 = *reinterpret_cast<const uint4*>(stg + row * RB + ((ch ^ sw) << 4));
             const int mm = mw + i * 32 + row, nn = nw + j0 * 32 + ch * 8;
             if (mm < p.M && nn < p.N) *reinterpret_cast<uint4*>(dst + (size_t)mm * p.ldo + nn) = v4;
+            if (pass == 1 && want_cs && mm < p.M) {
+              float f[8];
+              unpack_bf16x8(v4, f);
+#pragma unroll
+              for (int e = 0; e < 8; e++) cs[e] += f[e];
+            }
           }
           __builtin_amdgcn_s_waitcnt(0xc07f);          // reads returned before the slice is overwritten
         }
       }
-      if (want_cs) {                                   // column sums over this wave's rows: lane tree, one atomic per column and slot
+      if (want_cs) {                                   // lanes with the same chunk (lane % LPR) hold partial sums of the same 8 columns
 #pragma unroll
-        for (int jj = 0; jj < JW; jj++)
-#pragma unroll
-          for (int g = 0; g < 16; g++) {
-            float v = cs[jj][g];
-            v += __shfl_xor(v, 16); v += __shfl_xor(v, 8); v += __shfl_xor(v, 4); v += __shfl_xor(v, 2); v += __shfl_xor(v, 1);
-            const int n = nw + (j0 + jj) * 32 + 8 * (g >> 2) + 4 * hi + (g & 3);
-            if (srow == 0 && n < p.N) atomicAdd(p.colsum + (size_t)((mw >> 7) % PXA_COLSUM_SLOTS) * p.colsum_stride + n, v);
-          }
+        for (int e = 0; e < 8; e++) {
+          float v = cs[e];
+          if (LPR <= 4) v += __shfl_xor(v, 4);
+          v += __shfl_xor(v, 8); v += __shfl_xor(v, 16); v += __shfl_xor(v, 32);
+          const int n = nw + j0 * 32 + (lane % LPR) * 8 + e;
+          if (lane < LPR && n < p.N) atomicAdd(p.colsum + (size_t)((mw >> 7) % PXA_COLSUM_SLOTS) * p.colsum_stride + n, v);
+        }
       }
     };
 #pragma unroll

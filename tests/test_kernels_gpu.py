@@ -92,8 +92,8 @@ def test_gemm_persistent_kernel_epilogues(ops, M, N, K):
     part = torch.zeros(ops.COLSUM_SLOTS, N, device="cuda")
     out = ops.gemm(a, wt, ops.NN, act=ops.ACT_MUL_AUX, aux=aux, colsum=part)                   # backward of that path + bias-gradient sums
     assert rel_l2(out.float(), ref * aux.float()) < BF16_TOL
-    assert rel_l2(part.sum(0), out.float().sum(0)) < 2e-3       # sums of the fp32 values before the bf16 rounding of `out`
-    assert rel_l2(part.sum(0), (ref * aux.float()).sum(0)) < 1e-3
+    assert rel_l2(part.sum(0), out.float().sum(0)) < 1e-4       # the column sums are taken over exactly the bf16 values that are stored
+    assert rel_l2(part.sum(0), (ref * aux.float()).sum(0)) < 5e-3   # ... so they carry the bf16 rounding of the summands (2^-9 each)
     g = bf(pre)
     out = ops.gemm(a, wt, ops.NN, act=ops.ACT_GELU_GRAD, aux=g)
     gx = g.float().clone().requires_grad_(True)
