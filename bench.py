@@ -29,8 +29,8 @@ sys.path.insert(0, ROOT)
 D, H, DFF, DEPTH, LTXT = 1152, 16, 4608, 28, 300
 MFMA_PEAK = 2.5e15   # dense bf16, MI355X (MI355X_MICROARCH.md)
 # HBM bytes per launch of the dominant kernel (attn_bwd_dkv_kernel, self-attention B16 H16 N4096), from the PMC passes committed under
-# profiles/ (rocprofv3 cannot run inside the benchmark): 2 x 1,088,993 KB fetched + 160,055 KB written
-DKV_HBM_BYTES_PER_LAUNCH = 2 * 1088993.4e3 + 160055.3e3
+# profiles/r01_pmc_attention.txt (rocprofv3 cannot run inside the benchmark): 2 x 1,359,963 KB fetched + 296,308 KB written
+DKV_HBM_BYTES_PER_LAUNCH = 2 * 1359963.0e3 + 296308.2e3
 
 
 def fwd_flops_per_sample(N, L=LTXT, n_kv=None):
