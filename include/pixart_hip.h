@@ -79,6 +79,15 @@ int pxa_ln_mod_fwd(const float* x, const void* u_bf16, const float* gate, int ga
 int pxa_ln_mod_bwd(const void* dy_bf16, const float* x, const float* mean, const float* rstd, const float* scale, int mod_stride,
                    const float* dx_in, float* dx_out, void* dx_bf16, float* dshift, float* dscale, int dmod_stride,
                    int R, int D, int rows_per_batch, hipStream_t stream);
+
+/* q / k LayerNorm of AttentionKVCompress(qk_norm=True) (reference PixArt_blocks.py:90-92,133-134): nn.LayerNorm(D), affine, over bf16 rows
+ * with an element stride (the q / k column blocks of the qkv buffer, in place when y == x).  fwd also copies the un-normalised rows to
+ * xsave [R][D] (may be NULL) and writes fp32 mean / rstd [R]; bwd overwrites dy's rows with dx (dx may alias dy) and ADDS the weight / bias
+ * gradients into dw / db [D]. */
+int pxa_ln_affine_fwd(const void* x_bf16, long x_stride, const float* w, const float* b, void* y_bf16, long y_stride, void* xsave_bf16,
+                      float* mean, float* rstd, int R, int D, float eps, hipStream_t stream);
+int pxa_ln_affine_bwd(const void* dy_bf16, long dy_stride, const void* xsave_bf16, const float* mean, const float* rstd, const float* w,
+                      void* dx_bf16, long dx_stride, float* dw, float* db, int R, int D, hipStream_t stream);
 /* g = dx (+ add_bf16);  dx_out = g (optional);  du = gate*g (bf16; plain cast if gate NULL);  dgate[b] += sum g*u;
  * dbias[b % PXA_COLSUM_SLOTS][d] += sum_rows du (optional slotted partials: bias gradient of the Linear whose output gradient du is). */
 int pxa_gate_bwd(const float* dx, const void* add_bf16, const void* u_bf16, const float* gate, int mod_stride,

@@ -33,6 +33,10 @@ CASES = {
     "train_d2": (dict(depth=2, input_size=16, model_max_length=20, kv_sampling="conv", kv_scale_factor=2, kv_layers=(1,)),
                  dict(B=2, Hl=16, Wl=16, L=20, lens=[20, 9])),
     "train_d2_plain": (dict(depth=2, input_size=16, model_max_length=20), dict(B=2, Hl=16, Wl=24, L=20, lens=[20, 9])),
+    # qk_norm=True (off in every shipped config, but an option of AttentionKVCompress): forward with compressed K/V, and a training step
+    "fwd_d2_qknorm": (dict(depth=2, input_size=16, model_max_length=20, qk_norm=True, kv_sampling="conv", kv_scale_factor=2, kv_layers=(1,)),
+                      dict(B=2, Hl=16, Wl=16, L=20, lens=[20, 7])),
+    "train_d2_qknorm": (dict(depth=2, input_size=16, model_max_length=20, qk_norm=True), dict(B=2, Hl=16, Wl=16, L=20, lens=[20, 9])),
     "dpms_d2": (dict(depth=2, input_size=16, model_max_length=20), dict(B=2, Hl=16, Wl=16, L=20, lens=[20, 11])),
     # BASELINE.json configs[0]: XL/2 256px, batch 2, 2 DPM-Solver steps, CFG 4.5, random-init, CPU
     "cfg1_xl2_256": (dict(depth=28, input_size=32, model_max_length=300, pe_interpolation=0.5), dict(B=2, Hl=32, Wl=32, L=300, lens=[300, 77])),

@@ -273,6 +273,100 @@ __global__ __launch_bounds__(CS_CT * CS_RL) void colsum_kernel(const bf16_t* __r
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------ q / k LayerNorm (qk_norm=True)
+// nn.LayerNorm(dim) with affine weight/bias and eps 1e-5 over the full channel dimension, applied to the q and k column blocks
+// of the qkv GEMM output before compression / attention (reference PixArt_blocks.py:90-92,133-134).  bf16 rows in, bf16 rows out
+// (in place in the qkv buffer), statistics in fp32; the un-normalised rows are copied to `xsave` for the backward pass.
+template <int NV>
+__global__ __launch_bounds__(256) void ln_affine_fwd_kernel(const bf16_t* x, long x_stride, const float* __restrict__ w, const float* __restrict__ b,
+                                                            bf16_t* y, long y_stride, bf16_t* __restrict__ xsave, float* __restrict__ mean_out,
+                                                            float* __restrict__ rstd_out, int R, int D, float eps) {
+  const int hl = threadIdx.x & 31, row = blockIdx.x * 8 + (threadIdx.x >> 5);
+  if (row >= R) return;
+  float4 v[NV];
+  float s = 0.f;
+#pragma unroll
+  for (int j = 0; j < NV; j++) {
+    const int c = (hl + 32 * j) * 4;
+    const uint2 u = *reinterpret_cast<const uint2*>(x + (size_t)row * x_stride + c);
+    if (xsave) *reinterpret_cast<uint2*>(xsave + (size_t)row * D + c) = u;
+    unpack_bf16x2(u.x, v[j].x, v[j].y); unpack_bf16x2(u.y, v[j].z, v[j].w);
+    s += (v[j].x + v[j].y) + (v[j].z + v[j].w);
+  }
+  const float mean = half_wave_sum(s) / D;
+  float q = 0.f;
+#pragma unroll
+  for (int j = 0; j < NV; j++) {
+    const float a = v[j].x - mean, bb = v[j].y - mean, c = v[j].z - mean, d = v[j].w - mean;
+    q += (a * a + bb * bb) + (c * c + d * d);
+  }
+  const float rstd = rsqrtf(half_wave_sum(q) / D + eps);
+  if (hl == 0) { mean_out[row] = mean; rstd_out[row] = rstd; }
+#pragma unroll
+  for (int j = 0; j < NV; j++) {
+    const int c = (hl + 32 * j) * 4;
+    const float4 ww = *reinterpret_cast<const float4*>(w + c), bv = *reinterpret_cast<const float4*>(b + c);
+    *reinterpret_cast<uint2*>(y + (size_t)row * y_stride + c) =
+        pack_bf16x4((v[j].x - mean) * rstd * ww.x + bv.x, (v[j].y - mean) * rstd * ww.y + bv.y, (v[j].z - mean) * rstd * ww.z + bv.z,
+                    (v[j].w - mean) * rstd * ww.w + bv.w);
+  }
+}
+
+// dx = rstd (g - mean(g) - xhat mean(g xhat)),  g = dy w;   dw += sum_rows dy xhat,  db += sum_rows dy   (block-combined in LDS)
+template <int NV>
+__global__ __launch_bounds__(256) void ln_affine_bwd_kernel(const bf16_t* dy, long dy_stride, const bf16_t* __restrict__ xsave, const float* __restrict__ mean,
+                                                            const float* __restrict__ rstd, const float* __restrict__ w, bf16_t* dx, long dx_stride,
+                                                            float* __restrict__ dw, float* __restrict__ db, int R, int D) {
+  extern __shared__ float red[];                       // [2][D]
+  const int hl = threadIdx.x & 31;
+  const int chunk = blockIdx.x * 8 + (threadIdx.x >> 5);
+  const int r_beg = chunk * BWD_ROWS, r_end = min(R, r_beg + BWD_ROWS);
+  for (int i = threadIdx.x; i < 2 * D; i += 256) red[i] = 0.f;
+  __syncthreads();
+  float4 aw[NV], ab[NV];
+#pragma unroll
+  for (int j = 0; j < NV; j++) { aw[j] = make_float4(0, 0, 0, 0); ab[j] = make_float4(0, 0, 0, 0); }
+  for (int row = r_beg; row < r_end; row++) {
+    const float mu = mean[row], rs = rstd[row];
+    float4 g[NV], xh[NV];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < NV; j++) {
+      const int c = (hl + 32 * j) * 4;
+      const uint2 dd = *reinterpret_cast<const uint2*>(dy + (size_t)row * dy_stride + c);
+      const uint2 xx = *reinterpret_cast<const uint2*>(xsave + (size_t)row * D + c);
+      const float4 ww = *reinterpret_cast<const float4*>(w + c);
+      float d0, d1, d2, d3, x0, x1, x2, x3;
+      unpack_bf16x2(dd.x, d0, d1); unpack_bf16x2(dd.y, d2, d3);
+      unpack_bf16x2(xx.x, x0, x1); unpack_bf16x2(xx.y, x2, x3);
+      xh[j] = make_float4((x0 - mu) * rs, (x1 - mu) * rs, (x2 - mu) * rs, (x3 - mu) * rs);
+      ab[j].x += d0; ab[j].y += d1; ab[j].z += d2; ab[j].w += d3;
+      aw[j].x += d0 * xh[j].x; aw[j].y += d1 * xh[j].y; aw[j].z += d2 * xh[j].z; aw[j].w += d3 * xh[j].w;
+      g[j] = make_float4(d0 * ww.x, d1 * ww.y, d2 * ww.z, d3 * ww.w);
+      s1 += (g[j].x + g[j].y) + (g[j].z + g[j].w);
+      s2 += (g[j].x * xh[j].x + g[j].y * xh[j].y) + (g[j].z * xh[j].z + g[j].w * xh[j].w);
+    }
+    const float c1 = half_wave_sum(s1) / D, c2 = half_wave_sum(s2) / D;
+#pragma unroll
+    for (int j = 0; j < NV; j++) {
+      const int c = (hl + 32 * j) * 4;
+      *reinterpret_cast<uint2*>(dx + (size_t)row * dx_stride + c) =
+          pack_bf16x4(rs * (g[j].x - c1 - xh[j].x * c2), rs * (g[j].y - c1 - xh[j].y * c2), rs * (g[j].z - c1 - xh[j].z * c2),
+                      rs * (g[j].w - c1 - xh[j].w * c2));
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < NV; j++) {
+    float* pw = red + (hl + 32 * j) * 4;
+    float* pb = red + D + (hl + 32 * j) * 4;
+    atomicAdd(pw + 0, aw[j].x); atomicAdd(pw + 1, aw[j].y); atomicAdd(pw + 2, aw[j].z); atomicAdd(pw + 3, aw[j].w);
+    atomicAdd(pb + 0, ab[j].x); atomicAdd(pb + 1, ab[j].y); atomicAdd(pb + 2, ab[j].z); atomicAdd(pb + 3, ab[j].w);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < D; i += 256) { atomicAdd(dw + i, red[i]); atomicAdd(db + i, red[D + i]); }
+}
+
 #define DISPATCH_NV(D, CALL)                                            \
   switch ((D) / 128) {                                                  \
     case 9: { constexpr int NV = 9; CALL; } break;                      \
@@ -292,6 +386,28 @@ extern "C" int pxa_ln_mod_fwd(const float* x, const void* u_bf16, const float* g
   PXA_CHECK(!mean == !rstd, "pxa_ln_mod_fwd: mean/rstd must both be given or both null");
   DISPATCH_NV(D, hipLaunchKernelGGL(ln_mod_fwd_kernel<NV>, dim3((R + 7) / 8), dim3(256), 0, stream, x, (const bf16_t*)u_bf16, gate, shift, scale,
                                      mod_stride, gate_stride, x_out, (bf16_t*)xn_bf16, (bf16_t*)xb_bf16, mean, rstd, R, D, rows_per_batch, eps));
+  PXA_LAUNCH_CHECK();
+  return 0;
+}
+
+
+extern "C" int pxa_ln_affine_fwd(const void* x_bf16, long x_stride, const float* w, const float* b, void* y_bf16, long y_stride, void* xsave_bf16,
+                                 float* mean, float* rstd, int R, int D, float eps, hipStream_t stream) {
+  PXA_CHECK(x_bf16 && w && b && y_bf16 && mean && rstd, "pxa_ln_affine_fwd: null pointer");
+  PXA_CHECK(R > 0 && D % 128 == 0 && x_stride % 4 == 0 && y_stride % 4 == 0, "pxa_ln_affine_fwd: bad shape / strides");
+  DISPATCH_NV(D, hipLaunchKernelGGL(ln_affine_fwd_kernel<NV>, dim3((R + 7) / 8), dim3(256), 0, stream, (const bf16_t*)x_bf16, x_stride, w, b,
+                                     (bf16_t*)y_bf16, y_stride, (bf16_t*)xsave_bf16, mean, rstd, R, D, eps));
+  PXA_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int pxa_ln_affine_bwd(const void* dy_bf16, long dy_stride, const void* xsave_bf16, const float* mean, const float* rstd, const float* w,
+                                 void* dx_bf16, long dx_stride, float* dw, float* db, int R, int D, hipStream_t stream) {
+  PXA_CHECK(dy_bf16 && xsave_bf16 && mean && rstd && w && dx_bf16 && dw && db, "pxa_ln_affine_bwd: null pointer");
+  PXA_CHECK(R > 0 && D % 128 == 0 && dy_stride % 4 == 0 && dx_stride % 4 == 0, "pxa_ln_affine_bwd: bad shape / strides");
+  const int chunks = (R + BWD_ROWS - 1) / BWD_ROWS;
+  DISPATCH_NV(D, hipLaunchKernelGGL(ln_affine_bwd_kernel<NV>, dim3((chunks + 7) / 8), dim3(256), 2 * D * sizeof(float), stream, (const bf16_t*)dy_bf16, dy_stride,
+                                     (const bf16_t*)xsave_bf16, mean, rstd, w, (bf16_t*)dx_bf16, dx_stride, dw, db, R, D));
   PXA_LAUNCH_CHECK();
   return 0;
 }

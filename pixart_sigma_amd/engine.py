@@ -209,6 +209,10 @@ class Engine:
         r = ops.ln_mod_fwd(x_prev, sm, scm, st, u=u_prev, gate=gate_prev, gate_stride=st, rows_per_batch=N, want_stats=True)
         x_in, xn1, mean1, rstd1 = r["x"], r["xn"], r["mean"], r["rstd"]
         qkv = self._lin(xn1, p + "attn.qkv")
+        qkn = None
+        if c.get("qk_norm"):        # q_norm / k_norm on the full-resolution q, k column blocks, in place (PixArt_blocks.py:133-134)
+            qkn = (ops.ln_affine_fwd(qkv[:, :D], S.f(p + "attn.q_norm.weight"), S.f(p + "attn.q_norm.bias")),
+                   ops.ln_affine_fwd(qkv[:, D:2 * D], S.f(p + "attn.k_norm.weight"), S.f(p + "attn.k_norm.bias")))
         sr = c["kv_scale_factor"] if l in c["kv_layers"] else 1
         a = torch.empty((B * N, D), dtype=BF16, device=qkv.device)
         lse = torch.empty((B, H, N), dtype=F32, device=qkv.device)
@@ -258,7 +262,7 @@ class Engine:
         h = self._lin(xn2, p + "mlp.fc1", act=ops.ACT_GELU_SAVE_GRAD, out2=hpre)   # hpre holds GELU'(pre-activation), bf16
         u3 = self._lin(h, p + "mlp.fc2")
         saved = dict(x_in=x_in, mean1=mean1, rstd1=rstd1, xn1=xn1, qkv=qkv, a=a, lse=lse, u1=u1, x1b=x1b, qc=qc, kvc=kvc,
-                     cr=cr, lse_c=lse_c, x2=x2, mean2=mean2, rstd2=rstd2, xn2=xn2, hpre=hpre, h=h, u3=u3, kc=kc, vc=vc, sr=sr)
+                     cr=cr, lse_c=lse_c, x2=x2, mean2=mean2, rstd2=rstd2, xn2=xn2, hpre=hpre, h=h, u3=u3, kc=kc, vc=vc, sr=sr, qkn=qkn)
         return x2, u3, gl, saved
 
     def block_bwd(self, l, G, sv, ctx):
@@ -335,6 +339,10 @@ class Engine:
             else:
                 ops.kv_pick(dkc, dqkv[:, D:2 * D], N * 3 * D, 3 * D, B, hh, ww, D, sr, backward=True)
                 ops.kv_pick(dvc, dqkv[:, 2 * D:], N * 3 * D, 3 * D, B, hh, ww, D, sr, backward=True)
+        if sv.get("qkn") is not None:                        # back through q_norm / k_norm: dqkv's q, k blocks become d(raw q), d(raw k)
+            (qs, qm, qr), (ks_, km, kr) = sv["qkn"]
+            ops.ln_affine_bwd(dqkv[:, :D], qs, qm, qr, S.f(p + "attn.q_norm.weight"), S.g(p + "attn.q_norm.weight"), S.g(p + "attn.q_norm.bias"))
+            ops.ln_affine_bwd(dqkv[:, D:2 * D], ks_, km, kr, S.f(p + "attn.k_norm.weight"), S.g(p + "attn.k_norm.weight"), S.g(p + "attn.k_norm.bias"))
         # the attention kernels can also emit the q/k/v bias-gradient sums (pxa_attn_args.d*_colsum), but the cross-lane row
         # reductions cost them more (~0.5 ms/block) than one streaming column-sum pass over dqkv (~0.2 ms/block): measured, not used
         dxn = self._lin_bwd(dqkv, sv["xn1"], p + "attn.qkv")

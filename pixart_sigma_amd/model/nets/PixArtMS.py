@@ -98,8 +98,10 @@ class AttentionKVCompress(nn.Module):  # PixArt_blocks.py:61-95
             self.sr.weight.data.fill_(1 / sr_ratio ** 2)
             self.sr.bias.data.zero_()
             self.norm = nn.LayerNorm(dim)
-        if qk_norm:
-            raise NotImplementedError("qk_norm=True is not implemented on the HIP path (off in every reference config)")
+        self.qk_norm = bool(qk_norm)
+        if qk_norm:                                       # PixArt_blocks.py:90-92 (parameter containers; the HIP path runs pxa_ln_affine_*)
+            self.q_norm = nn.LayerNorm(dim)
+            self.k_norm = nn.LayerNorm(dim)
 
 
 class MultiHeadCrossAttention(nn.Module):  # PixArt_blocks.py:28-41
@@ -203,7 +205,7 @@ class PixArtMSBlock(nn.Module):
             store = ParamStore(named, dev)
             a = self.attn
             cfg = dict(hidden_size=self.hidden_size, num_heads=self.num_heads, depth=1, kv_sampling=a.sampling,
-                       kv_scale_factor=a.sr_ratio, kv_layers=(0,) if a.sr_ratio > 1 else ())
+                       kv_scale_factor=a.sr_ratio, kv_layers=(0,) if a.sr_ratio > 1 else (), qk_norm=a.qk_norm)
             self._standalone = Engine(store, cfg)
         self._standalone.S.refresh_shadow()
         return self._standalone
@@ -338,7 +340,8 @@ class PixArtMS(nn.Module):
             kvc = self.kv_compress_config
             cfg = dict(hidden_size=self.hidden_size, num_heads=self.num_heads, depth=self.depth, pe_interpolation=self.pe_interpolation,
                        base_size=self.base_size, out_channels=self.out_channels, kv_sampling=kvc["sampling"],
-                       kv_scale_factor=int(kvc["scale_factor"]), kv_layers=tuple(kvc["kv_compress_layer"]))
+                       kv_scale_factor=int(kvc["scale_factor"]), kv_layers=tuple(kvc["kv_compress_layer"]),
+                       qk_norm=self.blocks[0].attn.qk_norm)
             self._engine = Engine(self._store, cfg)
             self._anchor = torch.zeros(1, device=device, requires_grad=True)
         self._store.refresh_shadow()

@@ -98,6 +98,25 @@ def ln_mod_bwd(dy, x, mean, rstd, scale, mod_stride, dx_in, dx_out, dshift, dsca
     return dx_out
 
 
+def ln_affine_fwd(x, w, b, eps=1e-5, save=True):
+    """nn.LayerNorm(D) (affine) over bf16 rows, IN PLACE on the (possibly column-sliced) 2-D view x; returns (xsave, mean, rstd)."""
+    _chk(x, BF16, "x"); _chk(w, F32, "w"); _chk(b, F32, "b")
+    R, D = x.shape
+    assert x.stride(1) == 1
+    xsave = torch.empty((R, D), dtype=BF16, device=x.device) if save else None
+    mean, rstd = torch.empty(R, dtype=F32, device=x.device), torch.empty(R, dtype=F32, device=x.device)
+    call("pxa_ln_affine_fwd", ptr(x), x.stride(0), ptr(w), ptr(b), ptr(x), x.stride(0), ptr(xsave), ptr(mean), ptr(rstd), R, D, float(eps))
+    return xsave, mean, rstd
+
+
+def ln_affine_bwd(dy, xsave, mean, rstd, w, dw, db):
+    """Backward of ln_affine_fwd, IN PLACE on the 2-D view dy (dy <- dx); dw / db (fp32 [D]) are accumulated into."""
+    _chk(dy, BF16, "dy"); _chk(xsave, BF16, "xsave")
+    R, D = dy.shape
+    assert dy.stride(1) == 1 and xsave.is_contiguous()
+    call("pxa_ln_affine_bwd", ptr(dy), dy.stride(0), ptr(xsave), ptr(mean), ptr(rstd), ptr(w), ptr(dy), dy.stride(0), ptr(dw), ptr(db), R, D)
+
+
 def gate_bwd(dx, add=None, u=None, gate=None, mod_stride=0, dx_out=None, du=None, dgate=None, dmod_stride=0, rows_per_batch=None, dbias=None):
     R, D = dx.shape
     call("pxa_gate_bwd", ptr(dx), ptr(add), ptr(u), ptr(gate), mod_stride, ptr(dx_out), ptr(du), ptr(dgate), dmod_stride, ptr(dbias),

@@ -169,6 +169,28 @@ def test_ln_mod_bwd(ops, B, N):
     assert dmod[:, 2:].abs().max() == 0
 
 
+def test_ln_affine_fwd_bwd(ops):
+    """q / k LayerNorm of qk_norm=True: affine nn.LayerNorm(1152, eps 1e-5) in place on a column block of a wider bf16 buffer."""
+    R, D = 300, 1152
+    buf = bf(rnd(R, 3 * D, seed=1))
+    x = buf[:, D:2 * D].float().clone()
+    w, b = 1 + 0.1 * rnd(D, seed=2), 0.1 * rnd(D, seed=3)
+    xr, wr, br = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    y = F.layer_norm(xr, (D,), wr, br, eps=1e-5)
+    dy = bf(rnd(R, D, seed=4))
+    y.backward(dy.float())
+    keep = buf.clone()
+    xs, mean, rstd = ops.ln_affine_fwd(buf[:, D:2 * D], w, b)
+    assert rel_l2(buf[:, D:2 * D].float(), y.detach()) < BF16_TOL and torch.equal(xs, keep[:, D:2 * D])
+    assert torch.equal(buf[:, :D], keep[:, :D]) and torch.equal(buf[:, 2 * D:], keep[:, 2 * D:])     # neighbours untouched
+    dbuf = torch.zeros(R, 3 * D, dtype=torch.bfloat16, device="cuda")
+    dbuf[:, D:2 * D] = dy
+    dw, db = torch.ones(D, device="cuda"), torch.ones(D, device="cuda")
+    ops.ln_affine_bwd(dbuf[:, D:2 * D], xs, mean, rstd, w, dw, db)
+    assert rel_l2(dbuf[:, D:2 * D].float(), xr.grad) < BF16_TOL
+    assert rel_l2(dw - 1, wr.grad) < 1e-4 and rel_l2(db - 1, br.grad) < 1e-4
+
+
 @pytest.mark.parametrize("B,N", [(2, 40), (2, 256), (3, 128)])
 def test_gate_bwd_and_colsum(ops, B, N):
     D = 1152
