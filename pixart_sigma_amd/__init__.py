@@ -6,4 +6,4 @@ calls hand-written HIP kernels through the C ABI in include/pixart_hip.h (libpix
 """
 from .diffusion import DPMS, IDDPM  # noqa: F401
 from .model import MODELS, build_model  # noqa: F401
-from .model.nets import PixArtMS, PixArtMS_XL_2, PixArtMSBlock  # noqa: F401
+from .model.nets import PixArt, PixArt_XL_2, PixArtBlock, PixArtMS, PixArtMS_XL_2, PixArtMSBlock  # noqa: F401

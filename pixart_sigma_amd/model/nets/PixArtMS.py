@@ -413,3 +413,55 @@ class PixArtMS(nn.Module):
 @MODELS.register_module()
 def PixArtMS_XL_2(**kwargs):
     return PixArtMS(depth=28, hidden_size=1152, patch_size=2, num_heads=16, **kwargs)
+
+
+# ----------------------------------------------------------------------------- fixed-resolution registry names (PixArt.py:25-56,62-143,313-315)
+class PixArtBlock(PixArtMSBlock):
+    """PixArt.py:25-56 — the same adaLN-single block; its forward takes no HW (square token grid)."""
+
+    def forward(self, x, y, t, mask=None, **kwargs):
+        return super().forward(x, y, t, mask=mask, HW=None)
+
+
+@MODELS.register_module()
+class PixArt(PixArtMS):
+    """Fixed-resolution PixArt (PixArt.py:62-143): one square latent size, `pos_embed` is a real (persistent) buffer of the
+    state dict, `pred_sigma` alone decides the output channels, no micro-conditioning.  Runs on the same engine as PixArtMS —
+    the position table the engine builds for the (input_size/2)² grid equals this buffer (`tests/test_host_logic.py`)."""
+
+    def __init__(self, input_size=32, patch_size=2, in_channels=4, hidden_size=1152, depth=28, num_heads=16, mlp_ratio=4.0,
+                 class_dropout_prob=0.1, pred_sigma=True, drop_path: float = 0.0, caption_channels=4096, pe_interpolation=1.0,
+                 config=None, model_max_length=120, qk_norm=False, kv_compress_config=None, **kwargs):
+        kwargs.pop("learn_sigma", None)
+        kwargs.pop("micro_condition", None)
+        super().__init__(input_size=input_size, patch_size=patch_size, in_channels=in_channels, hidden_size=hidden_size, depth=depth,
+                         num_heads=num_heads, mlp_ratio=mlp_ratio, class_dropout_prob=class_dropout_prob, learn_sigma=pred_sigma,
+                         pred_sigma=pred_sigma, drop_path=drop_path, caption_channels=caption_channels,
+                         pe_interpolation=pe_interpolation, config=config, model_max_length=model_max_length, micro_condition=False,
+                         qk_norm=qk_norm, kv_compress_config=kv_compress_config, **kwargs)
+        self.input_size = input_size
+        from ...engine import sincos_pos_embed
+        g = input_size // patch_size
+        self.pos_embed.data.copy_(torch.from_numpy(sincos_pos_embed(hidden_size, g, g, pe_interpolation, self.base_size)).float().unsqueeze(0))
+
+    def load_state_dict(self, state_dict, strict=True, **kw):
+        return nn.Module.load_state_dict(self, state_dict, strict=strict, **kw)      # pos_embed is part of this class's wire format
+
+    def forward(self, x, timestep, y, mask=None, data_info=None, **kwargs):
+        assert x.shape[-1] == x.shape[-2] == self.input_size, f"PixArt is fixed-resolution: expected a {self.input_size}x{self.input_size} latent"
+        return super().forward(x, timestep, y, mask=mask, data_info=None, **kwargs)
+
+    def forward_with_dpmsolver(self, x, timestep, y, mask=None, **kwargs):
+        """PixArt.py:114-120."""
+        kwargs.pop("data_info", None)
+        return self.forward(x, timestep, y, mask=mask, **kwargs).chunk(2, dim=1)[0]
+
+    def forward_with_cfg(self, x, timestep, y, cfg_scale, mask=None, **kwargs):
+        """PixArt.py:122-135."""
+        kwargs.pop("data_info", None)
+        return PixArtMS.forward_with_cfg(self, x, timestep, y, cfg_scale, None, mask=mask, **kwargs)
+
+
+@MODELS.register_module()
+def PixArt_XL_2(**kwargs):
+    return PixArt(depth=28, hidden_size=1152, patch_size=2, num_heads=16, **kwargs)

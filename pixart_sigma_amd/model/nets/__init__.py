@@ -1,1 +1,1 @@
-from .PixArtMS import PixArtMS, PixArtMS_XL_2, PixArtMSBlock  # noqa: F401
+from .PixArtMS import PixArt, PixArt_XL_2, PixArtBlock, PixArtMS, PixArtMS_XL_2, PixArtMSBlock  # noqa: F401

@@ -77,6 +77,26 @@ def test_registry_and_state_dict_keys_match_reference():
     assert torch.all(m2.blocks[0].attn.sr.weight == 0.25)
 
 
+def test_fixed_resolution_pixart_class_and_qk_norm_keys(golden):
+    """PixArt / PixArt_XL_2 registry names (PixArt.py:62,313): pos_embed is a real buffer of the wire format and equals the
+    reference's table; qk_norm adds q_norm / k_norm LayerNorm parameters (PixArt_blocks.py:90-92)."""
+    from pixart_sigma_amd import MODELS, build_model
+    assert MODELS.get("PixArt") is not None and MODELS.get("PixArt_XL_2") is not None
+    m = build_model("PixArt", depth=1, hidden_size=1152, num_heads=16, input_size=32, pe_interpolation=0.5, model_max_length=20, qk_norm=True)
+    ref = golden("tables")["pos"][(16, 16, 0.5, 16)]
+    assert np.array_equal(m.pos_embed[0].numpy().astype(np.float32)[:: max(1, 256 // 37)], ref.numpy().astype(np.float32))
+    cfg = po.OracleCfg(depth=1, input_size=32, model_max_length=20, qk_norm=True)
+    want = {k: tuple(s) for k, s in param_shapes(cfg).items()}
+    want["pos_embed"] = (1, 256, 1152)
+    assert {k: tuple(v.shape) for k, v in m.state_dict().items()} == want
+    sd = make_state_dict(cfg, seed=0)
+    with pytest.raises(RuntimeError):
+        m.load_state_dict(sd)                      # this class's wire format includes pos_embed
+    sd["pos_embed"] = m.pos_embed.clone()
+    m.load_state_dict(sd)
+    assert m.out_channels == 8 and build_model("PixArt", depth=1, hidden_size=1152, num_heads=16, pred_sigma=False).out_channels == 4
+
+
 def test_xl2_parameter_count():
     from pixart_sigma_amd.model.nets import PixArtMS
     with torch.device("meta"):

@@ -54,6 +54,26 @@ def test_forward_matches_reference_and_oracle(golden, name):
     assert e_f32 < FWD_F32_TOL
 
 
+def test_fixed_resolution_pixart_forward(golden):
+    """The `PixArt` registry class (PixArt.py:62-143) on a square latent equals PixArtMS on the same weights (golden fwd_d2_sq)."""
+    from pixart_sigma_amd import build_model
+    g = golden("fwd_d2_sq")
+    cfg = po.OracleCfg(**g["cfg"])
+    sd = make_state_dict(cfg, seed=g["weights_seed"])
+    inp = make_inputs(seed=g["inputs_seed"], **g["inputs"])
+    m = build_model("PixArt", depth=cfg.depth, hidden_size=1152, num_heads=16, input_size=cfg.input_size, pe_interpolation=cfg.pe_interpolation,
+                    model_max_length=cfg.model_max_length, class_dropout_prob=0.0)
+    sd["pos_embed"] = m.pos_embed.clone()
+    m.load_state_dict(sd)
+    m = m.cuda().eval()
+    with torch.no_grad():
+        y = m(inp["x"].cuda(), inp["t"].cuda(), inp["y"].cuda(), mask=inp["mask"].cuda()).cpu()
+        eps = m.forward_with_dpmsolver(inp["x"].cuda(), inp["t"].cuda(), inp["y"].cuda(), mask=inp["mask"].cuda()).cpu()
+    assert rel_l2(y, g["y"]) < FWD_F32_TOL and torch.equal(eps, y[:, :4])
+    with pytest.raises(AssertionError):
+        m(inp["x"][..., :8].cuda(), inp["t"].cuda(), inp["y"].cuda())
+
+
 @pytest.mark.parametrize("gname", ["train_d2_plain", "train_d2", "train_d2_qknorm"])
 def test_training_step_loss_and_grads(golden, gname):
     """train_d2 has KV compression ('conv', x2) on block 1: exercises kv_compress_bwd and the shared sr/norm gradients."""
