@@ -154,6 +154,7 @@ class Engine:
     def __init__(self, store, cfg):
         self.S, self.cfg = store, cfg
         self._pos_cache = {}
+        self._len_cache = {}
         self.grad_ready_hook = None   # callable(prefix) fired when a parameter group's gradients are complete
 
     # ------------------------------------------------------------------ helpers
@@ -360,9 +361,14 @@ class Engine:
         h, w = Hl // 2, Wl // 2
         N, D, depth = h * w, c["hidden_size"], c["depth"]
         dev = x.device
-        kv_len = torch.tensor(lens, dtype=torch.int32, device=dev)
-        starts = np.concatenate([[0], np.cumsum(lens)[:-1]]).astype(np.int32)
-        ctx = dict(B=B, N=N, hw=(h, w), mod=mod, kv_len=kv_len, kv_start=torch.from_numpy(starts).to(dev), max_len=int(max(lens)))
+        lk = tuple(int(v) for v in lens)
+        if lk not in self._len_cache:                        # per-sample text lengths -> device index tensors, uploaded once per distinct set
+            if len(self._len_cache) > 64:
+                self._len_cache.clear()
+            starts = np.concatenate([[0], np.cumsum(lens)[:-1]]).astype(np.int32)
+            self._len_cache[lk] = (torch.tensor(lens, dtype=torch.int32, device=dev), torch.from_numpy(starts).to(dev))
+        kv_len, kv_start = self._len_cache[lk]
+        ctx = dict(B=B, N=N, hw=(h, w), mod=mod, kv_len=kv_len, kv_start=kv_start, max_len=int(max(lens)))
         L = y.shape[0] // B
         ye, cap_saved = self.caption_fwd(y, row_idx, L, drop, y_null)
         ctx["ye"] = ye

@@ -264,6 +264,7 @@ class PixArtMS(nn.Module):
         self.final_layer = T2IFinalLayer(hidden_size, patch_size, self.out_channels)
         self._store = self._engine = None
         self._anchor = None
+        self._mask_cache = {}
         self.initialize()
 
     # ---- reference init scheme (PixArtMS.py:250-285)
@@ -374,8 +375,17 @@ class PixArtMS(nn.Module):
             if m.shape[0] != bs:
                 m = m.repeat(bs // m.shape[0], 1)
             m = (m != 0)
-            lens = m.sum(dim=1).tolist()                                                 # same host sync as PixArtMS.py:201
-            row_idx = m.flatten().nonzero().flatten().to(device=dev, dtype=torch.int32)
+            key = (tuple(m.shape), m.numpy().tobytes()) if not m.is_cuda else None       # host mask: no sync, and the index tensors
+            hit = self._mask_cache.get(key) if key is not None else None                 # are built / uploaded once per distinct mask
+            if hit is None:                                                              # (lets a sampling loop be captured in a graph)
+                lens = m.sum(dim=1).tolist()                                             # device mask: same host sync as PixArtMS.py:201
+                row_idx = m.flatten().nonzero().flatten().to(device=dev, dtype=torch.int32)
+                if key is not None:
+                    if len(self._mask_cache) > 64:
+                        self._mask_cache.clear()
+                    self._mask_cache[key] = (lens, row_idx)
+            else:
+                lens, row_idx = hit
         else:
             lens = [L] * bs
             row_idx = torch.arange(bs * L, device=dev, dtype=torch.int32)
