@@ -578,64 +578,92 @@ __device__ __forceinline__ void wait_vm_upto(int n) {      // n (wave-uniform) i
 // 32 rows at a time through its private staging slice into full-row 16-byte stores - which are fire-and-forget - and waits once
 // (vmcnt(0): its stores and the prefetched units) before the next main loop.  Store drain and operand latency of consecutive
 // tiles overlap; bias / GELU / GELU' / second (pre-activation) output / bias-gradient column sums all ride in that epilogue.
-// Geometry: TBM x TBN block tile (TBM / 64 even), 8 waves as 2 (m) x 4 (n), wave tile (TBM/2) x (TBN/4); instantiated at 256 x 256.
-// (A 192 x 384 tile - same 128 FLOP per operand byte, divides every DiT width so N = 1152 would not waste 10 % of a 256-wide
-// tiling - was measured 5-20 % SLOWER: 144 accumulators leave the epilogue spilling and its phases must split k, not rows.)
-// A k-unit is (TBM + TBN) / 16 one-KiB DMA pieces (A rows first, then B); wave w owns pieces w, w + 8, ...: the first two are
-// issued in phase b of unit u - 3, the rest in phase a of unit u - 2.
-template <bool KC, int ROWS, int BKT>
-__device__ __forceinline__ const bf16_t* piece_ptr(const bf16_t* __restrict__ X, int ld, int r0, int R, int q) {   // q: 16-byte chunk index in the LDS image
+// Geometry: 256 x 256 block tile, 8 waves as 2 (m) x 4 (n), wave tile 128 x 64.  (A 192 x 384 tile - same 128 FLOP per operand
+// byte, divides every DiT width - was measured 5-20 % SLOWER: 144 accumulators leave the epilogue spilling and its phases must
+// split k, not rows.)  A k-unit is 32-40 one-KiB DMA pieces; wave w owns pieces w, w + 8, ...: the first two are issued in phase b
+// of unit u - 3, the rest in phase a of unit u - 2.
+// Half-width remainder columns (N = 1152 = 4.5 x 256: every projection back to the model width) are not padded to a fifth tile
+// column that wastes half its MFMAs: the remainder columns of TWO consecutive m-tiles form one "paired" item - 512 rows x 128
+// columns, the same 65,536 outputs, the same 128 x 64 per wave (waves wn = 0,1 take the first m-tile, wn = 2,3 the second) - whose
+// k-unit is 32 A pieces + 8 B pieces (40 KiB, hence the 40 KiB ring slots).
+template <bool KC>
+__device__ __forceinline__ const bf16_t* piece_ptr_rt(const bf16_t* __restrict__ X, int ld, int r0a, int r0b, int R, int q, int rows_log2) {
+  // q: 16-byte chunk index in the LDS image of one operand of a k-unit; image rows/columns [0, 256) come from r0a, [256, 512) from r0b
   if constexpr (KC) {
-    static_assert(BKT == 32, "k-contiguous image: 64-byte rows");
     const int row = q >> 2, c = (q & 3) ^ ((row >> 2) & 3);
-    return X + (size_t)min(r0 + row, R - 1) * ld + c * 8;
+    const int gr = (row < 256 ? r0a : r0b - 256) + row;
+    return X + (size_t)min(gr, R - 1) * ld + c * 8;
   } else {
-    constexpr int CPR = ROWS / 8;
-    static_assert(ROWS % 128 == 0, "k-strided image: the 64-byte block XOR needs 4 | blocks per row");
-    const int kr = q / CPR, cl = q % CPR, c = ((((cl >> 2) ^ (kr & 3)) << 2) | (cl & 3));
-    int gc = r0 + c * 8;
+    const int sh = rows_log2 - 3, kr = q >> sh, cl = q & ((1 << sh) - 1), c = ((((cl >> 2) ^ (kr & 3)) << 2) | (cl & 3));
+    const int col = c * 8;
+    int gc = (col < 256 ? r0a : r0b - 256) + col;
     gc = gc < R ? gc : 0;
     return X + (size_t)kr * ld + gc;
+  }
+}
+template <bool KC>
+__device__ __forceinline__ bf16x8 frag_rt(const char* lds, int rbase, int ks, int lane, int rows_log2) {
+  if constexpr (KC) {
+    return frag_p<true, 256, 32>(lds, rbase, ks, lane);           // 64-byte rows whatever the row count
+  } else {
+    const int gg = lane >> 4, tt = lane & 15, hi2 = gg >> 1;
+    const int kr = ks * 16 + 8 * hi2 + (tt >> 2), col = rbase + 16 * (gg & 1) + (tt & 3) * 4;
+    const int blk = col >> 5, inblk = (col & 31) * 2;
+    const char* p0 = lds + (kr << (rows_log2 + 1)) + ((blk ^ (kr & 3)) << 6) + inblk;
+    const char* p1 = lds + ((kr + 4) << (rows_log2 + 1)) + ((blk ^ ((kr + 4) & 3)) << 6) + inblk;
+    return concat_tr(lds_tr_read(p0), lds_tr_read(p1));
   }
 }
 
 // EPI (bf16 epilogue flavour, compiled separately so that none carries the others' registers - the epilogue runs with all
 // 128 accumulators live and spills at the slightest extra state): 0 = (+bias), 1 = act 3 (bias + GELU, GELU' as the second
 // output), 2 = act 4 (x aux) + bias-gradient column sums, 3 = everything decided at run time (acts 1 / 2 and odd mixes).
-template <int LAYOUT, int TBM, int TBN, int EPI>
+// PAIR: compile the paired-remainder path in.  Only the fp32 weight-gradient launches use it: with split-K their item count is
+// free to fill the CUs, so the saved half tile is saved time (dW of qkv / fc1: -12 %); the bf16 NT / NN GEMMs run whole rounds of
+// 256 items either way (4.5 rounds of work still take 5) and the run-time geometry costs them 3 %, so they compile it out.
+template <int LAYOUT, int EPI, bool PAIR>
 __global__ __launch_bounds__(512) void gemm_pers_kernel(GemmParams p) {
   constexpr bool A_KC = (LAYOUT != 2), B_KC = (LAYOUT == 0);
-  constexpr int WN = 4, NW = 8, TM = TBM / 64, TN = TBN / 128, BKT = 32;
-  static_assert(TM % 2 == 0, "the two phases of a k-unit split the wave's row tiles");
-  constexpr int PA = TBM / 16, PB = TBN / 16, NPIECE = PA + PB;      // 1 KiB DMA pieces per k-unit
-  constexpr int NP_LO = NPIECE / NW, NP_X = NPIECE % NW, NPMAX = NP_LO + (NP_X ? 1 : 0), H1 = 2;
-  constexpr int A_BYTES = PA * 1024, UNIT = NPIECE * 1024;
-  static_assert(NP_LO > H1, "piece split");
+  constexpr int NW = 8, TM = 4, TN = 2, TH = 2, BKT = 32, H1 = 2;
+  constexpr int UNIT = 40960;                          // ring slot: A image at 0 (16 KiB; 32 KiB paired), B image behind it (16 KiB; 8 KiB paired)
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), wm = wave / WN, wn = wave % WN, hi = lane >> 5;
-  const bool late = wave >= NW / 2, extra = wave < NP_X;
-  // epilogue staging: 4 KiB per wave inside ring slot 3, which the next tile's prefetch (slots 0, 1 and part of 2) leaves alone
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), wm = wave >> 2, wn = wave & 3, hi = lane >> 5;
+  const bool late = wave >= NW / 2;
+  // epilogue staging: 4 KiB per wave inside ring slot 3, which the next item's prefetch (slots 0, 1 and part of 2) leaves alone
   // until every wave has passed the barrier that opens the next main loop
   char* stg = smem + 3 * UNIT + wave * 4096;
-  static_assert(8 * 4096 <= UNIT, "staging must fit one ring slot");
-  // work items: output tile x k-slice (split-K only for the fp32 weight-gradient layout), walked in the XCD-aware order
-  const int mt = (p.M + TBM - 1) / TBM, nt = (p.N + TBN - 1) / TBN, T = mt * nt * p.split;
+  // work items: output tile (or paired half-width tile) x k-slice (split-K only for the fp32 weight-gradient layout), XCD-aware order
+  const int mt = (p.M + 255) / 256, ntf = p.N / 256, remn = p.N - ntf * 256;
+  const bool pairing = PAIR && remn > 0 && remn <= 128 && (mt % 2 == 0);
+  const int ntp = pairing ? ntf : (p.N + 255) / 256;   // n-tile columns handled as (possibly padded) full tiles
+  const int per_group = 8 * ntp + (pairing ? 4 : 0), tiles = mt * ntp + (pairing ? mt / 2 : 0), T = tiles * p.split;
   auto units_of = [&](int z) { return (min(p.K, (z + 1) * p.k_per_split) - z * p.k_per_split) / BKT; };   // >= 2: k ranges are multiples of 64
 
-  int tm_, tn_, z_;
+  // current / prefetched item: row origins of the (two) A row blocks, column origin, paired flag, k-slice
+  int m0a = 0, m0b = 0, n0 = 0, z_ = 0;
+  bool vt = false;
+  auto locate = [&](int L) {                           // logical item -> coordinates: workgroup b runs on XCD b % 8, every XCD owns a
+    const int q = T / 8, r = T % 8, x = L % 8, idx = L / 8;   // contiguous range of the grouped (8 m-tiles) order, k-slice major
+    const int Lg = x * q + min(x, r) + idx;
+    z_ = Lg / tiles;
+    const int t = Lg - z_ * tiles;
+    const int g = t / per_group, in_g = t - g * per_group, first_m = g * 8, gsz = min(mt - first_m, 8), nfull = gsz * ntp;
+    if (in_g < nfull) { vt = false; m0a = (first_m + in_g % gsz) * 256; m0b = m0a; n0 = (in_g / gsz) * 256; }
+    else if (PAIR) { vt = true; m0a = (first_m + 2 * (in_g - nfull)) * 256; m0b = m0a + 256; n0 = ntf * 256; }
+  };
   int L = blockIdx.x;
-  tile_coords(L, mt, nt, p.split, tm_, tn_, z_);
-  int m0 = tm_ * TBM, n0 = tn_ * TBN, nk = units_of(z_), nk_pf = nk;   // nk_pf: units of the item being prefetched
-  // running source pointers of this wave's DMA pieces and their per-unit strides (elements)
-  const bf16_t* pp[NPMAX];
-  long st[NPMAX];
+  locate(L);
+  int nk = units_of(z_), nk_pf = nk;                   // nk_pf: units of the item being prefetched
+  // running source pointers, per-unit strides (elements) and LDS offsets of this wave's (up to) 5 DMA pieces per k-unit
+  const bf16_t* pp[5];
+  long st[5];
+  int dof[5];
   const long stepA = A_KC ? BKT : (long)BKT * p.lda, stepB = B_KC ? BKT : (long)BKT * p.ldb;
-#pragma unroll
-  for (int i = 0; i < NPMAX; i++) st[i] = (wave + NW * i < PA) ? stepA : stepB;
   int s_lo = 0, s_hi = 0;                              // ring slots of the next first-half / second-half issue
+  bool vt_pf = false;                                  // paired flag of the item whose DMA is being issued
   auto piece = [&](int i, int slot) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)pp[i],
-                                     (__attribute__((address_space(3))) void*)(smem + slot * UNIT + (wave + NW * i) * 1024), 16, 0, 0);
+                                     (__attribute__((address_space(3))) void*)(smem + slot * UNIT + dof[i]), 16, 0, 0);
     pp[i] += st[i];
   };
   auto issue_lo = [&]() {
@@ -644,18 +672,26 @@ __global__ __launch_bounds__(512) void gemm_pers_kernel(GemmParams p) {
     s_lo = (s_lo + 1) & 3;
   };
   auto issue_hi = [&]() {
-#pragma unroll
-    for (int i = H1; i < NP_LO; i++) piece(i, s_hi);
-    if (NP_X && extra) piece(NPMAX - 1, s_hi);
+    piece(2, s_hi); piece(3, s_hi);
+    if (vt_pf) piece(4, s_hi);
     s_hi = (s_hi + 1) & 3;
   };
-  auto prefetch = [&]() {                              // units 0, 1 and the first half of unit 2 of the tile at (m0, n0)
+  auto prefetch = [&]() {                              // units 0, 1 and the first half of unit 2 of the item at (m0a, m0b, n0, z_)
+    vt_pf = PAIR && vt;
+    const long k0 = (long)z_ * p.k_per_split;
+    const bool vq = PAIR && vt;
+    const int rla = vq ? 9 : 8, rlb = vq ? 7 : 8;      // log2 of the A / B image row (column) counts
 #pragma unroll
-    for (int i = 0; i < NPMAX; i++) {
-      const int pc = wave + NW * i;
-      const long k0 = (long)z_ * p.k_per_split;
-      if (pc < PA) pp[i] = piece_ptr<A_KC, TBM, BKT>(p.A, p.lda, m0, p.M, pc * 64 + lane) + (A_KC ? k0 : k0 * p.lda);
-      else if (pc < NPIECE) pp[i] = piece_ptr<B_KC, TBN, BKT>(p.B, p.ldb, n0, p.N, (pc - PA) * 64 + lane) + (B_KC ? k0 : k0 * p.ldb);
+    for (int i = 0; i < 5; i++) {
+      const int id = wave + NW * i;                    // full tile: 16 A + 16 B pieces; paired: 32 A + 8 B
+      const bool is_a = vq ? (i < 4) : (i < 2);
+      const int pid = is_a ? id : (vq ? id - 32 : id - 16);
+      if (i < 4 || vq) {
+        if (is_a) pp[i] = piece_ptr_rt<A_KC>(p.A, p.lda, m0a, m0b, p.M, pid * 64 + lane, rla) + (A_KC ? k0 : k0 * p.lda);
+        else pp[i] = piece_ptr_rt<B_KC>(p.B, p.ldb, n0, n0, p.N, pid * 64 + lane, rlb) + (B_KC ? k0 : k0 * p.ldb);
+      }
+      st[i] = is_a ? stepA : stepB;
+      dof[i] = (is_a ? 0 : (vq ? 32768 : 16384)) + pid * 1024;
     }
     s_lo = s_hi = 0;
     issue_lo(); issue_hi(); issue_lo(); issue_hi();
@@ -671,47 +707,50 @@ __global__ __launch_bounds__(512) void gemm_pers_kernel(GemmParams p) {
       for (int j = 0; j < TN; j++)
 #pragma unroll
         for (int g = 0; g < 16; g++) acc[i][j][g] = 0.f;
-    wait_vmcnt<0>();                                   // this tile's first units have landed; last tile's stores are out
+    // this item's fragment geometry (the prefetch of the next item will overwrite vt / m0a / ...)
+    const bool vtc = PAIR && vt;
+    const int a_rb = (vtc ? (wn >> 1) * 256 : 0) + wm * 128, b_rb = vtc ? (wn & 1) * 64 : wn * 64;
+    const int rla = vtc ? 9 : 8, rlb = vtc ? 7 : 8, boff = vtc ? 32768 : 16384;
+    const int mw = ((vtc && (wn >> 1)) ? m0b : m0a) + wm * 128, nw = n0 + b_rb;   // this wave's output origin
+    const int zw = z_;                                  // this item's k-slice (fp32 slab index)
+    wait_vmcnt<0>();                                   // this item's first units have landed; last item's stores are out
     __builtin_amdgcn_s_barrier();
     if (late) __builtin_amdgcn_s_barrier();            // stagger the second wave of each SIMD by one barrier interval
-    // one k-unit = two phases (k-sub-steps); REM = units that follow it (3 = steady state)
+    // one k-unit = two phases; REM = units that follow it (3 = steady state: both DMA halves issued, 6-7 instructions left in flight)
     auto unit = [&](int t, auto rem_c) {
       constexpr int REM = decltype(rem_c)::value;
       const char* sA = smem + (t & 3) * UNIT;
-      const char* sB = sA + A_BYTES;
+      const char* sB = sA + boff;
       auto rest_a = [&]() { if (REM >= 2) issue_hi(); };           // phase a: rest of unit t+2
       auto rest_b = [&]() {                                          // phase b: first pieces of unit t+3, then the counted wait
         if (REM >= 3) issue_lo();
-        if (REM >= 3) { if (NP_X && extra) wait_vmcnt<NP_LO + 1 + H1>(); else wait_vmcnt<NP_LO + H1>(); }   // unit t+1 landed
-        else if (REM == 2) { if (NP_X && extra) wait_vmcnt<NP_LO + 1>(); else wait_vmcnt<NP_LO>(); }
+        if (REM >= 3) { if (vtc) wait_vmcnt<7>(); else wait_vmcnt<6>(); }   // unit t+1 landed; t+2 and the start of t+3 in flight
+        else if (REM == 2) { if (vtc) wait_vmcnt<5>(); else wait_vmcnt<4>(); }
         else if (REM == 1) wait_vmcnt<0>();
       };
-      {
-        // phases split the wave's rows: a = upper half x all columns (B fragments stay in registers for b = lower half)
-        constexpr int TH = TM / 2;
-        bf16x8 af[2][TH], bf[2][TN];
+      // phases split the wave's rows: a = upper half x all columns (B fragments stay in registers for b = lower half)
+      bf16x8 af[2][TH], bf[2][TN];
+#pragma unroll
+      for (int ks = 0; ks < 2; ks++)
+#pragma unroll
+        for (int j = 0; j < TN; j++) bf[ks][j] = frag_rt<B_KC>(sB, b_rb + j * 32, ks, lane, rlb);
+#pragma unroll
+      for (int h = 0; h < 2; h++) {
 #pragma unroll
         for (int ks = 0; ks < 2; ks++)
 #pragma unroll
-          for (int j = 0; j < TN; j++) bf[ks][j] = frag_p<B_KC, TBN, BKT>(sB, wn * (TN * 32) + j * 32, ks, lane);
+          for (int i = 0; i < TH; i++) af[ks][i] = frag_rt<A_KC>(sA, a_rb + (h * TH + i) * 32, ks, lane, rla);
+        if (h == 0) rest_a(); else rest_b();
+        PXA_SB(); __builtin_amdgcn_s_barrier(); PXA_SB();
+        __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-        for (int h = 0; h < 2; h++) {
+        for (int ks = 0; ks < 2; ks++)
 #pragma unroll
-          for (int ks = 0; ks < 2; ks++)
+          for (int i = 0; i < TH; i++)
 #pragma unroll
-            for (int i = 0; i < TH; i++) af[ks][i] = frag_p<A_KC, TBM, BKT>(sA, wm * (TM * 32) + (h * TH + i) * 32, ks, lane);
-          if (h == 0) rest_a(); else rest_b();
-          PXA_SB(); __builtin_amdgcn_s_barrier(); PXA_SB();
-          __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-          for (int ks = 0; ks < 2; ks++)
-#pragma unroll
-            for (int i = 0; i < TH; i++)
-#pragma unroll
-              for (int j = 0; j < TN; j++) acc[h * TH + i][j] = mfma32(bf[ks][j], af[ks][i], acc[h * TH + i][j]);
-          __builtin_amdgcn_s_setprio(0);
-          PXA_SB(); __builtin_amdgcn_s_barrier(); PXA_SB();
-        }
+            for (int j = 0; j < TN; j++) acc[h * TH + i][j] = mfma32(bf[ks][j], af[ks][i], acc[h * TH + i][j]);
+        __builtin_amdgcn_s_setprio(0);
+        PXA_SB(); __builtin_amdgcn_s_barrier(); PXA_SB();
       }
     };
     int t = 0;
@@ -721,14 +760,12 @@ __global__ __launch_bounds__(512) void gemm_pers_kernel(GemmParams p) {
     unit(t++, IntC<0>{});
     if (!late) __builtin_amdgcn_s_barrier();           // every wave has executed the same number of barriers; the ring is idle
 
-    // ---- hand-over: prefetch the next tile's first units, then this tile's epilogue
-    const int mw = m0 + wm * (TM * 32), nw = n0 + wn * (TN * 32);   // this wave's output origin (current tile)
-    const int zw = z_;                                  // this item's k-slice (fp32 slab index)
+    // ---- hand-over: prefetch the next item's first units, then this item's epilogue
     L += gridDim.x;
     const bool more = L < T;
     if (more) {
-      tile_coords(L, mt, nt, p.split, tm_, tn_, z_);
-      m0 = tm_ * TBM; n0 = tn_ * TBN; nk_pf = units_of(z_);
+      locate(L);
+      nk_pf = units_of(z_);
       prefetch();
     }
     const int srow = lane & 31;
@@ -872,23 +909,30 @@ __global__ __launch_bounds__(512) void gemm_pers_kernel(GemmParams p) {
   }
 }
 
-template <int LAYOUT, int TBM, int TBN, int EPI>
+// work items of the persistent kernel per k-slice (must match the kernel's own count)
+static inline bool pers_pairing(int M, int N) { return N % 256 > 0 && N % 256 <= 128 && ((M + 255) / 256) % 2 == 0; }
+static inline int pers_tiles(int M, int N, bool pair) {
+  const int mt = (M + 255) / 256, ntf = N / 256;
+  const bool pairing = pair && pers_pairing(M, N);
+  return mt * (pairing ? ntf : (N + 255) / 256) + (pairing ? mt / 2 : 0);
+}
+template <int LAYOUT, int EPI, bool PAIR = false>
 int launch_pers(GemmParams p, int split, hipStream_t s) {
   p.split = split;
-  constexpr int LDSP = 4 * (TBM + TBN) * 64;           // the ring: 128 KiB (256 x 256) / 144 KiB (192 x 384): one workgroup per CU
+  constexpr int LDSP = 4 * 40960;                      // the ring (4 x 40 KiB slots) = the CU's whole 160 KiB: one workgroup per CU
   static bool attr_set_pp = false;
   static int n_cu = 0;
   if (!attr_set_pp) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_pers_kernel<LAYOUT, TBM, TBN, EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, LDSP);
-    if (e != hipSuccess) { pxa_set_error("hipFuncSetAttribute(gemm_pers<%d,%d,%d>): %s", LAYOUT, TBM, TBN, hipGetErrorString(e)); return -3; }
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_pers_kernel<LAYOUT, EPI, PAIR>), hipFuncAttributeMaxDynamicSharedMemorySize, LDSP);
+    if (e != hipSuccess) { pxa_set_error("hipFuncSetAttribute(gemm_pers<%d,%d>): %s", LAYOUT, EPI, hipGetErrorString(e)); return -3; }
     int dev = 0;
     hipDeviceProp_t prop;
     if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) { pxa_set_error("gemm_pers: device query failed"); return -3; }
     n_cu = prop.multiProcessorCount;
     attr_set_pp = true;
   }
-  const int tiles = ((p.M + TBM - 1) / TBM) * ((p.N + TBN - 1) / TBN) * split;
-  hipLaunchKernelGGL((gemm_pers_kernel<LAYOUT, TBM, TBN, EPI>), dim3(tiles < n_cu ? tiles : n_cu), dim3(512), LDSP, s, p);
+  const int tiles = pers_tiles(p.M, p.N, PAIR) * split;
+  hipLaunchKernelGGL((gemm_pers_kernel<LAYOUT, EPI, PAIR>), dim3(tiles < n_cu ? tiles : n_cu), dim3(512), LDSP, s, p);
   PXA_LAUNCH_CHECK();
   return 0;
 }
@@ -918,14 +962,14 @@ int launch_glds(GemmParams p, int split, hipStream_t s) {
   static const bool no_pers = getenv("PXA_GEMM_NO_PERSISTENT") != nullptr;
   if (LAYOUT != 2 && TBM == 256 && TBN == 256 && split == 1 && p.out && !p.outf && !no_pers) {
     constexpr int LY = LAYOUT == 2 ? 0 : LAYOUT;
-    if (p.act == 0 && !p.colsum) return launch_pers<LY, 256, 256, 0>(p, 1, s);
-    if (p.act == 3 && !p.colsum) return launch_pers<LY, 256, 256, 1>(p, 1, s);
-    if (p.act == 4 && p.colsum) return launch_pers<LY, 256, 256, 2>(p, 1, s);
-    return launch_pers<LY, 256, 256, 3>(p, 1, s);
+    if (p.act == 0 && !p.colsum) return launch_pers<LY, 0>(p, 1, s);
+    if (p.act == 3 && !p.colsum) return launch_pers<LY, 1>(p, 1, s);
+    if (p.act == 4 && p.colsum) return launch_pers<LY, 2>(p, 1, s);
+    return launch_pers<LY, 3>(p, 1, s);
   }
   // fp32 weight gradients (TN, split-K slabs / single-slice read-modify-write / plain store): the same persistent kernel
   if (LAYOUT == 2 && TBM == 256 && TBN == 256 && p.outf && !p.out && !p.bias && p.act == 0 && p.accumulate != 1 && !p.colsum && !no_pers)
-    return launch_pers<2, 256, 256, 0>(p, split, s);
+    return pers_pairing(p.M, p.N) ? launch_pers<2, 0, true>(p, split, s) : launch_pers<2, 0, false>(p, split, s);
   if (LAYOUT != 2 && p.out && !p.outf && !dual && !no_stage) return launch_glds_e<LAYOUT, TBM, TBN, WM, WN, 1>(p, split, s);
   if (p.colsum) {                                         // not fused on this path: separate column-sum pass over the output
     float* cs = p.colsum;
@@ -1017,7 +1061,7 @@ extern "C" int pxa_gemm(const pxa_gemm_args* a, hipStream_t stream) {
     double best = 1e30;
     for (const Cfg& c : cfgs) {
       if (c.tile == 256 && (a->M < 256 || a->N < 256)) continue;
-      const long tiles = (long)((a->M + c.bm - 1) / c.bm) * ((a->N + c.bn - 1) / c.bn);
+      const long tiles = c.tile == 256 ? pers_tiles(a->M, a->N, true) : (long)((a->M + c.bm - 1) / c.bm) * ((a->N + c.bn - 1) / c.bn);
       for (int sp = 1; sp <= 16; sp++) {
         const int kp = ((a->K + sp - 1) / sp + BK - 1) / BK * BK;
         if ((long)kp * (sp - 1) >= a->K) continue;               // would leave an empty split
