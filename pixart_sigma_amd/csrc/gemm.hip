@@ -8,6 +8,7 @@
 // one output row m and 4 consecutive n per accumulator quad -> 8-byte bf16 / 16-byte fp32 stores.
 // k-contiguous operands sit in LDS as [128][64] with a 16-byte-chunk XOR swizzle (conflict-free ds_read_b128);
 // k-strided operands sit as [64][128+32] and are read with ds_read_b64_tr_b16 (hardware transpose).
+#include <atomic>
 #include "common.h"
 #include "../../include/pixart_hip.h"
 #include <cstdlib>
@@ -27,7 +28,7 @@ struct GemmParams {
   const float* bias; const bf16_t* aux; int ldaux;
   bf16_t* out; bf16_t* out2; int ldo;
   float* outf; int ldf;
-  int act, accumulate, k_per_split, tile_hint, split;
+  int act, accumulate, k_per_split, tile_hint, split, sched_slot;
   float* slab;
   float* colsum;   // optional [PXA_COLSUM_SLOTS][colsum_stride] partials: += column sums of the bf16 output, staged epilogue only
   long colsum_stride;
@@ -618,6 +619,16 @@ __device__ __forceinline__ bf16x8 frag_rt(const char* lds, int rbase, int ks, in
 // EPI (bf16 epilogue flavour, compiled separately so that none carries the others' registers - the epilogue runs with all
 // 128 accumulators live and spills at the slightest extra state): 0 = (+bias), 1 = act 3 (bias + GELU, GELU' as the second
 // output), 2 = act 4 (x aux) + bias-gradient column sums, 3 = everything decided at run time (acts 1 / 2 and odd mixes).
+// Dynamic item scheduler of the bf16 (NT / NN) instances.  A static "workgroup b takes items b, b + 256, ..." split makes the kernel
+// twice as long whenever another kernel (an RCCL all-reduce overlapping the backward) holds a few CUs: the workgroups that could not
+// start run their whole list after the others have finished.  Instead every XCD's contiguous item range has an atomic cursor; a
+// workgroup takes the next item of its own XCD's range (same L2 locality as the static order) and, when that is exhausted, of the
+// other XCDs' ranges.  The cursor fetch for item i+2 is issued at the hand-over i -> i+1 and resolved after the next vmcnt(0), so its
+// latency is never waited for.  Cursors live in a 64-slot global table (one slot per launch, round robin); the last workgroup to
+// retire zeroes its slot.
+__device__ unsigned g_sched[64][16];                   // [slot][0..7] per-XCD cursors, [8] retired workgroups
+__device__ unsigned g_sched_word[64][512];             // paired-tile instances (no spare LDS): per-workgroup broadcast word
+
 // PAIR: compile the paired-remainder path in.  Only the fp32 weight-gradient launches use it: with split-K their item count is
 // free to fill the CUs, so the saved half tile is saved time (dW of qkv / fc1: -12 %); the bf16 NT / NN GEMMs run whole rounds of
 // 256 items either way (4.5 rounds of work still take 5) and the run-time geometry costs them 3 %, so they compile it out.
@@ -642,17 +653,68 @@ __global__ __launch_bounds__(512) void gemm_pers_kernel(GemmParams p) {
   // current / prefetched item: row origins of the (two) A row blocks, column origin, paired flag, k-slice
   int m0a = 0, m0b = 0, n0 = 0, z_ = 0;
   bool vt = false;
-  auto locate = [&](int L) {                           // logical item -> coordinates: workgroup b runs on XCD b % 8, every XCD owns a
-    const int q = T / 8, r = T % 8, x = L % 8, idx = L / 8;   // contiguous range of the grouped (8 m-tiles) order, k-slice major
-    const int Lg = x * q + min(x, r) + idx;
+  // workgroup b runs on XCD b % 8; every XCD owns a contiguous range [xs(x), xs(x) + xc(x)) of the grouped (8 m-tiles), k-slice
+  // major item order
+  const int xq = T / 8, xr = T % 8;
+  auto xs = [&](int x) { return x * xq + min(x, xr); };
+  auto xc = [&](int x) { return xq + (x < xr ? 1 : 0); };
+  auto locate_g = [&](int Lg) {                        // position in that order -> coordinates
     z_ = Lg / tiles;
     const int t = Lg - z_ * tiles;
     const int g = t / per_group, in_g = t - g * per_group, first_m = g * 8, gsz = min(mt - first_m, 8), nfull = gsz * ntp;
     if (in_g < nfull) { vt = false; m0a = (first_m + in_g % gsz) * 256; m0b = m0a; n0 = (in_g / gsz) * 256; }
     else if (PAIR) { vt = true; m0a = (first_m + 2 * (in_g - nfull)) * 256; m0b = m0a + 256; n0 = ntf * 256; }
   };
+  auto locate = [&](int L) { locate_g(xs(L % 8) + L / 8); };   // static order: workgroup-strided index
+  const bool DYN = p.sched_slot >= 0;                  // slot < 0: static workgroup-strided split (A/B experiments)
+  const int myx = blockIdx.x % 8;
+  unsigned* sched = g_sched[p.sched_slot & 63];
+  // the fetched position travels from wave 0 to the others through a word the DMA never touches: bytes 32..40 KiB of ring slot 0
+  // are unused without pairing; the paired instances have no spare LDS and use a per-workgroup word in global memory instead
+  unsigned* sched_lds = reinterpret_cast<unsigned*>(smem + 32768);
+  unsigned* sched_glb = &g_sched_word[p.sched_slot & 63][blockIdx.x & 511];
+  auto publish = [&](int v) {                          // wave 0 / lane 0 writes, then the caller's barrier
+    if (PAIR) { if (lane == 0) __hip_atomic_store(sched_glb, (unsigned)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); wait_vmcnt<0>(); }
+    else { if (lane == 0) sched_lds[0] = (unsigned)v; asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+  };
+  auto receive = [&]() -> int {
+    const unsigned v = PAIR ? __hip_atomic_load(sched_glb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : sched_lds[0];
+    return __builtin_amdgcn_readfirstlane((int)v);
+  };
+  unsigned pend = 0u;                                  // wave 0 / lane 0: cursor value of the fetch in flight
+  int nxt = -1;                                        // the item after the current one (position in the order), -1: none
+  auto fetch_issue = [&]() { if (wave == 0 && lane == 0) pend = atomicAdd(&sched[myx], 1u); };
+  auto fetch_resolve = [&]() -> int {                  // wave 0 only; the own-XCD fetch has returned (vmcnt(0) was waited)
+    int res = -1;
+    if (lane == 0) {
+      if ((int)pend < xc(myx)) res = xs(myx) + (int)pend;
+      else
+        for (int k = 1; k < 8 && res < 0; k++) {       // own range exhausted: take from the others (blocking; only at a kernel's tail)
+          const int x2 = (myx + k) & 7;
+          const unsigned i2 = atomicAdd(&sched[x2], 1u);
+          if ((int)i2 < xc(x2)) res = xs(x2) + (int)i2;
+        }
+    }
+    return __builtin_amdgcn_readfirstlane(res);
+  };
   int L = blockIdx.x;
-  locate(L);
+  if (DYN) {
+    fetch_issue();
+    wait_vmcnt<0>();
+    if (wave == 0) publish(fetch_resolve());
+    __syncthreads();
+    const int first = receive();
+    __syncthreads();                                   // everybody has read the word before it is reused
+    if (first < 0) {                                   // nothing left for this workgroup (it started late): retire
+      if (wave == 0 && lane == 0 && atomicAdd(&sched[8], 1u) == gridDim.x - 1)
+        for (int k = 0; k < 9; k++) sched[k] = 0u;
+      return;
+    }
+    locate_g(first);
+    fetch_issue();                                     // the item after it
+  } else {
+    locate(L);
+  }
   int nk = units_of(z_), nk_pf = nk;                   // nk_pf: units of the item being prefetched
   // running source pointers, per-unit strides (elements) and LDS offsets of this wave's (up to) 5 DMA pieces per k-unit
   const bf16_t* pp[5];
@@ -714,7 +776,11 @@ __global__ __launch_bounds__(512) void gemm_pers_kernel(GemmParams p) {
     const int mw = ((vtc && (wn >> 1)) ? m0b : m0a) + wm * 128, nw = n0 + b_rb;   // this wave's output origin
     const int zw = z_;                                  // this item's k-slice (fp32 slab index)
     wait_vmcnt<0>();                                   // this item's first units have landed; last item's stores are out
+    if (DYN && wave == 0) {                            // ... and so has the cursor fetch issued at the last hand-over
+      publish(fetch_resolve());
+    }
     __builtin_amdgcn_s_barrier();
+    if (DYN) nxt = receive();
     if (late) __builtin_amdgcn_s_barrier();            // stagger the second wave of each SIMD by one barrier interval
     // one k-unit = two phases; REM = units that follow it (3 = steady state: both DMA halves issued, 6-7 instructions left in flight)
     auto unit = [&](int t, auto rem_c) {
@@ -761,12 +827,23 @@ __global__ __launch_bounds__(512) void gemm_pers_kernel(GemmParams p) {
     if (!late) __builtin_amdgcn_s_barrier();           // every wave has executed the same number of barriers; the ring is idle
 
     // ---- hand-over: prefetch the next item's first units, then this item's epilogue
-    L += gridDim.x;
-    const bool more = L < T;
-    if (more) {
-      locate(L);
-      nk_pf = units_of(z_);
-      prefetch();
+    bool more;
+    if (DYN) {
+      more = nxt >= 0;
+      if (more) {
+        locate_g(nxt);
+        nk_pf = units_of(z_);
+        prefetch();
+        fetch_issue();                                 // cursor fetch for the item after the next; resolved after the next vmcnt(0)
+      }
+    } else {
+      L += gridDim.x;
+      more = L < T;
+      if (more) {
+        locate(L);
+        nk_pf = units_of(z_);
+        prefetch();
+      }
     }
     const int srow = lane & 31;
     if constexpr (LAYOUT == 2) {
@@ -907,6 +984,8 @@ __global__ __launch_bounds__(512) void gemm_pers_kernel(GemmParams p) {
     nk = nk_pf;
     if (!more) break;
   }
+  if (DYN && wave == 0 && lane == 0 && atomicAdd(&sched[8], 1u) == gridDim.x - 1)
+    for (int k = 0; k < 9; k++) sched[k] = 0u;         // last workgroup out: the slot is clean for a later launch
 }
 
 // work items of the persistent kernel per k-slice (must match the kernel's own count)
@@ -932,6 +1011,9 @@ int launch_pers(GemmParams p, int split, hipStream_t s) {
     attr_set_pp = true;
   }
   const int tiles = pers_tiles(p.M, p.N, PAIR) * split;
+  static std::atomic<unsigned> launch_seq{0};
+  static const bool force_static = getenv("PXA_GEMM_STATIC") != nullptr;   // A/B experiments (tools/contention_test.py)
+  p.sched_slot = force_static ? -1 : (int)(launch_seq.fetch_add(1u) & 63u);
   hipLaunchKernelGGL((gemm_pers_kernel<LAYOUT, EPI, PAIR>), dim3(tiles < n_cu ? tiles : n_cu), dim3(512), LDSP, s, p);
   PXA_LAUNCH_CHECK();
   return 0;
