@@ -30,6 +30,9 @@ extern "C" {
 
 const char* pxa_last_error(void);
 int pxa_abi_version(void);
+/* 16-bit operand type of this build of the library: 0 = bfloat16 (libpixart_hip.so), 1 = IEEE half (libpixart_hip_f16.so).  Every
+ * "bf16" pointer of this header means "the operand type"; fp32 pointers are fp32 in both builds. */
+int pxa_operand_dtype(void);
 int pxa_device_info(int* cu_count, int* is_gfx950);
 
 /* ---------------------------------------------------------------------------------------------- GEMM family

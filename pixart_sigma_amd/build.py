@@ -16,6 +16,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, ".obj")
 LIB = os.path.join(HERE, "libpixart_hip.so")
+# (library file, extra compile flags): bf16 operands (training / default) and IEEE-fp16 operands (the 1e-3 forward-parity build)
+VARIANTS = {"bf16": ("libpixart_hip.so", []), "f16": ("libpixart_hip_f16.so", ["-DPXA_OPERAND_F16"])}
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 
@@ -27,30 +29,35 @@ def _hipcc():
     raise RuntimeError("hipcc not found")
 
 
-def _digest(path):
+def _digest(path, extra=()):
     h = hashlib.sha256()
     for p in [path, os.path.join(CSRC, "common.h"), os.path.join(INCLUDE, "pixart_hip.h")]:
         with open(p, "rb") as f:
             h.update(f.read())
-    h.update(" ".join(FLAGS).encode())
+    h.update(" ".join([*FLAGS, *extra]).encode())
     return h.hexdigest()[:16]
 
 
-def build(force=False, verbose=False):
+def build(force=False, verbose=False, variants=("bf16", "f16")):
     os.makedirs(OBJ, exist_ok=True)
     srcs = sorted(f for f in os.listdir(CSRC) if f.endswith(".hip"))
     hipcc = _hipcc()
-    objs, jobs = [], []
-    for s in srcs:
-        src = os.path.join(CSRC, s)
-        obj = os.path.join(OBJ, f"{s[:-4]}.{_digest(src)}.o")
-        objs.append(obj)
-        if force or not os.path.exists(obj):
-            jobs.append((src, obj))
+    jobs, plan, keep = [], [], set()
+    for v in variants:
+        libname, extra = VARIANTS[v]
+        objs = []
+        for s in srcs:
+            src = os.path.join(CSRC, s)
+            obj = os.path.join(OBJ, f"{s[:-4]}.{v}.{_digest(src, extra)}.o")
+            objs.append(obj)
+            keep.add(obj)
+            if force or not os.path.exists(obj):
+                jobs.append((src, obj, extra))
+        plan.append((os.path.join(HERE, libname), objs))
 
     def compile_one(job):
-        src, obj = job
-        cmd = [hipcc, *FLAGS, "-I", INCLUDE, "-c", src, "-o", obj]
+        src, obj, extra = job
+        cmd = [hipcc, *FLAGS, *extra, "-I", INCLUDE, "-c", src, "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
         r = subprocess.run(cmd, capture_output=True, text=True)
@@ -63,18 +70,19 @@ def build(force=False, verbose=False):
     if jobs:
         with ThreadPoolExecutor(max_workers=min(8, len(jobs))) as ex:
             list(ex.map(compile_one, jobs))
-    stale = not os.path.exists(LIB) or any(os.path.getmtime(o) > os.path.getmtime(LIB) for o in objs)
-    if jobs or stale or force:
-        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", LIB]
-        r = subprocess.run(cmd, capture_output=True, text=True)
-        if r.returncode != 0:
-            raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
-    # drop objects of older source versions
-    keep = set(objs)
-    for f in os.listdir(OBJ):
-        p = os.path.join(OBJ, f)
-        if p not in keep:
-            os.remove(p)
+    for lib, objs in plan:
+        stale = not os.path.exists(lib) or any(os.path.getmtime(o) > os.path.getmtime(lib) for o in objs)
+        if stale or force:
+            cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", lib]
+            r = subprocess.run(cmd, capture_output=True, text=True)
+            if r.returncode != 0:
+                raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
+    # drop objects of older source versions (only when every variant was planned, so a partial build keeps the other's cache)
+    if set(variants) == set(VARIANTS):
+        for f in os.listdir(OBJ):
+            p = os.path.join(OBJ, f)
+            if p not in keep:
+                os.remove(p)
     return LIB
 
 

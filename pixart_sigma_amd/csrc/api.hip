@@ -15,6 +15,7 @@ void pxa_set_error(const char* fmt, ...) {
 }
 extern "C" const char* pxa_last_error(void) { return g_err; }
 extern "C" int pxa_abi_version(void) { return PXA_ABI_VERSION; }
+extern "C" int pxa_operand_dtype(void) { return PXA_OPERAND_DTYPE_ID; }
 extern "C" int pxa_device_info(int* cu_count, int* is_gfx950) {
   hipDeviceProp_t p;
   int dev = 0;

@@ -94,7 +94,7 @@ __device__ __forceinline__ void init_pads(char* tile, bool ones_col72, int tid) 
   for (int i = tid; i < BKV * 3; i += 256) {
     const int r = i / 3, c = NCH + (i - r * 3);
     uint4 v = make_uint4(0, 0, 0, 0);
-    if (ones_col72 && c == NCH) v.x = 0x3f80u;   // bf16 1.0 in the low half = column 72
+    if (ones_col72 && c == NCH) v.x = PXA_OPERAND_ONE_BITS;   // 1.0 in the low half = column 72
     *reinterpret_cast<uint4*>(tile + soff(r, c)) = v;
   }
 }

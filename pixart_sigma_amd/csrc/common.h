@@ -7,10 +7,24 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+// The 16-bit operand type of this build.  The library is compiled twice from the same sources: libpixart_hip.so with bf16
+// operands (training and the default), libpixart_hip_f16.so (-DPXA_OPERAND_F16) with IEEE fp16 operands - the reference's own
+// inference dtype, 8x finer mantissa: the build that meets the 1e-3 forward-parity tolerance.  The type keeps its historical name.
+#ifdef PXA_OPERAND_F16
+typedef _Float16 bf16_t;
+typedef _Float16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 bf16x2 __attribute__((ext_vector_type(2)));
+#define PXA_OPERAND_ONE_BITS 0x3c00u
+#define PXA_OPERAND_DTYPE_ID 1
+#else
 typedef __bf16 bf16_t;
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+#define PXA_OPERAND_ONE_BITS 0x3f80u
+#define PXA_OPERAND_DTYPE_ID 0
+#endif
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -31,8 +45,14 @@ __device__ __forceinline__ uint2 pack_bf16x4(float a, float b, float c, float d)
   return make_uint2(pack_bf16x2(a, b), pack_bf16x2(c, d));
 }
 __device__ __forceinline__ void unpack_bf16x2(uint32_t u, float& a, float& b) {
+#ifdef PXA_OPERAND_F16
+  const bf16x2 v = __builtin_bit_cast(bf16x2, u);
+  a = (float)v[0];
+  b = (float)v[1];
+#else
   a = __builtin_bit_cast(float, u << 16);
   b = __builtin_bit_cast(float, u & 0xffff0000u);
+#endif
 }
 __device__ __forceinline__ void unpack_bf16x8(const uint4& u, float (&f)[8]) {
   unpack_bf16x2(u.x, f[0], f[1]); unpack_bf16x2(u.y, f[2], f[3]);
@@ -50,7 +70,11 @@ __device__ __forceinline__ bf16x8 concat_tr(s16x4 lo, s16x4 hi) {
 }
 
 __device__ __forceinline__ f32x16 mfma32(bf16x8 a, bf16x8 b, f32x16 c) {
+#ifdef PXA_OPERAND_F16
+  return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);   // same operand / accumulator lane layout as the bf16 form
+#else
   return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+#endif
 }
 
 // GELU(approximate="tanh") and its derivative (reference: nn.GELU(approximate="tanh"), PixArtMS.py:66), written through the

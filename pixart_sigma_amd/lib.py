@@ -7,7 +7,12 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get("PXA_LIB_PATH") or os.path.join(_HERE, "libpixart_hip.so")   # env override: A/B kernel builds
+# 16-bit operand type of the process: bf16 (default; training) or IEEE fp16 (PXA_OPERAND_DTYPE=f16: the reference's inference dtype,
+# the build that meets the 1e-3 forward-parity tolerance).  One library per type, built from the same sources.
+OPERAND = os.environ.get("PXA_OPERAND_DTYPE", "bf16").lower()
+assert OPERAND in ("bf16", "f16"), f"PXA_OPERAND_DTYPE must be bf16 or f16, got {OPERAND!r}"
+OPERAND_DTYPE = torch.float16 if OPERAND == "f16" else torch.bfloat16
+LIB_PATH = os.environ.get("PXA_LIB_PATH") or os.path.join(_HERE, "libpixart_hip_f16.so" if OPERAND == "f16" else "libpixart_hip.so")   # env override: A/B kernel builds
 ABI_VERSION = 1
 
 c_void_p, c_int, c_long, c_float = C.c_void_p, C.c_int, C.c_long, C.c_float
@@ -62,7 +67,7 @@ SIGNATURES = {
     "pxa_adamw_step": [_P, _P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _I, _P, _P],
     "pxa_cast_f32_bf16": [_P, _P, _L, _P],
 }
-OTHER_SYMBOLS = ["pxa_last_error", "pxa_abi_version", "pxa_device_info", "pxa_gemm_splitk_ws_elems"]
+OTHER_SYMBOLS = ["pxa_last_error", "pxa_abi_version", "pxa_operand_dtype", "pxa_device_info", "pxa_gemm_splitk_ws_elems"]
 
 _lib = None
 
@@ -88,6 +93,9 @@ def load():
     lib.pxa_device_info.argtypes, lib.pxa_device_info.restype = [C.POINTER(c_int), C.POINTER(c_int)], c_int
     if lib.pxa_abi_version() != ABI_VERSION:
         raise PixartHipError(f"ABI mismatch: library {lib.pxa_abi_version()} vs binding {ABI_VERSION}")
+    lib.pxa_operand_dtype.restype = c_int
+    if lib.pxa_operand_dtype() != (1 if OPERAND == "f16" else 0):
+        raise PixartHipError(f"{LIB_PATH} was built for the other operand type (PXA_OPERAND_DTYPE={OPERAND})")
     _lib = lib
     return lib
 

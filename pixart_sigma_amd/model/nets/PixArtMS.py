@@ -161,7 +161,7 @@ class _BlockFn(torch.autograd.Function):
         mod = (block.scale_shift_table.detach()[None] + t.detach().reshape(B, 6, D)).contiguous()[None]
         c = dict(B=B, N=N, hw=HW, mod=mod, kv_len=torch.tensor(lens, dtype=torch.int32, device=dev),
                  kv_start=torch.from_numpy(starts).to(dev), max_len=int(max(lens)),
-                 ye=y.detach().reshape(-1, D).to(torch.bfloat16).contiguous())
+                 ye=y.detach().reshape(-1, D).to(ops.BF16).contiguous())
         x2, u3, gl, sv = eng.block_fwd(0, x.detach().reshape(B * N, D).to(F32).contiguous(), None, None, c)
         r = ops.ln_mod_fwd(x2, u=u3, gate=gl, gate_stride=6 * D, want_xn=False, rows_per_batch=N)
         ctx.block, ctx.c, ctx.sv, ctx.shape = block, c, sv, (B, N, D)

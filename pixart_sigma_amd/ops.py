@@ -8,7 +8,9 @@ import torch
 from . import lib
 from .lib import AttnArgs, GemmArgs, call, ptr
 
-BF16, F32 = torch.bfloat16, torch.float32
+# BF16 = the process's 16-bit operand dtype: torch.bfloat16, or torch.float16 under PXA_OPERAND_DTYPE=f16 (historical name)
+from .lib import OPERAND_DTYPE as BF16  # noqa: E402
+F32 = torch.float32
 NT, NN, TN = 0, 1, 2
 ACT_NONE, ACT_GELU, ACT_GELU_GRAD, ACT_GELU_SAVE_GRAD, ACT_MUL_AUX = 0, 1, 2, 3, 4
 _SPLITK_WS = {}
