@@ -307,6 +307,140 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* __restric
   delta[((long)b * H + h) * Nq + q] = acc;
 }
 
+// Forward with TWO query sub-tiles per wave (256 queries per workgroup).  A K or V^T fragment read from LDS now feeds two MFMAs,
+// and a K/V tile pair fetched by LDS-DMA serves twice as many queries: the single-sub-tile kernel above moves 12.9 GB from L2 into
+// LDS per self-attention launch (8.6 TB/s - the same ballpark as the GEMM's DMA-only ceiling) and issues 1.9 LDS instructions per
+// MFMA.  Costs: 96 + 64 accumulator registers (two waves per SIMD instead of three).
+__global__ __launch_bounds__(256, 2) void attn_fwd2_kernel(AttnParams p) {
+  constexpr int QS = 2;
+  __shared__ __attribute__((aligned(16))) char smem[4 * TILE_B];   // 2 stages x {K, V}
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), hi = lane >> 5;
+  const int b = blockIdx.z, h = blockIdx.y;
+  long kbase, vbase, d0_, d1_; int kvlen;
+  kv_range(p, b, kbase, vbase, d0_, d1_, kvlen);
+  const bf16_t* Kp = p.K + kbase + (long)h * p.k_hs;
+  const bf16_t* Vp = p.V + vbase + (long)h * p.v_hs;
+  const int kts = (int)p.k_ts, vts = (int)p.v_ts;
+
+  int q[QS];
+  bool qvalid[QS];
+  bf16x8 qf[QS][KSTEPS];
+#pragma unroll
+  for (int s = 0; s < QS; s++) {
+    q[s] = blockIdx.x * 256 + wave * 64 + s * 32 + (lane & 31);
+    qvalid[s] = q[s] < p.Nq;
+    load_row_frags(qf[s], p.Q + (long)b * p.q_bs + (long)q[s] * p.q_ts + (long)h * p.q_hs, qvalid[s], hi);
+  }
+  DmaPlan pl;
+  dma_plan(pl, wave, lane);
+  FragAddr fa;
+  frag_addr(fa, lane);
+  for (int st = 0; st < 2; st++) {
+    init_pads(smem + st * 2 * TILE_B, false, tid);            // K
+    init_pads(smem + st * 2 * TILE_B + TILE_B, true, tid);    // V: column 72 = 1 -> O^T row 72 accumulates sum_kv P = l
+  }
+  f32x16 o[QS][3];
+  float m[QS];
+#pragma unroll
+  for (int s = 0; s < QS; s++) { zero3(o[s]); m[s] = -INFINITY; }
+  const float c = p.scale_log2;
+
+  auto tile = [&](auto tailc, const char* sK, const char* sV, int kv0) {
+    constexpr bool TAIL = decltype(tailc)::value;
+    f32x16 sc[QS][2];
+#pragma unroll
+    for (int s = 0; s < QS; s++)
+#pragma unroll
+      for (int sub = 0; sub < 2; sub++)
+#pragma unroll
+        for (int g = 0; g < 16; g++) sc[s][sub][g] = 0.f;
+#pragma unroll
+    for (int sub = 0; sub < 2; sub++)
+#pragma unroll
+      for (int ks = 0; ks < KSTEPS; ks++) {
+        const bf16x8 kf = rowfrag(sK, fa, sub, ks);          // one LDS read, two MFMAs
+#pragma unroll
+        for (int s = 0; s < QS; s++) sc[s][sub] = mfma32(kf, qf[s][ks], sc[s][sub]);
+      }
+#pragma unroll
+    for (int s = 0; s < QS; s++) {
+      if (TAIL) {
+#pragma unroll
+        for (int sub = 0; sub < 2; sub++)
+#pragma unroll
+          for (int g = 0; g < 16; g++)
+            if (kv0 + sub * 32 + (g & 3) + 8 * (g >> 2) + 4 * hi >= kvlen) sc[s][sub][g] = -INFINITY;
+      }
+      float mt = sc[s][0][0];
+#pragma unroll
+      for (int sub = 0; sub < 2; sub++)
+#pragma unroll
+        for (int g = 0; g < 16; g++) mt = fmaxf(mt, sc[s][sub][g]);
+      mt = fmaxf(mt, __shfl_xor(mt, 32));
+      if (__builtin_amdgcn_readfirstlane(__any((mt - m[s]) * c > RESCALE_LOG2))) {   // deferred rescale, see attn_fwd_kernel
+        asm volatile("" ::: "memory");
+        const float mn = fmaxf(m[s], mt);
+        const float alpha = __builtin_amdgcn_exp2f((m[s] - mn) * c);
+        m[s] = mn;
+#pragma unroll
+        for (int dt = 0; dt < 3; dt++)
+#pragma unroll
+          for (int g = 0; g < 16; g++) o[s][dt][g] *= alpha;
+      }
+      const float mc = m[s] * c;
+#pragma unroll
+      for (int sub = 0; sub < 2; sub++)
+#pragma unroll
+        for (int g = 0; g < 16; g++) sc[s][sub][g] = __builtin_amdgcn_exp2f(sc[s][sub][g] * c - mc);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      bf16x8 pb[QS];
+#pragma unroll
+      for (int s = 0; s < QS; s++) pb[s] = pack8(sc[s][u >> 1], 8 * (u & 1));
+#pragma unroll
+      for (int dt = 0; dt < 3; dt++) {
+        const bf16x8 vf = trfrag(sV, fa, dt, u);             // one transposed fragment, two MFMAs
+#pragma unroll
+        for (int s = 0; s < QS; s++) o[s][dt] = mfma32(vf, pb[s], o[s][dt]);
+      }
+    }
+  };
+
+  const int Tfull = kvlen / BKV, rem = kvlen - Tfull * BKV, T = Tfull + (rem ? 1 : 0);
+  auto issue = [&](int t) {                // DMA of tile t into stage t&1
+    char* nx = smem + (t & 1) * 2 * TILE_B;
+    if (t < Tfull) {
+      dma_tile<true>(nx, Kp, kts, t * BKV, kvlen, pl, wave);
+      dma_tile<true>(nx + TILE_B, Vp, vts, t * BKV, kvlen, pl, wave);
+    } else {
+      dma_tile<false>(nx, Kp, kts, t * BKV, kvlen, pl, wave);
+      dma_tile<false>(nx + TILE_B, Vp, vts, t * BKV, kvlen, pl, wave);
+    }
+  };
+  if (T > 0) issue(0);
+  for (int t = 0; t < Tfull; t++) {
+    __syncthreads();                       // own DMA drained (vmcnt(0)) + stage hand-over; ONE barrier per tile
+    if (t + 1 < T) issue(t + 1);
+    const char* st = smem + (t & 1) * 2 * TILE_B;
+    tile(BoolC<false>{}, st, st + TILE_B, t * BKV);
+  }
+  if (rem) {
+    __syncthreads();
+    const char* st = smem + (Tfull & 1) * 2 * TILE_B;
+    tile(BoolC<true>{}, st, st + TILE_B, Tfull * BKV);
+  }
+#pragma unroll
+  for (int s = 0; s < QS; s++) {
+    const float l = __shfl(o[s][2][4], lane & 31);     // row 72 of O^T = sum over keys of the bf16 P actually multiplied into O
+    if (qvalid[s]) {
+      const float inv = l > 0.f ? 1.f / l : 0.f;
+      store_rows(p.O + (long)b * p.o_bs + (long)q[s] * p.o_ts + (long)h * p.o_hs, o[s], inv, hi);
+      if (hi == 0 && p.LSE) p.LSE[((long)b * p.H + h) * p.Nq + q[s]] = m[s] * c + log2f(l);
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ backward: dQ
 #ifndef ATTN_BWD_WAVES
 #define ATTN_BWD_WAVES 2
@@ -524,7 +658,9 @@ extern "C" int pxa_attn_fwd(const pxa_attn_args* a, hipStream_t stream) {
   AttnParams p;
   if (int rc = fill(p, a)) return rc;
   PXA_CHECK(p.Q && p.K && p.V && p.O, "pxa_attn_fwd: null tensor");
-  hipLaunchKernelGGL(attn_fwd_kernel, dim3((p.Nq + 127) / 128, p.H, p.B), dim3(256), 0, stream, p);
+  static const bool one_sub = getenv("PXA_ATTN_FWD1") != nullptr;   // A/B: the one-sub-tile kernel
+  if (!one_sub && p.Nq >= 256) hipLaunchKernelGGL(attn_fwd2_kernel, dim3((p.Nq + 255) / 256, p.H, p.B), dim3(256), 0, stream, p);
+  else hipLaunchKernelGGL(attn_fwd_kernel, dim3((p.Nq + 127) / 128, p.H, p.B), dim3(256), 0, stream, p);
   PXA_LAUNCH_CHECK();
   return 0;
 }
