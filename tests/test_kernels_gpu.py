@@ -222,7 +222,7 @@ def _attn_ref(q, k, v):
     return torch.einsum("bhqk,bkhd->bqhd", s.softmax(-1), v)
 
 
-@pytest.mark.parametrize("B,H,Nq,Nk", [(2, 16, 256, 256), (1, 4, 200, 200), (2, 3, 130, 77), (1, 2, 64, 1024)])
+@pytest.mark.parametrize("B,H,Nq,Nk", [(2, 16, 256, 256), (1, 4, 200, 200), (2, 3, 130, 77), (1, 2, 64, 1024), (1, 2, 300, 77), (2, 2, 520, 200)])
 def test_attention_fwd_bwd_dense(ops, B, H, Nq, Nk):
     C = H * 72
     q, k, v = (bf(rnd(B, n, C, seed=s)) for n, s in ((Nq, 1), (Nk, 2), (Nk, 3)))
