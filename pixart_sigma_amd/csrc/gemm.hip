@@ -988,6 +988,7 @@ __global__ __launch_bounds__(512) void gemm_pers_kernel(GemmParams p) {
     for (int k = 0; k < 9; k++) sched[k] = 0u;         // last workgroup out: the slot is clean for a later launch
 }
 
+static std::atomic<unsigned> g_launch_seq{0};          // cursor-slot round robin, shared by every instantiation of the persistent kernel
 // work items of the persistent kernel per k-slice (must match the kernel's own count)
 static inline bool pers_pairing(int M, int N) { return N % 256 > 0 && N % 256 <= 128 && ((M + 255) / 256) % 2 == 0; }
 static inline int pers_tiles(int M, int N, bool pair) {
@@ -1011,9 +1012,8 @@ int launch_pers(GemmParams p, int split, hipStream_t s) {
     attr_set_pp = true;
   }
   const int tiles = pers_tiles(p.M, p.N, PAIR) * split;
-  static std::atomic<unsigned> launch_seq{0};
   static const bool force_static = getenv("PXA_GEMM_STATIC") != nullptr;   // A/B experiments (tools/contention_test.py)
-  p.sched_slot = force_static ? -1 : (int)(launch_seq.fetch_add(1u) & 63u);
+  p.sched_slot = force_static ? -1 : (int)(g_launch_seq.fetch_add(1u) & 63u);
   hipLaunchKernelGGL((gemm_pers_kernel<LAYOUT, EPI, PAIR>), dim3(tiles < n_cu ? tiles : n_cu), dim3(512), LDSP, s, p);
   PXA_LAUNCH_CHECK();
   return 0;
