@@ -629,13 +629,18 @@ __device__ __forceinline__ bf16x8 frag_rt(const char* lds, int rbase, int ks, in
 __device__ unsigned g_sched[64][16];                   // [slot][0..7] per-XCD cursors, [8] retired workgroups
 __device__ unsigned g_sched_word[64][512];             // paired-tile instances (no spare LDS): per-workgroup broadcast word
 
-// PAIR: compile the paired-remainder path in.  Only the fp32 weight-gradient launches use it: with split-K their item count is
-// free to fill the CUs, so the saved half tile is saved time (dW of qkv / fc1: -12 %); the bf16 NT / NN GEMMs run whole rounds of
-// 256 items either way (4.5 rounds of work still take 5) and the run-time geometry costs them 3 %, so they compile it out.
-template <int LAYOUT, int EPI, bool PAIR>
+// RM: how a half-width remainder column (0 < N % 256 <= 128) is handled; compiled in only where it is used, because the run-time
+// geometry costs the plain path 3 %.
+//   RM = 1 (fp32 weight gradients): PAIRED items, as described above - with split-K the item count is free to fill the CUs, so the
+//           saved half tile is saved time (dW of qkv / fc1: -12 %).
+//   RM = 2 (bf16 NT / NN): HALF items - one m-tile's remainder columns alone, 256 x 128 outputs on all 8 waves as 4 x 2 waves of
+//           64 x 64 (one row tile per phase: 8 MFMAs per k-unit and wave instead of 16).  Pairing would not help here: 256 CUs run
+//           whole rounds of equal items, 4.5 rounds of work still take 5; a round of half-duration items under the dynamic
+//           cursors makes it ~4.6.
+template <int LAYOUT, int EPI, int RM>
 __global__ __launch_bounds__(512) void gemm_pers_kernel(GemmParams p) {
   constexpr bool A_KC = (LAYOUT != 2), B_KC = (LAYOUT == 0);
-  constexpr int NW = 8, TM = 4, TN = 2, TH = 2, BKT = 32, H1 = 2;
+  constexpr int NW = 8, TM = 4, TN = 2, BKT = 32, H1 = 2;
   constexpr int UNIT = 40960;                          // ring slot: A image at 0 (16 KiB; 32 KiB paired), B image behind it (16 KiB; 8 KiB paired)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), wm = wave >> 2, wn = wave & 3, hi = lane >> 5;
@@ -645,9 +650,11 @@ __global__ __launch_bounds__(512) void gemm_pers_kernel(GemmParams p) {
   char* stg = smem + 3 * UNIT + wave * 4096;
   // work items: output tile (or paired half-width tile) x k-slice (split-K only for the fp32 weight-gradient layout), XCD-aware order
   const int mt = (p.M + 255) / 256, ntf = p.N / 256, remn = p.N - ntf * 256;
-  const bool pairing = PAIR && remn > 0 && remn <= 128 && (mt % 2 == 0);
-  const int ntp = pairing ? ntf : (p.N + 255) / 256;   // n-tile columns handled as (possibly padded) full tiles
-  const int per_group = 8 * ntp + (pairing ? 4 : 0), tiles = mt * ntp + (pairing ? mt / 2 : 0), T = tiles * p.split;
+  constexpr bool PAIR = (RM == 1), HALF = (RM == 2);
+  const bool remcol = RM != 0 && remn > 0 && remn <= 128 && (HALF || mt % 2 == 0);
+  const int ntp = remcol ? ntf : (p.N + 255) / 256;    // n-tile columns handled as (possibly padded) full tiles
+  const int rem_pg = remcol ? (PAIR ? 4 : 8) : 0;      // remainder items per group of 8 m-tiles
+  const int per_group = 8 * ntp + rem_pg, tiles = mt * ntp + (remcol ? (PAIR ? mt / 2 : mt) : 0), T = tiles * p.split;
   auto units_of = [&](int z) { return (min(p.K, (z + 1) * p.k_per_split) - z * p.k_per_split) / BKT; };   // >= 2: k ranges are multiples of 64
 
   // current / prefetched item: row origins of the (two) A row blocks, column origin, paired flag, k-slice
@@ -664,6 +671,7 @@ __global__ __launch_bounds__(512) void gemm_pers_kernel(GemmParams p) {
     const int g = t / per_group, in_g = t - g * per_group, first_m = g * 8, gsz = min(mt - first_m, 8), nfull = gsz * ntp;
     if (in_g < nfull) { vt = false; m0a = (first_m + in_g % gsz) * 256; m0b = m0a; n0 = (in_g / gsz) * 256; }
     else if (PAIR) { vt = true; m0a = (first_m + 2 * (in_g - nfull)) * 256; m0b = m0a + 256; n0 = ntf * 256; }
+    else if (HALF) { vt = true; m0a = (first_m + (in_g - nfull)) * 256; m0b = m0a; n0 = ntf * 256; }
   };
   auto locate = [&](int L) { locate_g(xs(L % 8) + L / 8); };   // static order: workgroup-strided index
   const bool DYN = p.sched_slot >= 0;                  // slot < 0: static workgroup-strided split (A/B experiments)
@@ -734,21 +742,22 @@ __global__ __launch_bounds__(512) void gemm_pers_kernel(GemmParams p) {
     s_lo = (s_lo + 1) & 3;
   };
   auto issue_hi = [&]() {
-    piece(2, s_hi); piece(3, s_hi);
-    if (vt_pf) piece(4, s_hi);
+    piece(2, s_hi);
+    if (!(HALF && vt_pf)) piece(3, s_hi);
+    if (PAIR && vt_pf) piece(4, s_hi);
     s_hi = (s_hi + 1) & 3;
   };
   auto prefetch = [&]() {                              // units 0, 1 and the first half of unit 2 of the item at (m0a, m0b, n0, z_)
-    vt_pf = PAIR && vt;
+    vt_pf = (RM != 0) && vt;
     const long k0 = (long)z_ * p.k_per_split;
-    const bool vq = PAIR && vt;
-    const int rla = vq ? 9 : 8, rlb = vq ? 7 : 8;      // log2 of the A / B image row (column) counts
+    const bool vq = PAIR && vt, hq = HALF && vt;
+    const int rla = vq ? 9 : 8, rlb = (vq || hq) ? 7 : 8;   // log2 of the A / B image row (column) counts
 #pragma unroll
     for (int i = 0; i < 5; i++) {
       const int id = wave + NW * i;                    // full tile: 16 A + 16 B pieces; paired: 32 A + 8 B
-      const bool is_a = vq ? (i < 4) : (i < 2);
+      const bool is_a = vq ? (i < 4) : (i < 2);                      // full: A A B B -, paired: A A A A B, half: A A B - -
       const int pid = is_a ? id : (vq ? id - 32 : id - 16);
-      if (i < 4 || vq) {
+      if (vq || (hq ? i < 3 : i < 4)) {
         if (is_a) pp[i] = piece_ptr_rt<A_KC>(p.A, p.lda, m0a, m0b, p.M, pid * 64 + lane, rla) + (A_KC ? k0 : k0 * p.lda);
         else pp[i] = piece_ptr_rt<B_KC>(p.B, p.ldb, n0, n0, p.N, pid * 64 + lane, rlb) + (B_KC ? k0 : k0 * p.ldb);
       }
@@ -770,10 +779,11 @@ __global__ __launch_bounds__(512) void gemm_pers_kernel(GemmParams p) {
 #pragma unroll
         for (int g = 0; g < 16; g++) acc[i][j][g] = 0.f;
     // this item's fragment geometry (the prefetch of the next item will overwrite vt / m0a / ...)
-    const bool vtc = PAIR && vt;
-    const int a_rb = (vtc ? (wn >> 1) * 256 : 0) + wm * 128, b_rb = vtc ? (wn & 1) * 64 : wn * 64;
-    const int rla = vtc ? 9 : 8, rlb = vtc ? 7 : 8, boff = vtc ? 32768 : 16384;
-    const int mw = ((vtc && (wn >> 1)) ? m0b : m0a) + wm * 128, nw = n0 + b_rb;   // this wave's output origin
+    const bool vtc = PAIR && vt, hfc = HALF && vt;
+    const int a_rb = hfc ? (wave >> 1) * 64 : (vtc ? (wn >> 1) * 256 : 0) + wm * 128, b_rb = (vtc || hfc) ? (wn & 1) * 64 : wn * 64;
+    const int rla = vtc ? 9 : 8, rlb = (vtc || hfc) ? 7 : 8, boff = vtc ? 32768 : 16384;
+    const int mw = hfc ? m0a + a_rb : ((vtc && (wn >> 1)) ? m0b : m0a) + wm * 128, nw = n0 + b_rb;   // this wave's output origin
+    const int tm_eff = hfc ? 2 : TM;                    // row tiles of this wave's output
     const int zw = z_;                                  // this item's k-slice (fp32 slab index)
     wait_vmcnt<0>();                                   // this item's first units have landed; last item's stores are out
     if (DYN && wave == 0) {                            // ... and so has the cursor fetch issued at the last hand-over
@@ -783,15 +793,15 @@ __global__ __launch_bounds__(512) void gemm_pers_kernel(GemmParams p) {
     if (DYN) nxt = receive();
     if (late) __builtin_amdgcn_s_barrier();            // stagger the second wave of each SIMD by one barrier interval
     // one k-unit = two phases; REM = units that follow it (3 = steady state: both DMA halves issued, 6-7 instructions left in flight)
-    auto unit = [&](int t, auto rem_c) {
-      constexpr int REM = decltype(rem_c)::value;
+    auto unit = [&](int t, auto rem_c, auto th_c) {
+      constexpr int REM = decltype(rem_c)::value, TH = decltype(th_c)::value;   // TH row tiles per phase (2; 1 for half items)
       const char* sA = smem + (t & 3) * UNIT;
       const char* sB = sA + boff;
       auto rest_a = [&]() { if (REM >= 2) issue_hi(); };           // phase a: rest of unit t+2
       auto rest_b = [&]() {                                          // phase b: first pieces of unit t+3, then the counted wait
         if (REM >= 3) issue_lo();
-        if (REM >= 3) { if (vtc) wait_vmcnt<7>(); else wait_vmcnt<6>(); }   // unit t+1 landed; t+2 and the start of t+3 in flight
-        else if (REM == 2) { if (vtc) wait_vmcnt<5>(); else wait_vmcnt<4>(); }
+        if (REM >= 3) { if (vtc) wait_vmcnt<7>(); else if (TH == 1) wait_vmcnt<5>(); else wait_vmcnt<6>(); }   // unit t+1 landed; t+2 and the start of t+3 in flight
+        else if (REM == 2) { if (vtc) wait_vmcnt<5>(); else if (TH == 1) wait_vmcnt<3>(); else wait_vmcnt<4>(); }
         else if (REM == 1) wait_vmcnt<0>();
       };
       // phases split the wave's rows: a = upper half x all columns (B fragments stay in registers for b = lower half)
@@ -819,11 +829,14 @@ __global__ __launch_bounds__(512) void gemm_pers_kernel(GemmParams p) {
         PXA_SB(); __builtin_amdgcn_s_barrier(); PXA_SB();
       }
     };
-    int t = 0;
-    for (; t < nk - 3; t++) unit(t, IntC<3>{});
-    if (nk >= 3) unit(t++, IntC<2>{});
-    unit(t++, IntC<1>{});
-    unit(t++, IntC<0>{});
+    auto run_units = [&](auto th_c) {
+      int t = 0;
+      for (; t < nk - 3; t++) unit(t, IntC<3>{}, th_c);
+      if (nk >= 3) unit(t++, IntC<2>{}, th_c);
+      unit(t++, IntC<1>{}, th_c);
+      unit(t++, IntC<0>{}, th_c);
+    };
+    if (HALF && hfc) run_units(IntC<1>{}); else run_units(IntC<2>{});
     if (!late) __builtin_amdgcn_s_barrier();           // every wave has executed the same number of barriers; the ring is idle
 
     // ---- hand-over: prefetch the next item's first units, then this item's epilogue
@@ -918,7 +931,8 @@ __global__ __launch_bounds__(512) void gemm_pers_kernel(GemmParams p) {
       if (want_aux) load_aux(0, ax[0]);
 #pragma unroll
       for (int i = 0; i < TM; i++) {
-        if (want_aux && i + 1 < TM) load_aux(i + 1, ax[(i + 1) & 1]);
+        if (i >= tm_eff) break;                        // half items: two row tiles per wave
+        if (want_aux && i + 1 < tm_eff) load_aux(i + 1, ax[(i + 1) & 1]);
 #pragma unroll
         for (int pass = 0; pass < 2; pass++) {         // pass 0: second output (dual-output flavours only); pass 1: final values
           if (pass == 0 && !dual) continue;
@@ -991,19 +1005,21 @@ __global__ __launch_bounds__(512) void gemm_pers_kernel(GemmParams p) {
 static std::atomic<unsigned> g_launch_seq{0};          // cursor-slot round robin, shared by every instantiation of the persistent kernel
 // work items of the persistent kernel per k-slice (must match the kernel's own count)
 static inline bool pers_pairing(int M, int N) { return N % 256 > 0 && N % 256 <= 128 && ((M + 255) / 256) % 2 == 0; }
-static inline int pers_tiles(int M, int N, bool pair) {
+static inline bool pers_halfcol(int N) { return N % 256 > 0 && N % 256 <= 128; }
+static inline int pers_tiles(int M, int N, int rm) {
   const int mt = (M + 255) / 256, ntf = N / 256;
-  const bool pairing = pair && pers_pairing(M, N);
+  if (rm == 2 && pers_halfcol(N)) return mt * ntf + mt;
+  const bool pairing = rm == 1 && pers_pairing(M, N);
   return mt * (pairing ? ntf : (N + 255) / 256) + (pairing ? mt / 2 : 0);
 }
-template <int LAYOUT, int EPI, bool PAIR = false>
+template <int LAYOUT, int EPI, int RM = 0>
 int launch_pers(GemmParams p, int split, hipStream_t s) {
   p.split = split;
   constexpr int LDSP = 4 * 40960;                      // the ring (4 x 40 KiB slots) = the CU's whole 160 KiB: one workgroup per CU
   static bool attr_set_pp = false;
   static int n_cu = 0;
   if (!attr_set_pp) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_pers_kernel<LAYOUT, EPI, PAIR>), hipFuncAttributeMaxDynamicSharedMemorySize, LDSP);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_pers_kernel<LAYOUT, EPI, RM>), hipFuncAttributeMaxDynamicSharedMemorySize, LDSP);
     if (e != hipSuccess) { pxa_set_error("hipFuncSetAttribute(gemm_pers<%d,%d>): %s", LAYOUT, EPI, hipGetErrorString(e)); return -3; }
     int dev = 0;
     hipDeviceProp_t prop;
@@ -1011,10 +1027,10 @@ int launch_pers(GemmParams p, int split, hipStream_t s) {
     n_cu = prop.multiProcessorCount;
     attr_set_pp = true;
   }
-  const int tiles = pers_tiles(p.M, p.N, PAIR) * split;
+  const int tiles = pers_tiles(p.M, p.N, RM) * split;
   static const bool force_static = getenv("PXA_GEMM_STATIC") != nullptr;   // A/B experiments (tools/contention_test.py)
   p.sched_slot = force_static ? -1 : (int)(g_launch_seq.fetch_add(1u) & 63u);
-  hipLaunchKernelGGL((gemm_pers_kernel<LAYOUT, EPI, PAIR>), dim3(tiles < n_cu ? tiles : n_cu), dim3(512), LDSP, s, p);
+  hipLaunchKernelGGL((gemm_pers_kernel<LAYOUT, EPI, RM>), dim3(tiles < n_cu ? tiles : n_cu), dim3(512), LDSP, s, p);
   PXA_LAUNCH_CHECK();
   return 0;
 }
@@ -1044,14 +1060,16 @@ int launch_glds(GemmParams p, int split, hipStream_t s) {
   static const bool no_pers = getenv("PXA_GEMM_NO_PERSISTENT") != nullptr;
   if (LAYOUT != 2 && TBM == 256 && TBN == 256 && split == 1 && p.out && !p.outf && !no_pers) {
     constexpr int LY = LAYOUT == 2 ? 0 : LAYOUT;
-    if (p.act == 0 && !p.colsum) return launch_pers<LY, 0>(p, 1, s);
-    if (p.act == 3 && !p.colsum) return launch_pers<LY, 1>(p, 1, s);
-    if (p.act == 4 && p.colsum) return launch_pers<LY, 2>(p, 1, s);
-    return launch_pers<LY, 3>(p, 1, s);
+    static const bool no_half = getenv("PXA_GEMM_NO_HALF_ITEMS") != nullptr;   // A/B: pad the remainder column to a full tile
+    const bool hc = pers_halfcol(p.N) && !no_half;
+    if (p.act == 0 && !p.colsum) return hc ? launch_pers<LY, 0, 2>(p, 1, s) : launch_pers<LY, 0, 0>(p, 1, s);
+    if (p.act == 3 && !p.colsum) return launch_pers<LY, 1, 0>(p, 1, s);      // fc1 forward: N = 4608, no remainder column
+    if (p.act == 4 && p.colsum) return hc ? launch_pers<LY, 2, 2>(p, 1, s) : launch_pers<LY, 2, 0>(p, 1, s);
+    return launch_pers<LY, 3, 0>(p, 1, s);
   }
   // fp32 weight gradients (TN, split-K slabs / single-slice read-modify-write / plain store): the same persistent kernel
   if (LAYOUT == 2 && TBM == 256 && TBN == 256 && p.outf && !p.out && !p.bias && p.act == 0 && p.accumulate != 1 && !p.colsum && !no_pers)
-    return pers_pairing(p.M, p.N) ? launch_pers<2, 0, true>(p, split, s) : launch_pers<2, 0, false>(p, split, s);
+    return pers_pairing(p.M, p.N) ? launch_pers<2, 0, 1>(p, split, s) : launch_pers<2, 0, 0>(p, split, s);
   if (LAYOUT != 2 && p.out && !p.outf && !dual && !no_stage) return launch_glds_e<LAYOUT, TBM, TBN, WM, WN, 1>(p, split, s);
   if (p.colsum) {                                         // not fused on this path: separate column-sum pass over the output
     float* cs = p.colsum;
@@ -1143,7 +1161,7 @@ extern "C" int pxa_gemm(const pxa_gemm_args* a, hipStream_t stream) {
     double best = 1e30;
     for (const Cfg& c : cfgs) {
       if (c.tile == 256 && (a->M < 256 || a->N < 256)) continue;
-      const long tiles = c.tile == 256 ? pers_tiles(a->M, a->N, true) : (long)((a->M + c.bm - 1) / c.bm) * ((a->N + c.bn - 1) / c.bn);
+      const long tiles = c.tile == 256 ? pers_tiles(a->M, a->N, 1) : (long)((a->M + c.bm - 1) / c.bm) * ((a->N + c.bn - 1) / c.bn);
       for (int sp = 1; sp <= 16; sp++) {
         const int kp = ((a->K + sp - 1) / sp + BK - 1) / BK * BK;
         if ((long)kp * (sp - 1) >= a->K) continue;               // would leave an empty split

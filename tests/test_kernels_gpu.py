@@ -72,9 +72,10 @@ def test_gemm_nn_gelu_grad(ops):
     assert rel_l2(part.sum(0)[:N], (dy[:, :72].float() @ w[:72].float()).to(torch.bfloat16).float().sum(0)) < 1e-4
 
 
-@pytest.mark.parametrize("M,N,K", [(1100, 1152, 256), (2048, 1280, 128), (1024, 4608, 64)])
+@pytest.mark.parametrize("M,N,K", [(1100, 1152, 256), (2048, 1280, 128), (1024, 4608, 64), (2300, 1096, 192), (4096, 1152, 96)])
 def test_gemm_persistent_kernel_epilogues(ops, M, N, K):
-    """M, N >= 1024: the persistent 256x256 kernel (ragged last tiles in both directions) with every epilogue flavour."""
+    """M, N >= 1024: the persistent 256x256 kernel (ragged last tiles in both directions; N % 256 <= 128: half-width remainder items)
+    with every epilogue flavour."""
     a, w, b = bf(rnd(M, K, seed=1)), bf(rnd(N, K, scale=K ** -0.5, seed=2)), rnd(N, seed=3)
     pre = a.float() @ w.float().t() + b
     x = pre.clone().requires_grad_(True)
