@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define PXA_ABI_VERSION 1
+#define PXA_ABI_VERSION 2
 /* Kernels that fuse a bias-gradient column sum add into one of PXA_COLSUM_SLOTS partial rows ([slot][stride] fp32, caller-zeroed),
  * chosen per sample / row tile, so no address sees thousands of atomics; pxa_colsum_reduce folds the partials into the gradient. */
 #define PXA_COLSUM_SLOTS 16
@@ -64,6 +64,9 @@ typedef struct {
   long splitk_ws_elems;          /*  pxa_gemm_splitk_ws_elems); NULL -> partials are combined with fp32 atomics (slow)       */
   float* colsum;                 /* optional slotted partials: += column sums of the bf16 output (bias gradient)              */
   long colsum_stride;
+  int k_seg;                     /* segmented-K A operand (layout NT only, 0 = plain): element k of row m is read from          */
+  long a_seg_stride;             /*  A[m*lda + (k / k_seg)*a_seg_stride + k % k_seg]; k_seg a multiple of 64 dividing K.       */
+                                 /*  The implicit 3x3 convolution of the VAE kernel set: see pxa_vae_* below.                  */
 } pxa_gemm_args;
 /* Upper bound of the split-K workspace (in floats) pxa_gemm may use for an (M, N) fp32-accumulate output. */
 long pxa_gemm_splitk_ws_elems(int M, int N);
@@ -165,6 +168,38 @@ int pxa_clip_coef(const float* sumsq, float* out2, float max_norm, float inv_wor
 int pxa_adamw_step(float* p, const float* g, float* m, float* v, void* p_bf16, long n, float lr, float beta1, float beta2,
                    float eps, float weight_decay, int step, const float* gscale, hipStream_t stream);
 int pxa_cast_f32_bf16(const float* x, void* y_bf16, long n, hipStream_t stream);
+
+/* ---------------------------------------------------------------------------------------------- VAE conv stack
+ * The SDXL-VAE / SD-VAE (diffusers AutoencoderKL) encode / decode path: vae.encode(...).latent_dist (train_scripts/train.py:149-153),
+ * vae.decode(latent / scaling_factor).sample (scripts/inference.py:136, train_scripts/train.py:88).  Forward only (the VAE is frozen).
+ * Activations are bf16 NHWC pixel grids; pixel (b, y, x) is the C-vector at  ptr + ((b*img_pitch + y*row_pitch + x + origin) * C).
+ *   compact grid:      row_pitch = W,   img_pitch = H*W,         origin = 0
+ *   padded-grid view:  row_pitch = W+2, img_pitch = (H+2)*(W+2), origin = W+3   (pixel (0,0) of the image inside its zero border)
+ * A 3x3 stride-1 pad-1 convolution is pxa_gemm over the PADDED pixels of a zero-bordered input (layout NT, A = first padded pixel
+ * minus (W+3) pixels, lda = C, M = B*(H+2)*(W+2), K = 9*C, k_seg = 3*C, a_seg_stride = (W+2)*C, B = weight as [Cout][ky][kx][Cin]):
+ * output row m is the convolution centred on padded pixel m, i.e. the result is itself a padded-grid view whose border rows hold
+ * garbage nobody reads.  The buffer needs W+3 readable pixels in front of and behind the padded images.
+ * 1x1 convolutions and the attention projections are plain pxa_gemm calls over the rows of a grid.                              */
+typedef struct { void* ptr; int B, H, W, C; int row_pitch; long img_pitch; long origin; } pxa_grid;
+/* GroupNorm statistics over the interior pixels: mean / rstd [B*groups] (torch.nn.GroupNorm(groups, C, eps): biased variance).
+ * ws: B*groups*2 doubles of scratch (zeroed by the call).  C/groups must be a multiple of 4, C = 8 * 2^n. */
+int pxa_vae_gn_stats(const pxa_grid* x, int groups, float eps, double* ws, float* mean, float* rstd, hipStream_t stream);
+/* y[b, yo, xo] = act(norm(x[b, yo/upsample, xo/upsample])): GroupNorm affine when mean != NULL, SiLU when silu, nearest-neighbour
+ * 2x upsampling when upsample == 2 (diffusers Upsample2D).  Writes the interior of y only. */
+int pxa_vae_gn_apply(const pxa_grid* x, const float* mean, const float* rstd, const float* gamma, const float* beta, int groups,
+                     int silu, int upsample, const pxa_grid* y, hipStream_t stream);
+/* Explicit patch matrix for the stride-2 / few-channel convolutions: col[(b, yo, xo)][(ky*3+kx)*C + c] (bf16, row length 9*C) =
+ * act(norm(x[b, yo*stride + ky - pad, xo*stride + kx - pad])), zero outside the image.  pad 1: Conv2d(padding=1); pad 0 with
+ * Ho = H/2: diffusers Downsample2D (F.pad (0,1,0,1) then stride 2, padding 0). */
+int pxa_vae_im2col3x3(const pxa_grid* x, const float* mean, const float* rstd, const float* gamma, const float* beta, int groups,
+                      int silu, int stride, int pad, int Ho, int Wo, void* col_bf16, hipStream_t stream);
+/* out = a + b over the interior pixels (residual connections; the three grids may have different pitches). */
+int pxa_vae_add(const pxa_grid* a, const pxa_grid* b, const pxa_grid* out, hipStream_t stream);
+/* P[r][:] = softmax(scale * S[r][:]) with fp32 scores in, bf16 probabilities out (mid-block attention: one 512-wide head). */
+int pxa_vae_softmax_rows(const float* s, long ld, void* p_bf16, long ldp, int rows, int cols, float scale, hipStream_t stream);
+/* fp32 NCHW (B, C, H, W) image / latent -> bf16 grid scaled by mul, channels C..grid.C-1 zero; and back (first C channels). */
+int pxa_vae_nchw_to_grid(const float* img, int C, float mul, const pxa_grid* y, hipStream_t stream);
+int pxa_vae_grid_to_nchw(const pxa_grid* x, int C, float* img, hipStream_t stream);
 
 #ifdef __cplusplus
 }

@@ -32,6 +32,8 @@ struct GemmParams {
   float* slab;
   float* colsum;   // optional [PXA_COLSUM_SLOTS][colsum_stride] partials: += column sums of the bf16 output, staged epilogue only
   long colsum_stride;
+  int k_seg;       // segmented-K A operand (implicit 3x3 convolution, layout NT): A[m][k] = A[m*lda + k + (k / k_seg) * seg_jump]
+  long seg_jump;   // = a_seg_stride - k_seg
 };
 
 // ---- global -> registers (4 x 16 B per thread per operand tile), zero-filled out of bounds
@@ -417,7 +419,10 @@ __device__ __forceinline__ void epilogue_t(const GemmParams& p, const f32x16 (&a
   }
 }
 
-template <int LAYOUT, int TBM, int TBN, int WM, int WN, int EPI>
+// SEG: the k range of A is cut into segments of p.k_seg elements, segment s starting p.seg_jump elements further on than a plain
+// row would have it (rows may overlap: lda < K).  A 3x3 convolution over a zero-padded NHWC image is exactly that GEMM: the three
+// taps of one kernel row are 3*C contiguous elements of the padded image, the next kernel row is one image row further on.
+template <int LAYOUT, int TBM, int TBN, int WM, int WN, int EPI, bool SEG = false>
 __global__ __launch_bounds__(WM * WN * 64) void gemm_glds_kernel(GemmParams p) {
   constexpr bool A_KC = (LAYOUT != 2), B_KC = (LAYOUT == 0);
   constexpr int NW = WM * WN, TM = TBM / WM / 32, TN = TBN / WN / 32;
@@ -439,9 +444,15 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_glds_kernel(GemmParams p) {
 #pragma unroll
       for (int g = 0; g < 16; g++) acc[i][j][g] = 0.f;
 
+  const bf16_t* Ab = p.A;                              // SEG: A base of the segment the next DMA reads from
+  int seg_left = SEG ? p.k_seg : 0;                    // ... and the k elements left in it (split-K is not combined with SEG)
+  auto seg_advance = [&]() {
+    if (SEG) { seg_left -= BK; if (seg_left == 0) { Ab += p.seg_jump; seg_left = p.k_seg; } }
+  };
   if (nk > 0) {
-    dma_tile<A_KC, TBM, NW>(smem, p.A, p.lda, m0, p.M, kbeg, wave, lane);
+    dma_tile<A_KC, TBM, NW>(smem, Ab, p.lda, m0, p.M, kbeg, wave, lane);
     dma_tile<B_KC, TBN, NW>(smem + A_BYTES, p.B, p.ldb, n0, p.N, kbeg, wave, lane);
+    seg_advance();
   }
   for (int kt = 0; kt < nk; kt++) {
     const int cur = kt & 1;
@@ -469,8 +480,9 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_glds_kernel(GemmParams p) {
         for (int j = 0; j < TN; j++) acc[i][j] = mfma32(bf[ks & 1][j], af[ks & 1][i], acc[i][j]);
       if (ks == 0 && kt + 1 < nk) {
         char* nxt = smem + (cur ^ 1) * STAGE;
-        dma_tile<A_KC, TBM, NW>(nxt, p.A, p.lda, m0, p.M, kbeg + (kt + 1) * BK, wave, lane);
+        dma_tile<A_KC, TBM, NW>(nxt, Ab, p.lda, m0, p.M, kbeg + (kt + 1) * BK, wave, lane);
         dma_tile<B_KC, TBN, NW>(nxt + A_BYTES, p.B, p.ldb, n0, p.N, kbeg + (kt + 1) * BK, wave, lane);
+        seg_advance();
       }
     }
   }
@@ -1035,19 +1047,19 @@ int launch_pers(GemmParams p, int split, hipStream_t s) {
   return 0;
 }
 
-template <int LAYOUT, int TBM, int TBN, int WM, int WN, int EPI>
+template <int LAYOUT, int TBM, int TBN, int WM, int WN, int EPI, bool SEG = false>
 int launch_glds_e(GemmParams p, int split, hipStream_t s) {
   p.split = split;
   constexpr int LDSG = 2 * (TBM + TBN) * 128;
   static_assert(WM * WN * (TBM / WM) * EPI_STRIDE <= LDSG, "staged epilogue must fit the operand stages");
   static bool attr_set_g = false;
   if (!attr_set_g) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_glds_kernel<LAYOUT, TBM, TBN, WM, WN, EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, LDSG);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_glds_kernel<LAYOUT, TBM, TBN, WM, WN, EPI, SEG>), hipFuncAttributeMaxDynamicSharedMemorySize, LDSG);
     if (e != hipSuccess) { pxa_set_error("hipFuncSetAttribute(gemm_glds<%d,%d,%d>): %s", LAYOUT, TBM, TBN, hipGetErrorString(e)); return -3; }
     attr_set_g = true;
   }
   dim3 grid(((p.M + TBM - 1) / TBM) * ((p.N + TBN - 1) / TBN) * split, 1, 1);
-  hipLaunchKernelGGL((gemm_glds_kernel<LAYOUT, TBM, TBN, WM, WN, EPI>), grid, dim3(WM * WN * 64), LDSG, s, p);
+  hipLaunchKernelGGL((gemm_glds_kernel<LAYOUT, TBM, TBN, WM, WN, EPI, SEG>), grid, dim3(WM * WN * 64), LDSG, s, p);
   PXA_LAUNCH_CHECK();
   return 0;
 }
@@ -1093,6 +1105,13 @@ int launch(GemmParams p, int split, hipStream_t s) {
   }
   dim3 grid(((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN) * split, 1, 1);
   const bool fast = (p.K % BK == 0) && (p.k_per_split % BK == 0) && !getenv("PXA_GEMM_NO_GLDS");
+  if (p.k_seg) {                                          // implicit 3x3 convolution (checked by pxa_gemm: NT, K and k_seg multiples of 64)
+    if constexpr (LAYOUT == 0) {
+      if (p.out && !p.outf && p.act == 0) return launch_glds_e<0, 128, 128, 2, 2, 1, true>(p, 1, s);
+      return launch_glds_e<0, 128, 128, 2, 2, 0, true>(p, 1, s);
+    }
+    return -2;
+  }
   if (fast) {
     static const char* force = getenv("PXA_GEMM_TILE");   // "128" | "256x128" | "256" : A/B experiments
     int tile = force ? atoi(force) * (strstr(force, "x128") ? -1 : 1) : 0;
@@ -1151,6 +1170,11 @@ extern "C" int pxa_gemm(const pxa_gemm_args* a, hipStream_t stream) {
   p.outf = a->out_f32; p.ldf = a->ld_f32;
   p.act = a->act; p.accumulate = a->accumulate;
   p.tile_hint = 0;
+  p.k_seg = a->k_seg; p.seg_jump = a->k_seg ? a->a_seg_stride - a->k_seg : 0;
+  if (a->k_seg) {
+    PXA_CHECK(a->layout == 0 && split == 1 && !a->colsum, "pxa_gemm: k_seg needs layout NT, no split-K, no colsum");
+    PXA_CHECK(a->k_seg > 0 && a->k_seg % BK == 0 && a->K % a->k_seg == 0 && a->a_seg_stride % 8 == 0, "pxa_gemm: k_seg=%d must be a multiple of %d dividing K=%d (segment stride a multiple of 8)", a->k_seg, BK, a->K);
+  }
   if (a->split_k == 0 && a->out_f32 && a->accumulate && !a->out_bf16 && a->act == 0 && !a->bias && a->K % BK == 0) {
     // Split-K weight-gradient GEMMs (K = tokens, 65536): a handful of long-running workgroups, so wave quantisation against the
     // 256 CUs decides the time.  Pick (tile, split) minimising  rounds x k-tiles x tile cost  + atomic epilogue traffic.

@@ -1,0 +1,302 @@
+// SDXL-VAE / SD-VAE (AutoencoderKL) conv stack: the kernels around the GEMMs.
+// Call sites in the reference: vae.encode(...).latent_dist (train_scripts/train.py:149-153), vae.decode(...).sample
+// (scripts/inference.py:136, train_scripts/train.py:88).  The network itself lives in an un-vendored dependency (diffusers
+// AutoencoderKL, unpinned: requirements.txt:2); the architecture is restated from its public config in oracle/vae_ref.py.
+//
+// Data layout: activations are bf16 NHWC "pixel grids" (pxa_grid): a pixel is a C-vector, so every convolution is a GEMM over
+// pixels.  A 3x3 stride-1 convolution reads a ZERO-PADDED grid (H+2) x (W+2): the three taps of one kernel row are 3*C contiguous
+// elements there, so the convolution is pxa_gemm with the segmented-K A operand (k_seg = 3*C, a_seg_stride = (W+2)*C, lda = C,
+// one output row per PADDED pixel; the border rows are never read by anybody).  No im2col matrix exists for those layers.
+// GroupNorm + SiLU (+ nearest 2x upsampling) are applied by the kernel that writes the padded grid: one read of the producer's
+// output, one write.  Stride-2 (encoder downsampling) and the 3/4-channel stem convolutions gather an explicit patch matrix
+// (im2col) - their outputs are 4x smaller / their K is 72, so that traffic is small.
+// All kernels here are HBM-bound; statistics and arithmetic are fp32 (group sums are combined in fp64).
+#include "common.h"
+#include "../../include/pixart_hip.h"
+
+namespace {
+using namespace pxa;
+
+struct Grid {
+  bf16_t* ptr; int B, H, W, C, row_pitch; long img_pitch, origin;
+  __device__ __forceinline__ bf16_t* at(int b, int y, int x) const { return ptr + ((long)b * img_pitch + (long)y * row_pitch + x + origin) * C; }
+};
+static inline Grid to_grid(const pxa_grid* g) { return Grid{(bf16_t*)g->ptr, g->B, g->H, g->W, g->C, g->row_pitch, g->img_pitch, g->origin}; }
+
+__device__ __forceinline__ uint4 pack8(const float (&f)[8]) {
+  const uint2 a = pack_bf16x4(f[0], f[1], f[2], f[3]), b = pack_bf16x4(f[4], f[5], f[6], f[7]);
+  return make_uint4(a.x, a.y, b.x, b.y);
+}
+
+// ---- GroupNorm statistics: per (sample, group) sum and sum of squares over H*W*(C/groups) elements.
+// A thread owns one 8-channel chunk of a pixel and keeps two partial pairs (channels 0-3 / 4-7: groups are >= 4 channels wide);
+// a block folds its partials per group in LDS and adds them to the fp64 accumulators with one atomic per group.
+__global__ __launch_bounds__(256) void gn_stats_kernel(Grid x, int cpg, double* __restrict__ ws) {
+  __shared__ float red[2 * 256];                       // [group][sum, sumsq], groups <= 256
+  const int CV = x.C / 8, PPB = 256 / CV, G = x.C / cpg, b = blockIdx.y;
+  const int cv = threadIdx.x % CV, pl = threadIdx.x / CV;
+  for (int i = threadIdx.x; i < 2 * G; i += 256) red[i] = 0.f;
+  __syncthreads();
+  float s0 = 0.f, q0 = 0.f, s1 = 0.f, q1 = 0.f;
+  const long HW = (long)x.H * x.W;
+  for (long p = (long)blockIdx.x * PPB + pl; p < HW; p += (long)gridDim.x * PPB) {
+    const int y = p / x.W, xx = p - (long)y * x.W;
+    float f[8];
+    unpack_bf16x8(*reinterpret_cast<const uint4*>(x.at(b, y, xx) + cv * 8), f);
+    s0 += (f[0] + f[1]) + (f[2] + f[3]); q0 += (f[0] * f[0] + f[1] * f[1]) + (f[2] * f[2] + f[3] * f[3]);
+    s1 += (f[4] + f[5]) + (f[6] + f[7]); q1 += (f[4] * f[4] + f[5] * f[5]) + (f[6] * f[6] + f[7] * f[7]);
+  }
+  const int g0 = (cv * 8) / cpg, g1 = (cv * 8 + 4) / cpg;
+  atomicAdd(&red[2 * g0], s0); atomicAdd(&red[2 * g0 + 1], q0);
+  atomicAdd(&red[2 * g1], s1); atomicAdd(&red[2 * g1 + 1], q1);
+  __syncthreads();
+  for (int i = threadIdx.x; i < 2 * G; i += 256) atomicAdd(&ws[(long)b * 2 * G + i], (double)red[i]);
+}
+__global__ void gn_finalize_kernel(const double* __restrict__ ws, float* __restrict__ mean, float* __restrict__ rstd, int n_groups, double count, float eps) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_groups) return;
+  const double m = ws[2 * i] / count, var = fmax(ws[2 * i + 1] / count - m * m, 0.0);
+  mean[i] = (float)m;
+  rstd[i] = (float)(1.0 / sqrt(var + (double)eps));
+}
+
+// the value a consumer sees: optional GroupNorm (affine), optional SiLU
+struct Norm {
+  const float* mean; const float* rstd; const float* gamma; const float* beta; int cpg, G, silu;
+  __device__ __forceinline__ void apply(float (&f)[8], int b, int c0) const {
+    if (mean) {
+#pragma unroll
+      for (int h = 0; h < 2; h++) {
+        const int g = (c0 + 4 * h) / cpg;
+        const float m = mean[b * G + g], r = rstd[b * G + g];
+        const float4 ga = *reinterpret_cast<const float4*>(gamma + c0 + 4 * h), be = *reinterpret_cast<const float4*>(beta + c0 + 4 * h);
+        f[4 * h] = (f[4 * h] - m) * r * ga.x + be.x; f[4 * h + 1] = (f[4 * h + 1] - m) * r * ga.y + be.y;
+        f[4 * h + 2] = (f[4 * h + 2] - m) * r * ga.z + be.z; f[4 * h + 3] = (f[4 * h + 3] - m) * r * ga.w + be.w;
+      }
+    }
+    if (silu) {
+#pragma unroll
+      for (int e = 0; e < 8; e++) f[e] = pxa_silu(f[e]);
+    }
+  }
+  static __device__ __forceinline__ float pxa_silu(float v) { return v / (1.f + __expf(-v)); }
+};
+
+// ---- y[b, yo, xo] = act(norm(x[b, yo / up, xo / up])): writes the interior of y (the zero border of a padded grid is the caller's)
+__global__ __launch_bounds__(256) void gn_apply_kernel(Grid x, Norm nm, int up, Grid y) {
+  const int CV = x.C / 8;
+  const long total = (long)y.B * y.H * y.W * CV;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += gridDim.x * 256L) {
+    const int cv = i % CV;
+    long p = i / CV;
+    const int xo = p % y.W; p /= y.W;
+    const int yo = p % y.H, b = p / y.H;
+    float f[8];
+    unpack_bf16x8(*reinterpret_cast<const uint4*>(x.at(b, yo / up, xo / up) + cv * 8), f);
+    nm.apply(f, b, cv * 8);
+    *reinterpret_cast<uint4*>(y.at(b, yo, xo) + cv * 8) = pack8(f);
+  }
+}
+
+// ---- explicit patch matrix: col[(b, yo, xo)][tap * C + c] = act(norm(x[b, yo*stride + ky - pad, xo*stride + kx - pad])) or 0 outside
+__global__ __launch_bounds__(256) void im2col3x3_kernel(Grid x, Norm nm, int stride, int pad, int Ho, int Wo, bf16_t* __restrict__ col) {
+  const int CV = x.C / 8;
+  const long total = (long)x.B * Ho * Wo * 9 * CV;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += gridDim.x * 256L) {
+    const int cv = i % CV;
+    long p = i / CV;
+    const int tap = p % 9; p /= 9;
+    const int xo = p % Wo; p /= Wo;
+    const int yo = p % Ho, b = p / Ho;
+    const int yi = yo * stride + tap / 3 - pad, xi = xo * stride + tap % 3 - pad;
+    uint4 v = make_uint4(0u, 0u, 0u, 0u);
+    if (yi >= 0 && yi < x.H && xi >= 0 && xi < x.W) {
+      float f[8];
+      unpack_bf16x8(*reinterpret_cast<const uint4*>(x.at(b, yi, xi) + cv * 8), f);
+      nm.apply(f, b, cv * 8);
+      v = pack8(f);
+    }
+    *reinterpret_cast<uint4*>(col + i * 8) = v;          // i enumerates the 16-byte chunks of col in memory order
+  }
+}
+
+__global__ __launch_bounds__(256) void add_kernel(Grid a, Grid bb, Grid o) {
+  const int CV = a.C / 8;
+  const long total = (long)a.B * a.H * a.W * CV;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += gridDim.x * 256L) {
+    const int cv = i % CV;
+    long p = i / CV;
+    const int xx = p % a.W; p /= a.W;
+    const int y = p % a.H, b = p / a.H;
+    float f[8], g[8];
+    unpack_bf16x8(*reinterpret_cast<const uint4*>(a.at(b, y, xx) + cv * 8), f);
+    unpack_bf16x8(*reinterpret_cast<const uint4*>(bb.at(b, y, xx) + cv * 8), g);
+#pragma unroll
+    for (int e = 0; e < 8; e++) f[e] += g[e];
+    *reinterpret_cast<uint4*>(o.at(b, y, xx) + cv * 8) = pack8(f);
+  }
+}
+
+// ---- P = softmax(scale * S) per row, S fp32 (the single 512-wide head of the mid-block attention: the scores stay fp32 until here)
+__global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restrict__ s, long ld, bf16_t* __restrict__ p, long ldp, int cols, float scale) {
+  __shared__ float red[4];
+  const float* row = s + (long)blockIdx.x * ld;
+  bf16_t* out = p + (long)blockIdx.x * ldp;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  auto block_reduce = [&](float v, bool is_max) -> float {
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const float w = __shfl_xor(v, o); v = is_max ? fmaxf(v, w) : v + w; }
+    __syncthreads();
+    if (lane == 0) red[wave] = v;
+    __syncthreads();
+    return is_max ? fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])) : (red[0] + red[1]) + (red[2] + red[3]);
+  };
+  float mx = -INFINITY;
+  for (int c = threadIdx.x * 4; c < cols; c += 1024) {
+    const float4 v = *reinterpret_cast<const float4*>(row + c);
+    mx = fmaxf(fmaxf(mx, fmaxf(v.x, v.y)), fmaxf(v.z, v.w));
+  }
+  mx = block_reduce(mx, true);
+  float sum = 0.f;
+  for (int c = threadIdx.x * 4; c < cols; c += 1024) {   // second and third pass hit the L2 (a row is <= 64 KiB at 2K latents)
+    const float4 v = *reinterpret_cast<const float4*>(row + c);
+    sum += (__expf((v.x - mx) * scale) + __expf((v.y - mx) * scale)) + (__expf((v.z - mx) * scale) + __expf((v.w - mx) * scale));
+  }
+  sum = block_reduce(sum, false);
+  const float inv = 1.f / sum;
+  for (int c = threadIdx.x * 4; c < cols; c += 1024) {
+    const float4 v = *reinterpret_cast<const float4*>(row + c);
+    *reinterpret_cast<uint2*>(out + c) = pack_bf16x4(__expf((v.x - mx) * scale) * inv, __expf((v.y - mx) * scale) * inv,
+                                                     __expf((v.z - mx) * scale) * inv, __expf((v.w - mx) * scale) * inv);
+  }
+}
+
+// ---- fp32 NCHW image / latent <-> bf16 grid (channels padded with zeros up to the grid's C)
+__global__ __launch_bounds__(256) void nchw_to_grid_kernel(const float* __restrict__ img, int C, float mul, Grid y) {
+  const long total = (long)y.B * y.H * y.W, HW = (long)y.H * y.W;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += gridDim.x * 256L) {
+    const int b = i / HW;
+    const long p = i - b * HW;
+    const int yy = p / y.W, xx = p - (long)yy * y.W;
+    bf16_t* dst = y.at(b, yy, xx);
+    for (int c0 = 0; c0 < y.C; c0 += 8) {
+      float f[8];
+#pragma unroll
+      for (int e = 0; e < 8; e++) f[e] = (c0 + e < C) ? img[((long)b * C + c0 + e) * HW + p] * mul : 0.f;
+      *reinterpret_cast<uint4*>(dst + c0) = pack8(f);
+    }
+  }
+}
+__global__ __launch_bounds__(256) void grid_to_nchw_kernel(Grid x, int C, float* __restrict__ img) {
+  const long total = (long)x.B * x.H * x.W, HW = (long)x.H * x.W;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += gridDim.x * 256L) {
+    const int b = i / HW;
+    const long p = i - b * HW;
+    const int yy = p / x.W, xx = p - (long)yy * x.W;
+    const bf16_t* src = x.at(b, yy, xx);
+    for (int c0 = 0; c0 < C; c0 += 8) {
+      float f[8];
+      unpack_bf16x8(*reinterpret_cast<const uint4*>(src + c0), f);
+#pragma unroll
+      for (int e = 0; e < 8; e++)
+        if (c0 + e < C) img[((long)b * C + c0 + e) * HW + p] = f[e];
+    }
+  }
+}
+
+static inline int grid_blocks(long items) { const long b = (items + 255) / 256; return (int)(b < 1 ? 1 : (b > 65536 ? 65536 : b)); }
+static int check_grid(const pxa_grid* g, const char* what) {
+  PXA_CHECK(g && g->ptr, "%s: null grid", what);
+  PXA_CHECK(g->B > 0 && g->H > 0 && g->W > 0 && g->C > 0 && g->C % 8 == 0, "%s: bad grid %d x %d x %d x %d (C must be a multiple of 8)", what, g->B, g->H, g->W, g->C);
+  PXA_CHECK(g->row_pitch >= g->W && g->img_pitch >= (long)(g->H - 1) * g->row_pitch + g->W, "%s: bad pitches", what);
+  return 0;
+}
+static int make_norm(Norm& nm, const float* mean, const float* rstd, const float* gamma, const float* beta, int C, int groups, int silu, const char* what) {
+  nm = Norm{mean, rstd, gamma, beta, 1, 1, silu};
+  if (mean) {
+    PXA_CHECK(rstd && gamma && beta, "%s: GroupNorm needs mean, rstd, gamma and beta", what);
+    PXA_CHECK(groups > 0 && C % groups == 0 && (C / groups) % 4 == 0, "%s: C=%d / groups=%d must be a multiple of 4", what, C, groups);
+    nm.cpg = C / groups; nm.G = groups;
+  }
+  return 0;
+}
+}  // namespace
+
+extern "C" int pxa_vae_gn_stats(const pxa_grid* x, int groups, float eps, double* ws, float* mean, float* rstd, hipStream_t stream) {
+  if (int rc = check_grid(x, "pxa_vae_gn_stats")) return rc;
+  PXA_CHECK(ws && mean && rstd, "pxa_vae_gn_stats: null output");
+  const int C = x->C, CV = C / 8;
+  PXA_CHECK(groups > 0 && groups <= 256 && C % groups == 0 && (C / groups) % 4 == 0, "pxa_vae_gn_stats: C=%d / groups=%d must be a multiple of 4", C, groups);
+  PXA_CHECK(CV <= 256 && 256 % CV == 0, "pxa_vae_gn_stats: C=%d must be 8 * a power of two <= 2048", C);
+  hipError_t e = hipMemsetAsync(ws, 0, sizeof(double) * 2 * groups * x->B, stream);
+  PXA_CHECK(e == hipSuccess, "pxa_vae_gn_stats: memset failed: %s", hipGetErrorString(e));
+  const long HW = (long)x->H * x->W, ppb = 256 / CV;
+  long nb = (HW + ppb * 8 - 1) / (ppb * 8);            // ~8 pixels per thread
+  nb = nb < 1 ? 1 : (nb > 1024 ? 1024 : nb);
+  hipLaunchKernelGGL(gn_stats_kernel, dim3((unsigned)nb, x->B), dim3(256), 0, stream, to_grid(x), C / groups, ws);
+  PXA_LAUNCH_CHECK();
+  const int n = groups * x->B;
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, ws, mean, rstd, n, (double)HW * (C / groups), eps);
+  PXA_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int pxa_vae_gn_apply(const pxa_grid* x, const float* mean, const float* rstd, const float* gamma, const float* beta, int groups,
+                                int silu, int upsample, const pxa_grid* y, hipStream_t stream) {
+  if (int rc = check_grid(x, "pxa_vae_gn_apply(x)")) return rc;
+  if (int rc = check_grid(y, "pxa_vae_gn_apply(y)")) return rc;
+  PXA_CHECK(upsample == 1 || upsample == 2, "pxa_vae_gn_apply: upsample must be 1 or 2");
+  PXA_CHECK(y->B == x->B && y->C == x->C && y->H == x->H * upsample && y->W == x->W * upsample, "pxa_vae_gn_apply: output grid does not match");
+  Norm nm;
+  if (int rc = make_norm(nm, mean, rstd, gamma, beta, x->C, groups, silu, "pxa_vae_gn_apply")) return rc;
+  hipLaunchKernelGGL(gn_apply_kernel, dim3(grid_blocks((long)y->B * y->H * y->W * (y->C / 8))), dim3(256), 0, stream, to_grid(x), nm, upsample, to_grid(y));
+  PXA_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int pxa_vae_im2col3x3(const pxa_grid* x, const float* mean, const float* rstd, const float* gamma, const float* beta, int groups,
+                                 int silu, int stride, int pad, int Ho, int Wo, void* col_bf16, hipStream_t stream) {
+  if (int rc = check_grid(x, "pxa_vae_im2col3x3")) return rc;
+  PXA_CHECK(col_bf16 && (stride == 1 || stride == 2) && (pad == 0 || pad == 1) && Ho > 0 && Wo > 0, "pxa_vae_im2col3x3: bad arguments");
+  Norm nm;
+  if (int rc = make_norm(nm, mean, rstd, gamma, beta, x->C, groups, silu, "pxa_vae_im2col3x3")) return rc;
+  hipLaunchKernelGGL(im2col3x3_kernel, dim3(grid_blocks((long)x->B * Ho * Wo * 9 * (x->C / 8))), dim3(256), 0, stream, to_grid(x), nm, stride, pad, Ho, Wo,
+                     (bf16_t*)col_bf16);
+  PXA_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int pxa_vae_add(const pxa_grid* a, const pxa_grid* b, const pxa_grid* out, hipStream_t stream) {
+  if (int rc = check_grid(a, "pxa_vae_add(a)")) return rc;
+  if (int rc = check_grid(b, "pxa_vae_add(b)")) return rc;
+  if (int rc = check_grid(out, "pxa_vae_add(out)")) return rc;
+  PXA_CHECK(a->B == b->B && a->H == b->H && a->W == b->W && a->C == b->C && a->B == out->B && a->H == out->H && a->W == out->W && a->C == out->C,
+            "pxa_vae_add: grids differ");
+  hipLaunchKernelGGL(add_kernel, dim3(grid_blocks((long)a->B * a->H * a->W * (a->C / 8))), dim3(256), 0, stream, to_grid(a), to_grid(b), to_grid(out));
+  PXA_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int pxa_vae_softmax_rows(const float* s, long ld, void* p_bf16, long ldp, int rows, int cols, float scale, hipStream_t stream) {
+  PXA_CHECK(s && p_bf16 && rows > 0 && cols > 0, "pxa_vae_softmax_rows: bad arguments");
+  PXA_CHECK(cols % 4 == 0 && ld % 4 == 0 && ldp % 4 == 0, "pxa_vae_softmax_rows: cols / ld / ldp must be multiples of 4");
+  hipLaunchKernelGGL(softmax_rows_kernel, dim3(rows), dim3(256), 0, stream, s, ld, (bf16_t*)p_bf16, ldp, cols, scale);
+  PXA_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int pxa_vae_nchw_to_grid(const float* img, int C, float mul, const pxa_grid* y, hipStream_t stream) {
+  if (int rc = check_grid(y, "pxa_vae_nchw_to_grid")) return rc;
+  PXA_CHECK(img && C > 0 && C <= y->C, "pxa_vae_nchw_to_grid: bad channel count %d (grid has %d)", C, y->C);
+  hipLaunchKernelGGL(nchw_to_grid_kernel, dim3(grid_blocks((long)y->B * y->H * y->W)), dim3(256), 0, stream, img, C, mul, to_grid(y));
+  PXA_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int pxa_vae_grid_to_nchw(const pxa_grid* x, int C, float* img, hipStream_t stream) {
+  if (int rc = check_grid(x, "pxa_vae_grid_to_nchw")) return rc;
+  PXA_CHECK(img && C > 0 && C <= x->C, "pxa_vae_grid_to_nchw: bad channel count %d (grid has %d)", C, x->C);
+  hipLaunchKernelGGL(grid_to_nchw_kernel, dim3(grid_blocks((long)x->B * x->H * x->W)), dim3(256), 0, stream, to_grid(x), C, img);
+  PXA_LAUNCH_CHECK();
+  return 0;
+}

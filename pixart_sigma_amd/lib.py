@@ -13,7 +13,7 @@ OPERAND = os.environ.get("PXA_OPERAND_DTYPE", "bf16").lower()
 assert OPERAND in ("bf16", "f16"), f"PXA_OPERAND_DTYPE must be bf16 or f16, got {OPERAND!r}"
 OPERAND_DTYPE = torch.float16 if OPERAND == "f16" else torch.bfloat16
 LIB_PATH = os.environ.get("PXA_LIB_PATH") or os.path.join(_HERE, "libpixart_hip_f16.so" if OPERAND == "f16" else "libpixart_hip.so")   # env override: A/B kernel builds
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 c_void_p, c_int, c_long, c_float = C.c_void_p, C.c_int, C.c_long, C.c_float
 
@@ -24,7 +24,14 @@ class GemmArgs(C.Structure):
                 ("bias", c_void_p), ("act", c_int), ("aux", c_void_p), ("ldaux", c_int),
                 ("out_bf16", c_void_p), ("out2_bf16", c_void_p), ("ld_out", c_int),
                 ("out_f32", c_void_p), ("ld_f32", c_int), ("accumulate", c_int), ("split_k", c_int),
-                ("splitk_ws", c_void_p), ("splitk_ws_elems", c_long), ("colsum", c_void_p), ("colsum_stride", c_long)]
+                ("splitk_ws", c_void_p), ("splitk_ws_elems", c_long), ("colsum", c_void_p), ("colsum_stride", c_long),
+                ("k_seg", c_int), ("a_seg_stride", c_long)]
+
+
+class GridArg(C.Structure):
+    """pxa_grid: a bf16 NHWC pixel grid (include/pixart_hip.h, VAE conv stack)."""
+    _fields_ = [("ptr", c_void_p), ("B", c_int), ("H", c_int), ("W", c_int), ("C", c_int),
+                ("row_pitch", c_int), ("img_pitch", c_long), ("origin", c_long)]
 
 
 class AttnArgs(C.Structure):
@@ -43,6 +50,7 @@ class AttnArgs(C.Structure):
 
 # name -> argtypes (all return int); must list every symbol include/pixart_hip.h declares
 _P, _I, _L, _F = c_void_p, c_int, c_long, c_float
+_G = C.POINTER(GridArg)
 SIGNATURES = {
     "pxa_gemm": [C.POINTER(GemmArgs), _P],
     "pxa_ln_mod_fwd": [_P, _P, _P, _I, _P, _P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _F, _P],
@@ -66,6 +74,13 @@ SIGNATURES = {
     "pxa_clip_coef": [_P, _P, _F, _F, _P],
     "pxa_adamw_step": [_P, _P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _I, _P, _P],
     "pxa_cast_f32_bf16": [_P, _P, _L, _P],
+    "pxa_vae_gn_stats": [_G, _I, _F, _P, _P, _P, _P],
+    "pxa_vae_gn_apply": [_G, _P, _P, _P, _P, _I, _I, _I, _G, _P],
+    "pxa_vae_im2col3x3": [_G, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P],
+    "pxa_vae_add": [_G, _G, _G, _P],
+    "pxa_vae_softmax_rows": [_P, _L, _P, _L, _I, _I, _F, _P],
+    "pxa_vae_nchw_to_grid": [_P, _I, _F, _G, _P],
+    "pxa_vae_grid_to_nchw": [_G, _I, _P, _P],
 }
 OTHER_SYMBOLS = ["pxa_last_error", "pxa_abi_version", "pxa_operand_dtype", "pxa_device_info", "pxa_gemm_splitk_ws_elems"]
 

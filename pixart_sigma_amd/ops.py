@@ -6,7 +6,7 @@ import math
 import torch
 
 from . import lib
-from .lib import AttnArgs, GemmArgs, call, ptr
+from .lib import AttnArgs, GemmArgs, GridArg, call, ptr
 
 # BF16 = the process's 16-bit operand dtype: torch.bfloat16, or torch.float16 under PXA_OPERAND_DTYPE=f16 (historical name)
 from .lib import OPERAND_DTYPE as BF16  # noqa: E402
@@ -21,9 +21,10 @@ def _chk(t, dtype, name):
 
 
 def gemm(a, b, layout=NT, bias=None, act=ACT_NONE, aux=None, out=None, out2=None, out_f32=None, accumulate=False,
-         split_k=1, out_dtype=BF16, colsum=None):
+         split_k=1, out_dtype=BF16, colsum=None, k_seg=0, a_seg_stride=0):
     """C = op(A) op(B) (see include/pixart_hip.h).  a, b: 2-D bf16 (row stride arbitrary multiple of 8).
-    Returns the bf16 output (or fp32 when out_dtype is float32 / out_f32 is given)."""
+    Returns the bf16 output (or fp32 when out_dtype is float32 / out_f32 is given).
+    k_seg / a_seg_stride: segmented-K A operand (the implicit 3x3 convolution of the VAE kernel set)."""
     _chk(a, BF16, "A")
     _chk(b, BF16, "B")
     if layout == NT:
@@ -63,6 +64,7 @@ def gemm(a, b, layout=NT, bias=None, act=ACT_NONE, aux=None, out=None, out2=None
         assert out is not None and out2.stride(0) == out.stride(0)
         g.out2_bf16 = ptr(out2)
     g.accumulate, g.split_k = int(accumulate), split_k
+    g.k_seg, g.a_seg_stride = k_seg, a_seg_stride
     if colsum is not None:               # (PXA_COLSUM_SLOTS, stride) partial buffer view: row 0 of the slice to accumulate
         g.colsum, g.colsum_stride = ptr(colsum), colsum.stride(0)
     if accumulate and split_k != 1:       # split-K partial slabs: caller-owned workspace, cached per device (max 16 slabs)
@@ -236,3 +238,93 @@ def cast_bf16(x, out=None):
         out = torch.empty(x.shape, dtype=BF16, device=x.device)
     call("pxa_cast_f32_bf16", ptr(x), ptr(out), x.numel())
     return out
+
+
+# ------------------------------------------------------------------------------------------------ VAE conv stack
+class Grid:
+    """A bf16 NHWC pixel grid (pxa_grid): pixel (b, y, x) is the C-vector at buf[(b*img_pitch + y*row_pitch + x + origin) * C]."""
+
+    def __init__(self, buf, B, H, W, C, row_pitch=None, img_pitch=None, origin=0):
+        _chk(buf, BF16, "grid buffer")
+        self.buf, self.B, self.H, self.W, self.C = buf, B, H, W, C
+        self.row_pitch = W if row_pitch is None else row_pitch
+        self.img_pitch = H * W if img_pitch is None else img_pitch
+        self.origin = origin
+
+    @classmethod
+    def compact(cls, B, H, W, C, device):
+        return cls(torch.empty(B * H * W, C, dtype=BF16, device=device), B, H, W, C)
+
+    @property
+    def is_compact(self):
+        return self.origin == 0 and self.row_pitch == self.W and self.img_pitch == self.H * self.W
+
+    def rows(self):
+        """(pixels, C) matrix over every pixel slot of the grid (border slots of a padded-grid view included)."""
+        return self.buf.view(-1, self.C)[: self.B * self.img_pitch] if not self.is_compact else self.buf.view(-1, self.C)
+
+    def like_rows(self, out, C):
+        """The grid of a row-wise op's output: same pixel slots, C channels."""
+        return Grid(out, self.B, self.H, self.W, C, self.row_pitch, self.img_pitch, self.origin)
+
+    def arg(self):
+        g = GridArg()
+        g.ptr, g.B, g.H, g.W, g.C = ptr(self.buf), self.B, self.H, self.W, self.C
+        g.row_pitch, g.img_pitch, g.origin = self.row_pitch, self.img_pitch, self.origin
+        return g
+
+
+_GN_WS = {}
+
+
+def vae_gn_stats(x, groups, eps):
+    """GroupNorm statistics of a grid: (mean, rstd), each (B*groups,) fp32."""
+    dev = x.buf.device
+    ws = _GN_WS.get((dev, x.B * groups))
+    if ws is None:
+        ws = _GN_WS[(dev, x.B * groups)] = torch.empty(x.B * groups * 2, dtype=torch.float64, device=dev)
+    mean = torch.empty(x.B * groups, dtype=F32, device=dev)
+    rstd = torch.empty_like(mean)
+    call("pxa_vae_gn_stats", x.arg(), groups, eps, ptr(ws), ptr(mean), ptr(rstd))
+    return mean, rstd
+
+
+def vae_gn_apply(x, y, norm=None, silu=False, upsample=1):
+    """y = act(norm(x)) (optionally 2x nearest upsampled).  norm = (mean, rstd, gamma, beta, groups) or None."""
+    mean, rstd, gamma, beta, groups = norm if norm is not None else (None, None, None, None, 1)
+    call("pxa_vae_gn_apply", x.arg(), ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), groups, int(silu), upsample, y.arg())
+    return y
+
+
+def vae_im2col3x3(x, stride, pad, Ho, Wo, norm=None, silu=False):
+    mean, rstd, gamma, beta, groups = norm if norm is not None else (None, None, None, None, 1)
+    col = torch.empty(x.B * Ho * Wo, 9 * x.C, dtype=BF16, device=x.buf.device)
+    call("pxa_vae_im2col3x3", x.arg(), ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), groups, int(silu), stride, pad, Ho, Wo, ptr(col))
+    return col
+
+
+def vae_add(a, b, out):
+    call("pxa_vae_add", a.arg(), b.arg(), out.arg())
+    return out
+
+
+def vae_softmax_rows(s, scale, out=None):
+    _chk(s, F32, "scores")
+    rows, cols = s.shape
+    if out is None:
+        out = torch.empty(rows, cols, dtype=BF16, device=s.device)
+    call("pxa_vae_softmax_rows", ptr(s), s.stride(0), ptr(out), out.stride(0), rows, cols, scale)
+    return out
+
+
+def vae_nchw_to_grid(img, y, mul=1.0):
+    _chk(img, F32, "image")
+    assert img.is_contiguous() and img.shape[0] == y.B and img.shape[2] == y.H and img.shape[3] == y.W
+    call("pxa_vae_nchw_to_grid", ptr(img), img.shape[1], mul, y.arg())
+    return y
+
+
+def vae_grid_to_nchw(x, C):
+    img = torch.empty(x.B, C, x.H, x.W, dtype=F32, device=x.buf.device)
+    call("pxa_vae_grid_to_nchw", x.arg(), C, ptr(img))
+    return img

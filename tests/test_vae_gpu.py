@@ -1,0 +1,154 @@
+"""GPU parity of the VAE conv-stack kernel set (csrc/vae.hip + the segmented-K pxa_gemm) through the C ABI.
+Kernel level: against plain PyTorch fp32 references of the same op on the same bf16-rounded inputs (one bf16 rounding -> 4e-3).
+Model level: encode / decode of the product AutoencoderKL against oracle/vae_ref.py (fp32, CPU) with the same random weights.
+Tolerance, stated: every activation between layers is stored as bf16 (the reference runs this network in fp16 storage), so the
+end-to-end rel-L2 is bounded at 2e-2 for the ~30-layer decoder; parity is unpinned for this row (no reference vectors exist)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from conftest import rel_l2  # noqa: E402
+
+BF16_TOL = 4e-3
+MODEL_TOL = 2e-2
+
+
+@pytest.fixture(scope="module")
+def ops():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from pixart_sigma_amd import ops as o
+    return o
+
+
+def rnd(*shape, scale=1.0, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).cuda()
+
+
+def to_grid(ops, t):
+    """(B, C, H, W) fp32 -> compact grid holding the bf16-rounded NHWC copy; returns (grid, the rounded tensor as fp32 NCHW)."""
+    B, C, H, W = t.shape
+    nhwc = t.permute(0, 2, 3, 1).contiguous().to(ops.BF16)
+    return ops.Grid(nhwc.view(-1, C), B, H, W, C), nhwc.float().permute(0, 3, 1, 2).contiguous()
+
+
+def from_grid(g):
+    """grid -> (B, C, H, W) fp32 of the interior pixels, whatever the pitches."""
+    rows = g.buf.view(-1, g.C).float()
+    idx = (torch.arange(g.B, device=rows.device)[:, None, None] * g.img_pitch + torch.arange(g.H, device=rows.device)[None, :, None] * g.row_pitch
+           + torch.arange(g.W, device=rows.device)[None, None, :] + g.origin)
+    return rows[idx].permute(0, 3, 1, 2).contiguous()
+
+
+@pytest.mark.parametrize("B,C,H,W,groups", [(2, 128, 12, 20, 32), (1, 512, 8, 8, 32), (3, 64, 5, 7, 16), (1, 256, 40, 36, 32)])
+def test_groupnorm_stats_and_apply(ops, B, C, H, W, groups):
+    g, x = to_grid(ops, rnd(B, C, H, W, seed=1) * 2.0 + 0.7)
+    gamma, beta = rnd(C, seed=2) * 0.3 + 1.0, rnd(C, seed=3) * 0.2
+    mean, rstd = ops.vae_gn_stats(g, groups, 1e-6)
+    xg = x.view(B, groups, -1)
+    assert rel_l2(mean, xg.mean(-1).flatten()) < 2e-5
+    assert rel_l2(rstd, (xg.var(-1, unbiased=False) + 1e-6).rsqrt().flatten()) < 2e-5
+    ref = F.group_norm(x, groups, gamma, beta, eps=1e-6)
+    y = ops.vae_gn_apply(g, ops.Grid.compact(B, H, W, C, "cuda"), (mean, rstd, gamma, beta, groups))
+    assert rel_l2(from_grid(y), ref) < BF16_TOL
+    y = ops.vae_gn_apply(g, ops.Grid.compact(B, 2 * H, 2 * W, C, "cuda"), (mean, rstd, gamma, beta, groups), silu=True, upsample=2)
+    assert rel_l2(from_grid(y), F.interpolate(F.silu(ref), scale_factor=2.0, mode="nearest")) < BF16_TOL
+    y = ops.vae_gn_apply(g, ops.Grid.compact(B, 2 * H, 2 * W, C, "cuda"), None, upsample=2)                 # plain upsampling copy
+    assert torch.equal(from_grid(y), F.interpolate(x, scale_factor=2.0, mode="nearest"))
+
+
+@pytest.mark.parametrize("B,C,Co,H,W", [(2, 64, 128, 9, 13), (1, 128, 8, 20, 20), (2, 256, 256, 16, 8), (1, 512, 512, 8, 8)])
+def test_implicit_conv3x3_is_conv2d(ops, B, C, Co, H, W):
+    """The zero-bordered padded grid + segmented-K GEMM (k_seg = 3C, a_seg_stride = (W+2)C) == Conv2d(3, padding=1)."""
+    g, x = to_grid(ops, rnd(B, C, H, W, seed=1))
+    w = rnd(Co, C, 3, 3, scale=(9 * C) ** -0.5, seed=2).to(ops.BF16)
+    bias = rnd(Co, seed=3)
+    ref = F.conv2d(x, w.float(), bias, padding=1)
+    ip, rp = (H + 2) * (W + 2), W + 2
+    buf = torch.zeros((B * ip + 2 * (W + 3)) * C, dtype=ops.BF16, device="cuda")
+    ops.vae_gn_apply(g, ops.Grid(buf, B, H, W, C, rp, ip, origin=(W + 3) + rp + 1))
+    wk = w.permute(0, 2, 3, 1).reshape(Co, 9 * C).contiguous()
+    a = buf.as_strided((B * ip, 9 * C), (C, 1))
+    out = ops.gemm(a, wk, ops.NT, bias=bias, k_seg=3 * C, a_seg_stride=rp * C)
+    assert rel_l2(from_grid(ops.Grid(out, B, H, W, Co, rp, ip, origin=W + 3)), ref) < BF16_TOL
+    outf = ops.gemm(a, wk, ops.NT, bias=bias, out_dtype=torch.float32, k_seg=3 * C, a_seg_stride=rp * C)      # fp32 output flavour
+    assert rel_l2(outf.view(B, H + 2, W + 2, Co)[:, 1:-1, 1:-1].permute(0, 3, 1, 2), ref) < 2e-5
+
+
+@pytest.mark.parametrize("stride", [1, 2])
+def test_im2col_conv(ops, stride):
+    B, C, Co, H, W = 2, 8, 128, 10, 14
+    g, x = to_grid(ops, rnd(B, C, H, W, seed=1))
+    w = rnd(Co, C, 3, 3, scale=(9 * C) ** -0.5, seed=2).to(ops.BF16)
+    wk = w.permute(0, 2, 3, 1).reshape(Co, 9 * C).contiguous()
+    if stride == 1:
+        ref, Ho, Wo, pad = F.conv2d(x, w.float(), padding=1), H, W, 1
+    else:
+        ref, Ho, Wo, pad = F.conv2d(F.pad(x, (0, 1, 0, 1)), w.float(), stride=2), H // 2, W // 2, 0
+    col = ops.vae_im2col3x3(g, stride, pad, Ho, Wo)
+    out = ops.gemm(col, wk, ops.NT)
+    assert rel_l2(out.float().view(B, Ho, Wo, Co).permute(0, 3, 1, 2), ref) < BF16_TOL
+
+
+def test_im2col_with_norm_and_silu(ops):
+    B, C, H, W, groups = 1, 128, 6, 6, 32
+    g, x = to_grid(ops, rnd(B, C, H, W, seed=1))
+    gamma, beta = rnd(C, seed=2) * 0.3 + 1.0, rnd(C, seed=3) * 0.2
+    mean, rstd = ops.vae_gn_stats(g, groups, 1e-6)
+    act = F.silu(F.group_norm(x, groups, gamma, beta, eps=1e-6))
+    col = ops.vae_im2col3x3(g, 1, 1, H, W, (mean, rstd, gamma, beta, groups), silu=True)
+    ref = F.unfold(act, 3, padding=1).view(B, C, 9, H * W).permute(0, 3, 2, 1).reshape(B * H * W, 9 * C)
+    assert rel_l2(col.float(), ref) < BF16_TOL
+
+
+def test_softmax_rows_add_and_layout_conversion(ops):
+    s = rnd(300, 1024, scale=20.0, seed=1)
+    p = ops.vae_softmax_rows(s, 0.044)
+    assert rel_l2(p.float(), torch.softmax(s * 0.044, -1)) < BF16_TOL
+    s = rnd(64, 4100, scale=5.0, seed=2)[:, :4096]                       # strided rows
+    assert rel_l2(ops.vae_softmax_rows(s, 1.0).float(), torch.softmax(s, -1)) < BF16_TOL
+    img = rnd(2, 3, 6, 10, seed=3)
+    g = ops.vae_nchw_to_grid(img, ops.Grid.compact(2, 6, 10, 8, "cuda"), mul=0.5)
+    back = from_grid(g)
+    assert rel_l2(back[:, :3], img * 0.5) < BF16_TOL and back[:, 3:].abs().max() == 0
+    ga, a = to_grid(ops, rnd(2, 64, 6, 10, seed=4))
+    H, W = 6, 10
+    pad = torch.full(((2 * (H + 2) * (W + 2)) * 64,), 7.0, dtype=ops.BF16, device="cuda")                    # padded-grid view with a garbage border
+    gb = ops.vae_gn_apply(ga, ops.Grid(pad, 2, H, W, 64, W + 2, (H + 2) * (W + 2), origin=W + 3))
+    out = ops.vae_add(ga, gb, ops.Grid.compact(2, H, W, 64, "cuda"))
+    assert rel_l2(from_grid(out), 2 * a) < BF16_TOL
+    assert (pad.view(2, H + 2, W + 2, 64)[:, 0] == 7.0).all()            # interior-only writes
+
+
+def _pair(cfg, seed):
+    from oracle.vae_ref import AutoencoderKLRef, randomize_
+    from pixart_sigma_amd.vae import AutoencoderKL
+    ref = randomize_(AutoencoderKLRef(**cfg), seed=seed)
+    vae = AutoencoderKL(**cfg)
+    vae.load_state_dict(ref.state_dict())
+    return ref, vae.cuda()
+
+
+@pytest.mark.parametrize("cfg,B,H,W", [(dict(block_out_channels=(128, 256), layers_per_block=1), 2, 16, 24),
+                                      (dict(block_out_channels=(128, 256, 512, 512), layers_per_block=2), 1, 64, 64)])
+def test_autoencoder_decode_and_encode_match_oracle(ops, cfg, B, H, W):
+    ref, vae = _pair(cfg, seed=5)
+    f = 1 << (len(cfg["block_out_channels"]) - 1)
+    z = rnd(B, 4, H // f, W // f, seed=6).cpu()
+    with torch.no_grad():
+        want = ref.decode(z)
+    got = vae.decode(z.cuda()).sample
+    assert got.shape == want.shape and got.dtype == torch.float32
+    assert rel_l2(got.cpu(), want) < MODEL_TOL
+    x = rnd(B, 3, H, W, seed=7).cpu()
+    with torch.no_grad():
+        mean, logvar = ref.encode_moments(x)
+    dist = vae.encode(x.cuda()).latent_dist
+    assert rel_l2(dist.mean.cpu(), mean) < MODEL_TOL and rel_l2(dist.logvar.cpu(), logvar) < MODEL_TOL
+    g = torch.Generator(device="cuda").manual_seed(0)
+    assert dist.sample(generator=g).shape == mean.shape
+    half = vae.decode(z.cuda().half()).sample                            # the reference calls it with fp16 latents (inference.py:136)
+    assert half.dtype == torch.float16 and rel_l2(half.float().cpu(), want) < MODEL_TOL
