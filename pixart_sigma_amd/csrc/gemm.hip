@@ -649,7 +649,8 @@ __device__ unsigned g_sched_word[64][512];             // paired-tile instances 
 //           64 x 64 (one row tile per phase: 8 MFMAs per k-unit and wave instead of 16).  Pairing would not help here: 256 CUs run
 //           whole rounds of equal items, 4.5 rounds of work still take 5; a round of half-duration items under the dynamic
 //           cursors makes it ~4.6.
-template <int LAYOUT, int EPI, int RM>
+// SEG: segmented-K A operand (see gemm_glds_kernel): the running A pointers take an extra p.seg_jump every p.k_seg elements.
+template <int LAYOUT, int EPI, int RM, bool SEG = false>
 __global__ __launch_bounds__(512) void gemm_pers_kernel(GemmParams p) {
   constexpr bool A_KC = (LAYOUT != 2), B_KC = (LAYOUT == 0);
   constexpr int NW = 8, TM = 4, TN = 2, BKT = 32, H1 = 2;
@@ -748,9 +749,14 @@ __global__ __launch_bounds__(512) void gemm_pers_kernel(GemmParams p) {
                                      (__attribute__((address_space(3))) void*)(smem + slot * UNIT + dof[i]), 16, 0, 0);
     pp[i] += st[i];
   };
+  int seg_left = 0;                                    // SEG: k elements left in the A segment the next first-half issue reads
   auto issue_lo = [&]() {
 #pragma unroll
     for (int i = 0; i < H1; i++) piece(i, s_lo);
+    if (SEG) {                                         // pieces 0 and 1 are the A pieces of every SEG instantiation (no pairing)
+      seg_left -= BKT;
+      if (seg_left == 0) { pp[0] += p.seg_jump; pp[1] += p.seg_jump; seg_left = p.k_seg; }
+    }
     s_lo = (s_lo + 1) & 3;
   };
   auto issue_hi = [&]() {
@@ -777,6 +783,7 @@ __global__ __launch_bounds__(512) void gemm_pers_kernel(GemmParams p) {
       dof[i] = (is_a ? 0 : (vq ? 32768 : 16384)) + pid * 1024;
     }
     s_lo = s_hi = 0;
+    if (SEG) seg_left = p.k_seg;
     issue_lo(); issue_hi(); issue_lo(); issue_hi();
     if (nk_pf > 2) issue_lo();
   };
@@ -1024,14 +1031,15 @@ static inline int pers_tiles(int M, int N, int rm) {
   const bool pairing = rm == 1 && pers_pairing(M, N);
   return mt * (pairing ? ntf : (N + 255) / 256) + (pairing ? mt / 2 : 0);
 }
-template <int LAYOUT, int EPI, int RM = 0>
+template <int LAYOUT, int EPI, int RM = 0, bool SEG = false>
 int launch_pers(GemmParams p, int split, hipStream_t s) {
+  static_assert(!SEG || (LAYOUT == 0 && RM != 1), "segmented A: layout NT without pairing");
   p.split = split;
   constexpr int LDSP = 4 * 40960;                      // the ring (4 x 40 KiB slots) = the CU's whole 160 KiB: one workgroup per CU
   static bool attr_set_pp = false;
   static int n_cu = 0;
   if (!attr_set_pp) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_pers_kernel<LAYOUT, EPI, RM>), hipFuncAttributeMaxDynamicSharedMemorySize, LDSP);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_pers_kernel<LAYOUT, EPI, RM, SEG>), hipFuncAttributeMaxDynamicSharedMemorySize, LDSP);
     if (e != hipSuccess) { pxa_set_error("hipFuncSetAttribute(gemm_pers<%d,%d>): %s", LAYOUT, EPI, hipGetErrorString(e)); return -3; }
     int dev = 0;
     hipDeviceProp_t prop;
@@ -1042,7 +1050,7 @@ int launch_pers(GemmParams p, int split, hipStream_t s) {
   const int tiles = pers_tiles(p.M, p.N, RM) * split;
   static const bool force_static = getenv("PXA_GEMM_STATIC") != nullptr;   // A/B experiments (tools/contention_test.py)
   p.sched_slot = force_static ? -1 : (int)(g_launch_seq.fetch_add(1u) & 63u);
-  hipLaunchKernelGGL((gemm_pers_kernel<LAYOUT, EPI, RM>), dim3(tiles < n_cu ? tiles : n_cu), dim3(512), LDSP, s, p);
+  hipLaunchKernelGGL((gemm_pers_kernel<LAYOUT, EPI, RM, SEG>), dim3(tiles < n_cu ? tiles : n_cu), dim3(512), LDSP, s, p);
   PXA_LAUNCH_CHECK();
   return 0;
 }
@@ -1107,6 +1115,9 @@ int launch(GemmParams p, int split, hipStream_t s) {
   const bool fast = (p.K % BK == 0) && (p.k_per_split % BK == 0) && !getenv("PXA_GEMM_NO_GLDS");
   if (p.k_seg) {                                          // implicit 3x3 convolution (checked by pxa_gemm: NT, K and k_seg multiples of 64)
     if constexpr (LAYOUT == 0) {
+      static const bool no_pers_seg = getenv("PXA_GEMM_NO_PERSISTENT") != nullptr;
+      if (p.out && !p.outf && p.act == 0 && p.M >= 1024 && p.N >= 128 && p.N % 128 == 0 && p.k_seg % 32 == 0 && !no_pers_seg)
+        return pers_halfcol(p.N) ? launch_pers<0, 0, 2, true>(p, 1, s) : launch_pers<0, 0, 0, true>(p, 1, s);
       if (p.out && !p.outf && p.act == 0) return launch_glds_e<0, 128, 128, 2, 2, 1, true>(p, 1, s);
       return launch_glds_e<0, 128, 128, 2, 2, 0, true>(p, 1, s);
     }

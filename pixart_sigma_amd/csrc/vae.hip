@@ -38,13 +38,14 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(Grid x, int cpg, double* 
   for (int i = threadIdx.x; i < 2 * G; i += 256) red[i] = 0.f;
   __syncthreads();
   float s0 = 0.f, q0 = 0.f, s1 = 0.f, q1 = 0.f;
-  const long HW = (long)x.H * x.W;
-  for (long p = (long)blockIdx.x * PPB + pl; p < HW; p += (long)gridDim.x * PPB) {
-    const int y = p / x.W, xx = p - (long)y * x.W;
-    float f[8];
-    unpack_bf16x8(*reinterpret_cast<const uint4*>(x.at(b, y, xx) + cv * 8), f);
-    s0 += (f[0] + f[1]) + (f[2] + f[3]); q0 += (f[0] * f[0] + f[1] * f[1]) + (f[2] * f[2] + f[3] * f[3]);
-    s1 += (f[4] + f[5]) + (f[6] + f[7]); q1 += (f[4] * f[4] + f[5] * f[5]) + (f[6] * f[6] + f[7] * f[7]);
+  for (int y = blockIdx.x; y < x.H; y += gridDim.x) {   // a block walks whole image rows: no index divisions in the loop
+    const bf16_t* row = x.at(b, y, 0) + cv * 8;
+    for (int xx = pl; xx < x.W; xx += PPB) {
+      float f[8];
+      unpack_bf16x8(*reinterpret_cast<const uint4*>(row + (long)xx * x.C), f);
+      s0 += (f[0] + f[1]) + (f[2] + f[3]); q0 += (f[0] * f[0] + f[1] * f[1]) + (f[2] * f[2] + f[3] * f[3]);
+      s1 += (f[4] + f[5]) + (f[6] + f[7]); q1 += (f[4] * f[4] + f[5] * f[5]) + (f[6] * f[6] + f[7] * f[7]);
+    }
   }
   const int g0 = (cv * 8) / cpg, g1 = (cv * 8 + 4) / cpg;
   atomicAdd(&red[2 * g0], s0); atomicAdd(&red[2 * g0 + 1], q0);
@@ -63,11 +64,12 @@ __global__ void gn_finalize_kernel(const double* __restrict__ ws, float* __restr
 // the value a consumer sees: optional GroupNorm (affine), optional SiLU
 struct Norm {
   const float* mean; const float* rstd; const float* gamma; const float* beta; int cpg, G, silu;
+  int cpg_shift;                                       // log2(cpg) when it is a power of two (every SD / SDXL VAE layer), else -1
   __device__ __forceinline__ void apply(float (&f)[8], int b, int c0) const {
     if (mean) {
 #pragma unroll
       for (int h = 0; h < 2; h++) {
-        const int g = (c0 + 4 * h) / cpg;
+        const int g = cpg_shift >= 0 ? (c0 + 4 * h) >> cpg_shift : (c0 + 4 * h) / cpg;
         const float m = mean[b * G + g], r = rstd[b * G + g];
         const float4 ga = *reinterpret_cast<const float4*>(gamma + c0 + 4 * h), be = *reinterpret_cast<const float4*>(beta + c0 + 4 * h);
         f[4 * h] = (f[4 * h] - m) * r * ga.x + be.x; f[4 * h + 1] = (f[4 * h + 1] - m) * r * ga.y + be.y;
@@ -79,62 +81,46 @@ struct Norm {
       for (int e = 0; e < 8; e++) f[e] = pxa_silu(f[e]);
     }
   }
-  static __device__ __forceinline__ float pxa_silu(float v) { return v / (1.f + __expf(-v)); }
+  static __device__ __forceinline__ float pxa_silu(float v) { return v * __builtin_amdgcn_rcpf(1.f + __expf(-v)); }   // rcp: 1 ulp
 };
 
 // ---- y[b, yo, xo] = act(norm(x[b, yo / up, xo / up])): writes the interior of y (the zero border of a padded grid is the caller's)
 __global__ __launch_bounds__(256) void gn_apply_kernel(Grid x, Norm nm, int up, Grid y) {
-  const int CV = x.C / 8;
-  const long total = (long)y.B * y.H * y.W * CV;
-  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += gridDim.x * 256L) {
-    const int cv = i % CV;
-    long p = i / CV;
-    const int xo = p % y.W; p /= y.W;
-    const int yo = p % y.H, b = p / y.H;
-    float f[8];
-    unpack_bf16x8(*reinterpret_cast<const uint4*>(x.at(b, yo / up, xo / up) + cv * 8), f);
-    nm.apply(f, b, cv * 8);
-    *reinterpret_cast<uint4*>(y.at(b, yo, xo) + cv * 8) = pack8(f);
-  }
+  const int CV = x.C / 8, i = blockIdx.x * 256 + threadIdx.x;   // grid: (chunks of one output row, output row, sample)
+  if (i >= y.W * CV) return;
+  const int xo = i / CV, cv = i - xo * CV, yo = blockIdx.y, b = blockIdx.z;
+  float f[8];
+  unpack_bf16x8(*reinterpret_cast<const uint4*>(x.at(b, yo >> (up - 1), xo >> (up - 1)) + cv * 8), f);
+  nm.apply(f, b, cv * 8);
+  *reinterpret_cast<uint4*>(y.at(b, yo, xo) + cv * 8) = pack8(f);
 }
 
 // ---- explicit patch matrix: col[(b, yo, xo)][tap * C + c] = act(norm(x[b, yo*stride + ky - pad, xo*stride + kx - pad])) or 0 outside
 __global__ __launch_bounds__(256) void im2col3x3_kernel(Grid x, Norm nm, int stride, int pad, int Ho, int Wo, bf16_t* __restrict__ col) {
-  const int CV = x.C / 8;
-  const long total = (long)x.B * Ho * Wo * 9 * CV;
-  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += gridDim.x * 256L) {
-    const int cv = i % CV;
-    long p = i / CV;
-    const int tap = p % 9; p /= 9;
-    const int xo = p % Wo; p /= Wo;
-    const int yo = p % Ho, b = p / Ho;
-    const int yi = yo * stride + tap / 3 - pad, xi = xo * stride + tap % 3 - pad;
-    uint4 v = make_uint4(0u, 0u, 0u, 0u);
-    if (yi >= 0 && yi < x.H && xi >= 0 && xi < x.W) {
-      float f[8];
-      unpack_bf16x8(*reinterpret_cast<const uint4*>(x.at(b, yi, xi) + cv * 8), f);
-      nm.apply(f, b, cv * 8);
-      v = pack8(f);
-    }
-    *reinterpret_cast<uint4*>(col + i * 8) = v;          // i enumerates the 16-byte chunks of col in memory order
+  const int CV = x.C / 8, i = blockIdx.x * 256 + threadIdx.x;   // grid: (chunks of one output row's patches, output row, sample)
+  if (i >= Wo * 9 * CV) return;
+  const int t = i / CV, cv = i - t * CV, xo = t / 9, tap = t - xo * 9, yo = blockIdx.y, b = blockIdx.z;
+  const int yi = yo * stride + tap / 3 - pad, xi = xo * stride + tap % 3 - pad;
+  uint4 v = make_uint4(0u, 0u, 0u, 0u);
+  if (yi >= 0 && yi < x.H && xi >= 0 && xi < x.W) {
+    float f[8];
+    unpack_bf16x8(*reinterpret_cast<const uint4*>(x.at(b, yi, xi) + cv * 8), f);
+    nm.apply(f, b, cv * 8);
+    v = pack8(f);
   }
+  // i enumerates the 16-byte chunks of this output row's patches in memory order
+  *reinterpret_cast<uint4*>(col + (((long)b * Ho + yo) * Wo * 9 * CV + i) * 8) = v;
 }
 
 __global__ __launch_bounds__(256) void add_kernel(Grid a, Grid bb, Grid o) {
-  const int CV = a.C / 8;
-  const long total = (long)a.B * a.H * a.W * CV;
-  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += gridDim.x * 256L) {
-    const int cv = i % CV;
-    long p = i / CV;
-    const int xx = p % a.W; p /= a.W;
-    const int y = p % a.H, b = p / a.H;
-    float f[8], g[8];
-    unpack_bf16x8(*reinterpret_cast<const uint4*>(a.at(b, y, xx) + cv * 8), f);
-    unpack_bf16x8(*reinterpret_cast<const uint4*>(bb.at(b, y, xx) + cv * 8), g);
+  const int i = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y, b = blockIdx.z;   // grid: (chunks of one row, row, sample)
+  if (i >= a.W * (a.C / 8)) return;
+  float f[8], g[8];
+  unpack_bf16x8(*reinterpret_cast<const uint4*>(a.at(b, y, 0) + i * 8), f);
+  unpack_bf16x8(*reinterpret_cast<const uint4*>(bb.at(b, y, 0) + i * 8), g);
 #pragma unroll
-    for (int e = 0; e < 8; e++) f[e] += g[e];
-    *reinterpret_cast<uint4*>(o.at(b, y, xx) + cv * 8) = pack8(f);
-  }
+  for (int e = 0; e < 8; e++) f[e] += g[e];
+  *reinterpret_cast<uint4*>(o.at(b, y, 0) + i * 8) = pack8(f);
 }
 
 // ---- P = softmax(scale * S) per row, S fp32 (the single 512-wide head of the mid-block attention: the scores stay fp32 until here)
@@ -173,38 +159,31 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restri
 
 // ---- fp32 NCHW image / latent <-> bf16 grid (channels padded with zeros up to the grid's C)
 __global__ __launch_bounds__(256) void nchw_to_grid_kernel(const float* __restrict__ img, int C, float mul, Grid y) {
-  const long total = (long)y.B * y.H * y.W, HW = (long)y.H * y.W;
-  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += gridDim.x * 256L) {
-    const int b = i / HW;
-    const long p = i - b * HW;
-    const int yy = p / y.W, xx = p - (long)yy * y.W;
-    bf16_t* dst = y.at(b, yy, xx);
-    for (int c0 = 0; c0 < y.C; c0 += 8) {
-      float f[8];
+  const int xx = blockIdx.x * 256 + threadIdx.x, yy = blockIdx.y, b = blockIdx.z;
+  if (xx >= y.W) return;
+  const long HW = (long)y.H * y.W, p = (long)yy * y.W + xx;
+  bf16_t* dst = y.at(b, yy, xx);
+  for (int c0 = 0; c0 < y.C; c0 += 8) {
+    float f[8];
 #pragma unroll
-      for (int e = 0; e < 8; e++) f[e] = (c0 + e < C) ? img[((long)b * C + c0 + e) * HW + p] * mul : 0.f;
-      *reinterpret_cast<uint4*>(dst + c0) = pack8(f);
-    }
+    for (int e = 0; e < 8; e++) f[e] = (c0 + e < C) ? img[((long)b * C + c0 + e) * HW + p] * mul : 0.f;
+    *reinterpret_cast<uint4*>(dst + c0) = pack8(f);
   }
 }
 __global__ __launch_bounds__(256) void grid_to_nchw_kernel(Grid x, int C, float* __restrict__ img) {
-  const long total = (long)x.B * x.H * x.W, HW = (long)x.H * x.W;
-  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += gridDim.x * 256L) {
-    const int b = i / HW;
-    const long p = i - b * HW;
-    const int yy = p / x.W, xx = p - (long)yy * x.W;
-    const bf16_t* src = x.at(b, yy, xx);
-    for (int c0 = 0; c0 < C; c0 += 8) {
-      float f[8];
-      unpack_bf16x8(*reinterpret_cast<const uint4*>(src + c0), f);
+  const int xx = blockIdx.x * 256 + threadIdx.x, yy = blockIdx.y, b = blockIdx.z;
+  if (xx >= x.W) return;
+  const long HW = (long)x.H * x.W, p = (long)yy * x.W + xx;
+  const bf16_t* src = x.at(b, yy, xx);
+  for (int c0 = 0; c0 < C; c0 += 8) {
+    float f[8];
+    unpack_bf16x8(*reinterpret_cast<const uint4*>(src + c0), f);
 #pragma unroll
-      for (int e = 0; e < 8; e++)
-        if (c0 + e < C) img[((long)b * C + c0 + e) * HW + p] = f[e];
-    }
+    for (int e = 0; e < 8; e++)
+      if (c0 + e < C) img[((long)b * C + c0 + e) * HW + p] = f[e];
   }
 }
 
-static inline int grid_blocks(long items) { const long b = (items + 255) / 256; return (int)(b < 1 ? 1 : (b > 65536 ? 65536 : b)); }
 static int check_grid(const pxa_grid* g, const char* what) {
   PXA_CHECK(g && g->ptr, "%s: null grid", what);
   PXA_CHECK(g->B > 0 && g->H > 0 && g->W > 0 && g->C > 0 && g->C % 8 == 0, "%s: bad grid %d x %d x %d x %d (C must be a multiple of 8)", what, g->B, g->H, g->W, g->C);
@@ -212,11 +191,12 @@ static int check_grid(const pxa_grid* g, const char* what) {
   return 0;
 }
 static int make_norm(Norm& nm, const float* mean, const float* rstd, const float* gamma, const float* beta, int C, int groups, int silu, const char* what) {
-  nm = Norm{mean, rstd, gamma, beta, 1, 1, silu};
+  nm = Norm{mean, rstd, gamma, beta, 1, 1, silu, 0};
   if (mean) {
     PXA_CHECK(rstd && gamma && beta, "%s: GroupNorm needs mean, rstd, gamma and beta", what);
     PXA_CHECK(groups > 0 && C % groups == 0 && (C / groups) % 4 == 0, "%s: C=%d / groups=%d must be a multiple of 4", what, C, groups);
     nm.cpg = C / groups; nm.G = groups;
+    nm.cpg_shift = (nm.cpg & (nm.cpg - 1)) == 0 ? __builtin_ctz(nm.cpg) : -1;
   }
   return 0;
 }
@@ -230,9 +210,10 @@ extern "C" int pxa_vae_gn_stats(const pxa_grid* x, int groups, float eps, double
   PXA_CHECK(CV <= 256 && 256 % CV == 0, "pxa_vae_gn_stats: C=%d must be 8 * a power of two <= 2048", C);
   hipError_t e = hipMemsetAsync(ws, 0, sizeof(double) * 2 * groups * x->B, stream);
   PXA_CHECK(e == hipSuccess, "pxa_vae_gn_stats: memset failed: %s", hipGetErrorString(e));
-  const long HW = (long)x->H * x->W, ppb = 256 / CV;
-  long nb = (HW + ppb * 8 - 1) / (ppb * 8);            // ~8 pixels per thread
-  nb = nb < 1 ? 1 : (nb > 1024 ? 1024 : nb);
+  const long HW = (long)x->H * x->W;
+  const int ppb = 256 / CV, per_row = (x->W + ppb - 1) / ppb;      // loads per thread and image row
+  int nb = per_row >= 8 ? x->H : (x->H * per_row + 7) / 8;         // ~8 loads per thread, at most one block per row
+  nb = nb < 1 ? 1 : (nb > x->H ? x->H : nb);
   hipLaunchKernelGGL(gn_stats_kernel, dim3((unsigned)nb, x->B), dim3(256), 0, stream, to_grid(x), C / groups, ws);
   PXA_LAUNCH_CHECK();
   const int n = groups * x->B;
@@ -249,7 +230,8 @@ extern "C" int pxa_vae_gn_apply(const pxa_grid* x, const float* mean, const floa
   PXA_CHECK(y->B == x->B && y->C == x->C && y->H == x->H * upsample && y->W == x->W * upsample, "pxa_vae_gn_apply: output grid does not match");
   Norm nm;
   if (int rc = make_norm(nm, mean, rstd, gamma, beta, x->C, groups, silu, "pxa_vae_gn_apply")) return rc;
-  hipLaunchKernelGGL(gn_apply_kernel, dim3(grid_blocks((long)y->B * y->H * y->W * (y->C / 8))), dim3(256), 0, stream, to_grid(x), nm, upsample, to_grid(y));
+  PXA_CHECK(y->H <= 65535 && y->B <= 65535, "pxa_vae_gn_apply: grid too large");
+  hipLaunchKernelGGL(gn_apply_kernel, dim3((y->W * (y->C / 8) + 255) / 256, y->H, y->B), dim3(256), 0, stream, to_grid(x), nm, upsample, to_grid(y));
   PXA_LAUNCH_CHECK();
   return 0;
 }
@@ -260,7 +242,8 @@ extern "C" int pxa_vae_im2col3x3(const pxa_grid* x, const float* mean, const flo
   PXA_CHECK(col_bf16 && (stride == 1 || stride == 2) && (pad == 0 || pad == 1) && Ho > 0 && Wo > 0, "pxa_vae_im2col3x3: bad arguments");
   Norm nm;
   if (int rc = make_norm(nm, mean, rstd, gamma, beta, x->C, groups, silu, "pxa_vae_im2col3x3")) return rc;
-  hipLaunchKernelGGL(im2col3x3_kernel, dim3(grid_blocks((long)x->B * Ho * Wo * 9 * (x->C / 8))), dim3(256), 0, stream, to_grid(x), nm, stride, pad, Ho, Wo,
+  PXA_CHECK(Ho <= 65535 && x->B <= 65535, "pxa_vae_im2col3x3: grid too large");
+  hipLaunchKernelGGL(im2col3x3_kernel, dim3((Wo * 9 * (x->C / 8) + 255) / 256, Ho, x->B), dim3(256), 0, stream, to_grid(x), nm, stride, pad, Ho, Wo,
                      (bf16_t*)col_bf16);
   PXA_LAUNCH_CHECK();
   return 0;
@@ -272,7 +255,8 @@ extern "C" int pxa_vae_add(const pxa_grid* a, const pxa_grid* b, const pxa_grid*
   if (int rc = check_grid(out, "pxa_vae_add(out)")) return rc;
   PXA_CHECK(a->B == b->B && a->H == b->H && a->W == b->W && a->C == b->C && a->B == out->B && a->H == out->H && a->W == out->W && a->C == out->C,
             "pxa_vae_add: grids differ");
-  hipLaunchKernelGGL(add_kernel, dim3(grid_blocks((long)a->B * a->H * a->W * (a->C / 8))), dim3(256), 0, stream, to_grid(a), to_grid(b), to_grid(out));
+  PXA_CHECK(a->H <= 65535 && a->B <= 65535, "pxa_vae_add: grid too large");
+  hipLaunchKernelGGL(add_kernel, dim3((a->W * (a->C / 8) + 255) / 256, a->H, a->B), dim3(256), 0, stream, to_grid(a), to_grid(b), to_grid(out));
   PXA_LAUNCH_CHECK();
   return 0;
 }
@@ -288,7 +272,8 @@ extern "C" int pxa_vae_softmax_rows(const float* s, long ld, void* p_bf16, long 
 extern "C" int pxa_vae_nchw_to_grid(const float* img, int C, float mul, const pxa_grid* y, hipStream_t stream) {
   if (int rc = check_grid(y, "pxa_vae_nchw_to_grid")) return rc;
   PXA_CHECK(img && C > 0 && C <= y->C, "pxa_vae_nchw_to_grid: bad channel count %d (grid has %d)", C, y->C);
-  hipLaunchKernelGGL(nchw_to_grid_kernel, dim3(grid_blocks((long)y->B * y->H * y->W)), dim3(256), 0, stream, img, C, mul, to_grid(y));
+  PXA_CHECK(y->H <= 65535 && y->B <= 65535, "pxa_vae_nchw_to_grid: grid too large");
+  hipLaunchKernelGGL(nchw_to_grid_kernel, dim3((y->W + 255) / 256, y->H, y->B), dim3(256), 0, stream, img, C, mul, to_grid(y));
   PXA_LAUNCH_CHECK();
   return 0;
 }
@@ -296,7 +281,8 @@ extern "C" int pxa_vae_nchw_to_grid(const float* img, int C, float mul, const px
 extern "C" int pxa_vae_grid_to_nchw(const pxa_grid* x, int C, float* img, hipStream_t stream) {
   if (int rc = check_grid(x, "pxa_vae_grid_to_nchw")) return rc;
   PXA_CHECK(img && C > 0 && C <= x->C, "pxa_vae_grid_to_nchw: bad channel count %d (grid has %d)", C, x->C);
-  hipLaunchKernelGGL(grid_to_nchw_kernel, dim3(grid_blocks((long)x->B * x->H * x->W)), dim3(256), 0, stream, to_grid(x), C, img);
+  PXA_CHECK(x->H <= 65535 && x->B <= 65535, "pxa_vae_grid_to_nchw: grid too large");
+  hipLaunchKernelGGL(grid_to_nchw_kernel, dim3((x->W + 255) / 256, x->H, x->B), dim3(256), 0, stream, to_grid(x), C, img);
   PXA_LAUNCH_CHECK();
   return 0;
 }

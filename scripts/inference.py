@@ -2,8 +2,9 @@
 """Text-to-image sampling entry point with the reference's CLI (reference scripts/inference.py:24-44), on the MI355X
 denoiser.  The frozen side nets are outside this repo's scope: captions are read as
 precomputed T5 features (tools/extract_features.py format: .npz with `caption_feature` (1,L,4096) and `attention_mask`
-(1,L)), or encoded with transformers' T5 when `--pipeline_load_from` holds the weights; latents are decoded with diffusers'
-AutoencoderKL when it is installed, else saved as `.pt`.
+(1,L)), or encoded with transformers' T5 when `--pipeline_load_from` holds the weights; latents are decoded by the HIP VAE
+(pixart_sigma_amd.vae.AutoencoderKL, reference inference.py:136,191-196) when the diffusers-format `vae/` directory exists, else
+saved as latents (`--random_vae` decodes with a random-init VAE: plumbing / timing runs without weights).
 
 Fixes relative to the reference script: `--kv_compress*` reaches the model constructor, and
 batch size 1 no longer indexes an empty prompt list.
@@ -27,6 +28,7 @@ def get_args():
     p.add_argument("--caption_feats", default=None, type=str, help="dir of <idx>.npz T5 features (one per prompt line)")
     p.add_argument("--model_path", default=None, type=str, help=".pth checkpoint in the reference's format (random init if omitted)")
     p.add_argument("--sdvae", action="store_true")
+    p.add_argument("--random_vae", action="store_true")
     p.add_argument("--bs", default=1, type=int)
     p.add_argument("--cfg_scale", default=4.5, type=float)
     p.add_argument("--sampling_algo", default="dpm-solver", type=str, choices=["dpm-solver"])
@@ -74,6 +76,13 @@ def main():
         sd = torch.load(args.model_path, map_location="cpu")
         model.load_state_dict(sd.get("state_dict", sd), strict=False)
     model = model.to(dev).eval()
+    from pixart_sigma_amd.vae import AutoencoderKL
+    vae_dir = "output/pretrained_models/sd-vae-ft-ema" if args.sdvae else f"{args.pipeline_load_from}/vae"    # reference inference.py:191-196
+    vae = None
+    if os.path.isdir(vae_dir):
+        vae = AutoencoderKL.from_pretrained(vae_dir).to(dev).to(torch.float16)
+    elif args.random_vae:
+        vae = AutoencoderKL(scaling_factor=0.18215 if args.sdvae else 0.13025).to(dev).to(torch.float16)
     prompts = [ln.strip() for ln in open(args.txt_file)] if os.path.exists(args.txt_file) else [f"prompt {i}" for i in range(args.bs)]
     os.makedirs(os.path.join("output", args.save_name), exist_ok=True)
     for start in range(0, len(prompts), args.bs):
@@ -86,12 +95,10 @@ def main():
         dpms = DPMS(model.forward_with_dpmsolver, condition=y, uncondition=null_y.repeat(n, 1, 1, 1), cfg_scale=args.cfg_scale,
                     model_kwargs=dict(data_info={"img_hw": hw, "aspect_ratio": ar}, mask=mask))
         samples = dpms.sample(z, steps=steps, order=2, skip_type="time_uniform", method="multistep")
-        try:
-            from diffusers.models import AutoencoderKL
-            vae = AutoencoderKL.from_pretrained(f"{args.pipeline_load_from}/vae").to(dev).to(torch.float16)
+        if vae is not None:
             imgs = vae.decode(samples.half() / vae.config.scaling_factor).sample
             torch.save(imgs.cpu(), os.path.join("output", args.save_name, f"images_{start}.pt"))
-        except ImportError:
+        else:
             torch.save(samples.cpu(), os.path.join("output", args.save_name, f"latents_{start}.pt"))
         print(f"[{start}:{start + n}] sampled {tuple(samples.shape)} in {steps} steps")
 

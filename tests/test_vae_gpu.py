@@ -60,9 +60,12 @@ def test_groupnorm_stats_and_apply(ops, B, C, H, W, groups):
     assert torch.equal(from_grid(y), F.interpolate(x, scale_factor=2.0, mode="nearest"))
 
 
-@pytest.mark.parametrize("B,C,Co,H,W", [(2, 64, 128, 9, 13), (1, 128, 8, 20, 20), (2, 256, 256, 16, 8), (1, 512, 512, 8, 8)])
+@pytest.mark.parametrize("B,C,Co,H,W", [(2, 64, 128, 9, 13), (1, 128, 8, 20, 20), (2, 256, 256, 16, 8), (1, 512, 512, 8, 8),
+                                         (2, 128, 128, 30, 30), (1, 256, 512, 40, 24), (2, 512, 256, 24, 24), (3, 64, 384, 20, 31)])
 def test_implicit_conv3x3_is_conv2d(ops, B, C, Co, H, W):
-    """The zero-bordered padded grid + segmented-K GEMM (k_seg = 3C, a_seg_stride = (W+2)C) == Conv2d(3, padding=1)."""
+    """The zero-bordered padded grid + segmented-K GEMM (k_seg = 3C, a_seg_stride = (W+2)C) == Conv2d(3, padding=1).
+    Fewer than 1024 padded pixels: the 128x128 two-stage kernel; more (and Cout a multiple of 128): the persistent 256x256 kernel
+    (Cout 128: half-width items only; 384: full + half; 256 / 512: full)."""
     g, x = to_grid(ops, rnd(B, C, H, W, seed=1))
     w = rnd(Co, C, 3, 3, scale=(9 * C) ** -0.5, seed=2).to(ops.BF16)
     bias = rnd(Co, seed=3)
@@ -114,6 +117,7 @@ def test_softmax_rows_add_and_layout_conversion(ops):
     g = ops.vae_nchw_to_grid(img, ops.Grid.compact(2, 6, 10, 8, "cuda"), mul=0.5)
     back = from_grid(g)
     assert rel_l2(back[:, :3], img * 0.5) < BF16_TOL and back[:, 3:].abs().max() == 0
+    assert torch.equal(ops.vae_grid_to_nchw(g, 3), back[:, :3])
     ga, a = to_grid(ops, rnd(2, 64, 6, 10, seed=4))
     H, W = 6, 10
     pad = torch.full(((2 * (H + 2) * (W + 2)) * 64,), 7.0, dtype=ops.BF16, device="cuda")                    # padded-grid view with a garbage border

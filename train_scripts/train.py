@@ -4,7 +4,9 @@
 [--resume-from ...] [--debug]`), driving the MI355X denoiser + fused AdamW + overlapped RCCL all-reduce.
 
 Data: precomputed features in the reference's layout (tools/extract_features.py: `<name>.npy` = cat[mean,std] latent,
-`<name>.npz` = caption_feature + attention_mask) listed in `config.data_root`, or `--synthetic`.  VAE / T5 on the fly, mmcv
+`<name>.npz` = caption_feature + attention_mask) listed in `config.data_root`, or `--synthetic`.  With `load_vae_feat = False`
+the batches are images and the latents come from the HIP VAE on the fly, as in reference train.py:144-153 (`vae_pretrained` = a
+diffusers AutoencoderKL directory; synthetic images and a random-init VAE when it is absent).  T5 on the fly, mmcv
 configs with `_base_` inheritance, tensorboard/wandb trackers and validation image logging are outside this repo's scope
 (SURVEY.md section 2): the config is a plain Python file whose module-level names are the keys of section 5 of the survey.
 """
@@ -27,7 +29,8 @@ DEFAULTS = dict(model="PixArtMS_XL_2", image_size=1024, train_batch_size=16, num
                 learn_sigma=True, class_dropout_prob=0.1, kv_compress=False, kv_compress_config=None, micro_condition=False,
                 grad_checkpointing=False, fp32_attention=False, gc_step=1, scale_factor=0.13025, gradient_clip=0.01,
                 optimizer=dict(type="AdamW", lr=2e-5, weight_decay=3e-2, eps=1e-10), train_sampling_steps=1000, snr_loss=False,
-                log_interval=20, save_model_steps=1000, seed=43, data_root=None)
+                log_interval=20, save_model_steps=1000, seed=43, data_root=None, load_vae_feat=True,
+                vae_pretrained="output/pretrained_models/pixart_sigma_sdxlvae_T5_diffusers/vae")
 
 
 def parse_args():
@@ -45,6 +48,8 @@ def parse_args():
 def batches(cfg, B, lat, L, dev, rank, world, synthetic):
     if synthetic or not cfg["data_root"]:
         g = torch.Generator().manual_seed(cfg["seed"] + rank)
+        while not cfg["load_vae_feat"]:                                            # images in, latents from the VAE inside the step
+            yield torch.randn(B, 3, lat * 8, lat * 8, generator=g).clamp(-1, 1).to(dev), torch.randn(B, 1, L, 4096, generator=g).to(dev), torch.ones(B, L, dtype=torch.int64)
         while True:
             yield torch.randn(B, 4, lat, lat, generator=g).to(dev), torch.randn(B, 1, L, 4096, generator=g).to(dev), torch.ones(B, L, dtype=torch.int64)
     names = sorted(glob.glob(os.path.join(cfg["data_root"], "*.npz")))[rank::world]
@@ -94,11 +99,19 @@ def main():
         opt.load_state_dict(sd["optimizer"])
         start_step = int(os.path.basename(a.resume_from).split("_step_")[-1].split(".")[0]) if "_step_" in a.resume_from else sd.get("step", 0)
     diff = IDDPM(str(cfg["train_sampling_steps"]), learn_sigma=cfg["learn_sigma"], pred_sigma=cfg["pred_sigma"], snr=cfg["snr_loss"])
+    vae = None
+    if not cfg["load_vae_feat"]:                                                   # reference train.py:351-354
+        from pixart_sigma_amd.vae import AutoencoderKL
+        have = os.path.isdir(str(cfg["vae_pretrained"]))
+        vae = (AutoencoderKL.from_pretrained(cfg["vae_pretrained"], torch_dtype=torch.float16) if have else AutoencoderKL(scaling_factor=cfg["scale_factor"])).to(dev)
+        cfg["scale_factor"] = vae.config.scaling_factor
     os.makedirs(os.path.join(a.work_dir, "checkpoints"), exist_ok=True)
     it = batches(cfg, cfg["train_batch_size"], lat, L, dev, rank, world, a.synthetic)
     t0, step = time.time(), start_step
     while a.max_steps is None or step < start_step + a.max_steps:
         z, y, mask = next(it)
+        if vae is not None:                                                        # reference train.py:147-153
+            z = vae.encode(z).latent_dist.sample().float()
         x0 = z * cfg["scale_factor"]
         t = torch.randint(0, cfg["train_sampling_steps"], (z.shape[0],), device=dev).long()
         opt.zero_grad()
