@@ -169,6 +169,36 @@ int pxa_adamw_step(float* p, const float* g, float* m, float* v, void* p_bf16, l
                    float eps, float weight_decay, int step, const float* gscale, hipStream_t stream);
 int pxa_cast_f32_bf16(const float* x, void* y_bf16, long n, hipStream_t stream);
 
+/* ---------------------------------------------------------------------------------------------- CAME optimizer
+ * came_pytorch.CAME.step() (un-vendored dependency; the reference's CAMEWrapper subclasses it unchanged:
+ * diffusion/utils/optimizer.py:15,242-246; used by every PixArt-Sigma config, e.g.
+ * configs/pixart_sigma_config/PixArt_sigma_xl2_img1024_internalms.py:29) over the flat parameter store, all tensors per launch.
+ * A tensor with >= 2 dims is factored: viewed as [batch][R][C] (its last two dims), state = row means [batch*R] and column means
+ * [batch*C] of the second moment and of the confidence residual; 1-D tensors keep a full second moment.  Tables are built once by
+ * the caller (pixart_sigma_amd/dp.py: FusedCAME) and live in device memory:
+ *   tensors[t]: off = first element in the flat buffers; factored: batch, R, C and the offsets of its row state (row_off, length
+ *               batch*R), column state (col_off, batch*C) and row-state means (rm_off, batch); 1-D: factored = 0, C = numel,
+ *               nf_off = offset of its full second moment in nf_sq.
+ *   tiles[i]:   factored: global rows [first, first+count) of tensor `tensor` (whole rows only); 1-D: elements [first, first+count).
+ *   col_inv_r:  [n_cols_total] 1/R of the tensor owning each column-state entry.
+ * scratch: pxa_came_scratch_elems() floats, zeroed by the call.  gscale: optional device scalar multiplying every gradient (the
+ * clip coefficient of pxa_clip_coef).  Also refreshes the bf16 shadow weights.                                                   */
+typedef struct { long off; int batch, R, C, factored; long row_off, col_off, rm_off, nf_off; } pxa_came_tensor;
+typedef struct { int tensor, first, count, pad; } pxa_came_tile;
+typedef struct {
+  float* p; const float* g; float* exp_avg; void* p_bf16;
+  float* sq_row; float* sq_col; float* res_row; float* res_col; float* nf_sq;
+  float* scratch;
+  const pxa_came_tensor* tensors; int n_tensors;
+  const pxa_came_tile* tiles; int n_tiles;
+  const float* col_inv_r;
+  long n_cols_total, n_rm_total;
+  double lr, beta1, beta2, beta3, eps0, eps1, clip_threshold, weight_decay;   /* doubles: 1 - beta is formed in fp64 like torch's alpha */
+  const float* gscale;
+} pxa_came_args;
+long pxa_came_scratch_elems(long n_cols_total, long n_rm_total, int n_tensors);
+int pxa_came_step(const pxa_came_args* args, hipStream_t stream);
+
 /* ---------------------------------------------------------------------------------------------- VAE conv stack
  * The SDXL-VAE / SD-VAE (diffusers AutoencoderKL) encode / decode path: vae.encode(...).latent_dist (train_scripts/train.py:149-153),
  * vae.decode(latent / scaling_factor).sample (scripts/inference.py:136, train_scripts/train.py:88).  Forward only (the VAE is frozen).

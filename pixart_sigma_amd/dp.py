@@ -88,3 +88,92 @@ class FusedAdamW:
         self.m.copy_(sd["m"])
         self.v.copy_(sd["v"])
         self.t, self.lr = sd["t"], sd.get("lr", self.lr)
+
+
+class FusedCAME(FusedAdamW):
+    """came_pytorch.CAME semantics (the reference's CAMEWrapper, diffusion/utils/optimizer.py:242-246; config defaults of
+    configs/pixart_sigma_config/*.py: lr 2e-5, weight_decay 0, betas (0.9, 0.999, 0.9999), eps (1e-30, 1e-16)) + clip_grad_norm_ on
+    the flat buffers: one pxa_came_step call per step (6 launches over all tensors).  Memory: exp_avg (fp32, one per parameter) +
+    row / column statistics - the factored second moments are 0.1 % of AdamW's `v`."""
+    TILE_ELEMS = 262144      # per workgroup: every tile ends in C same-address atomics on the column partials, so tiles are large
+
+    def __init__(self, model, lr=2e-5, betas=(0.9, 0.999, 0.9999), eps=(1e-30, 1e-16), clip_threshold=1.0, weight_decay=0.0,
+                 max_grad_norm=0.01, reducer=None):
+        from .lib import CameTensor, CameTile
+        import ctypes as C
+        assert model._store is not None, "call model.prepare(device) (or run one forward) before building the optimizer"
+        self.model, self.store = model, model._store
+        self.lr, self.betas, self.eps, self.clip, self.wd, self.max_norm = lr, betas, eps, clip_threshold, weight_decay, max_grad_norm
+        st, dev = self.store, self.store.device
+        tensors, tiles, inv_r = [], [], []
+        n_row = n_col = n_rm = n_nf = 0
+        self.layout = {}                                  # name -> dict(kind, offsets): for state_dict / tests
+        for ti, name in enumerate(st.names):
+            shape, numel = st.shape[name], st.numel[name]
+            t = CameTensor()
+            t.off = st.offset[name]
+            if len(shape) >= 2:
+                R, Cc = shape[-2], shape[-1]
+                batch = numel // (R * Cc)
+                t.batch, t.R, t.C, t.factored = batch, R, Cc, 1
+                t.row_off, t.col_off, t.rm_off, t.nf_off = n_row, n_col, n_rm, 0
+                self.layout[name] = dict(factored=True, row=(n_row, batch * R), col=(n_col, batch * Cc))
+                pad = -(batch * Cc) % 4                       # keep every tensor's column state 16-byte aligned
+                inv_r += [1.0 / R] * (batch * Cc) + [0.0] * pad
+                rows = batch * R
+                per = max(4, self.TILE_ELEMS // Cc // 4 * 4)
+                for r0 in range(0, rows, per):
+                    tiles.append((ti, r0, min(per, rows - r0)))
+                n_row, n_col, n_rm = n_row + rows, n_col + batch * Cc + pad, n_rm + batch
+            else:
+                t.batch, t.R, t.C, t.factored = 1, 1, numel, 0
+                t.row_off = t.col_off = t.rm_off = 0
+                t.nf_off = n_nf
+                self.layout[name] = dict(factored=False, nf=(n_nf, numel))
+                for e0 in range(0, numel, self.TILE_ELEMS):
+                    tiles.append((ti, e0, min(self.TILE_ELEMS, numel - e0)))
+                n_nf += numel
+            tensors.append(t)
+        self.n_col, self.n_rm, self.n_tensors, self.n_tiles = n_col, n_rm, len(tensors), len(tiles)
+        tarr = (CameTensor * len(tensors))(*tensors)
+        larr = (CameTile * len(tiles))(*[CameTile(a, b, c, 0) for a, b, c in tiles])
+        self.tensors_dev = torch.frombuffer(bytearray(C.string_at(C.addressof(tarr), C.sizeof(tarr))), dtype=torch.uint8).to(dev)
+        self.tiles_dev = torch.frombuffer(bytearray(C.string_at(C.addressof(larr), C.sizeof(larr))), dtype=torch.uint8).to(dev)
+        self.col_inv_r = torch.tensor(inv_r if inv_r else [0.0], dtype=torch.float32, device=dev)
+        z = lambda n: torch.zeros(max(n, 1), dtype=torch.float32, device=dev)
+        self.m = torch.zeros_like(st.master)
+        self.sq_row, self.res_row, self.sq_col, self.res_col, self.nf_sq = z(n_row), z(n_row), z(n_col), z(n_col), z(n_nf)
+        from . import lib
+        self.scratch = z(lib.load().pxa_came_scratch_elems(n_col, n_rm, len(tensors)))
+        self.sumsq = torch.zeros(1, device=dev)
+        self.coef = torch.zeros(2, device=dev)
+        self.t = 0
+        self.reducer = reducer or GradReducer(self.store)
+        model._engine.grad_ready_hook = self.reducer.on_group_ready
+
+    def step(self):
+        from . import ops
+        from .lib import CameArgs, call, ptr
+        self.store.attach_grads()
+        inv_world = self.reducer.finish()
+        self.t += 1
+        self.sumsq.zero_()
+        ops.sumsq(self.store.grad, self.sumsq)
+        ops.clip_coef(self.sumsq, self.coef, self.max_norm if self.max_norm else 0.0, inv_world)
+        a = CameArgs()
+        a.p, a.g, a.exp_avg, a.p_bf16 = ptr(self.store.master), ptr(self.store.grad), ptr(self.m), ptr(self.store.shadow)
+        a.sq_row, a.sq_col, a.res_row, a.res_col, a.nf_sq = ptr(self.sq_row), ptr(self.sq_col), ptr(self.res_row), ptr(self.res_col), ptr(self.nf_sq)
+        a.scratch, a.tensors, a.n_tensors, a.tiles, a.n_tiles = ptr(self.scratch), ptr(self.tensors_dev), self.n_tensors, ptr(self.tiles_dev), self.n_tiles
+        a.col_inv_r, a.n_cols_total, a.n_rm_total = ptr(self.col_inv_r), self.n_col, self.n_rm
+        a.lr, a.beta1, a.beta2, a.beta3 = self.lr, self.betas[0], self.betas[1], self.betas[2]
+        a.eps0, a.eps1, a.clip_threshold, a.weight_decay = self.eps[0], self.eps[1], self.clip, self.wd
+        a.gscale = ptr(self.coef)
+        call("pxa_came_step", a)                        # refreshes the bf16 shadow itself (no parameter version is bumped)
+
+    def state_dict(self):
+        return {k: getattr(self, k) for k in ("m", "sq_row", "sq_col", "res_row", "res_col", "nf_sq")} | {"t": self.t, "lr": self.lr}
+
+    def load_state_dict(self, sd):
+        for k in ("m", "sq_row", "sq_col", "res_row", "res_col", "nf_sq"):
+            getattr(self, k).copy_(sd[k])
+        self.t, self.lr = sd["t"], sd.get("lr", self.lr)

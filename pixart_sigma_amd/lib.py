@@ -34,6 +34,24 @@ class GridArg(C.Structure):
                 ("row_pitch", c_int), ("img_pitch", c_long), ("origin", c_long)]
 
 
+class CameTensor(C.Structure):
+    _fields_ = [("off", c_long), ("batch", c_int), ("R", c_int), ("C", c_int), ("factored", c_int),
+                ("row_off", c_long), ("col_off", c_long), ("rm_off", c_long), ("nf_off", c_long)]
+
+
+class CameTile(C.Structure):
+    _fields_ = [("tensor", c_int), ("first", c_int), ("count", c_int), ("pad", c_int)]
+
+
+class CameArgs(C.Structure):
+    _fields_ = [("p", c_void_p), ("g", c_void_p), ("exp_avg", c_void_p), ("p_bf16", c_void_p),
+                ("sq_row", c_void_p), ("sq_col", c_void_p), ("res_row", c_void_p), ("res_col", c_void_p), ("nf_sq", c_void_p),
+                ("scratch", c_void_p), ("tensors", c_void_p), ("n_tensors", c_int), ("tiles", c_void_p), ("n_tiles", c_int),
+                ("col_inv_r", c_void_p), ("n_cols_total", c_long), ("n_rm_total", c_long),
+                ("lr", C.c_double), ("beta1", C.c_double), ("beta2", C.c_double), ("beta3", C.c_double), ("eps0", C.c_double), ("eps1", C.c_double),
+                ("clip_threshold", C.c_double), ("weight_decay", C.c_double), ("gscale", c_void_p)]
+
+
 class AttnArgs(C.Structure):
     _fields_ = [("q", c_void_p), ("k", c_void_p), ("v", c_void_p), ("o", c_void_p),
                 ("d_o", c_void_p), ("dq", c_void_p), ("dk", c_void_p), ("dv", c_void_p),
@@ -74,6 +92,7 @@ SIGNATURES = {
     "pxa_clip_coef": [_P, _P, _F, _F, _P],
     "pxa_adamw_step": [_P, _P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _I, _P, _P],
     "pxa_cast_f32_bf16": [_P, _P, _L, _P],
+    "pxa_came_step": [C.POINTER(CameArgs), _P],
     "pxa_vae_gn_stats": [_G, _I, _F, _P, _P, _P, _P],
     "pxa_vae_gn_apply": [_G, _P, _P, _P, _P, _I, _I, _I, _G, _P],
     "pxa_vae_im2col3x3": [_G, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P],
@@ -82,7 +101,7 @@ SIGNATURES = {
     "pxa_vae_nchw_to_grid": [_P, _I, _F, _G, _P],
     "pxa_vae_grid_to_nchw": [_G, _I, _P, _P],
 }
-OTHER_SYMBOLS = ["pxa_last_error", "pxa_abi_version", "pxa_operand_dtype", "pxa_device_info", "pxa_gemm_splitk_ws_elems"]
+OTHER_SYMBOLS = ["pxa_last_error", "pxa_abi_version", "pxa_operand_dtype", "pxa_device_info", "pxa_gemm_splitk_ws_elems", "pxa_came_scratch_elems"]
 
 _lib = None
 
@@ -105,6 +124,7 @@ def load():
         fn.argtypes, fn.restype = argtypes, c_int
     lib.pxa_last_error.restype = C.c_char_p
     lib.pxa_abi_version.restype = c_int
+    lib.pxa_came_scratch_elems.argtypes, lib.pxa_came_scratch_elems.restype = [c_long, c_long, c_int], c_long
     lib.pxa_device_info.argtypes, lib.pxa_device_info.restype = [C.POINTER(c_int), C.POINTER(c_int)], c_int
     if lib.pxa_abi_version() != ABI_VERSION:
         raise PixartHipError(f"ABI mismatch: library {lib.pxa_abi_version()} vs binding {ABI_VERSION}")

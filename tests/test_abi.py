@@ -30,7 +30,8 @@ def test_struct_layouts_match_header():
     """Field order of the ctypes structures follows the C structs (guards against silent ABI drift)."""
     from pixart_sigma_amd import lib
     src = open(os.path.join(ROOT, "include", "pixart_hip.h")).read()
-    for cname, st in (("pxa_gemm_args", lib.GemmArgs), ("pxa_attn_args", lib.AttnArgs), ("pxa_grid", lib.GridArg)):
+    for cname, st in (("pxa_gemm_args", lib.GemmArgs), ("pxa_attn_args", lib.AttnArgs), ("pxa_grid", lib.GridArg),
+                      ("pxa_came_tensor", lib.CameTensor), ("pxa_came_tile", lib.CameTile), ("pxa_came_args", lib.CameArgs)):
         body = re.search(r"typedef struct \{([^}]*)\} " + cname, src, flags=re.S).group(1)
         body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
         fields = []

@@ -23,7 +23,7 @@ import torch.distributed as dist
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from pixart_sigma_amd import IDDPM, build_model  # noqa: E402
-from pixart_sigma_amd.dp import FusedAdamW  # noqa: E402
+from pixart_sigma_amd.dp import FusedAdamW, FusedCAME  # noqa: E402
 
 DEFAULTS = dict(model="PixArtMS_XL_2", image_size=1024, train_batch_size=16, num_epochs=1, model_max_length=300, pred_sigma=True,
                 learn_sigma=True, class_dropout_prob=0.1, kv_compress=False, kv_compress_config=None, micro_condition=False,
@@ -93,8 +93,12 @@ def main():
     model = model.to(dev).train()
     model.prepare(dev)
     o = cfg["optimizer"]
-    opt = FusedAdamW(model, lr=o["lr"], weight_decay=o["weight_decay"], eps=o.get("eps", 1e-8), betas=o.get("betas", (0.9, 0.999)),
-                     max_grad_norm=cfg["gradient_clip"])
+    if o.get("type", "AdamW") in ("CAMEWrapper", "CAME"):      # the optimizer of the PixArt-Sigma configs (reference optimizer.py:242-246)
+        opt = FusedCAME(model, lr=o["lr"], weight_decay=o.get("weight_decay", 0.0), eps=o.get("eps", (1e-30, 1e-16)),
+                        betas=o.get("betas", (0.9, 0.999, 0.9999)), max_grad_norm=cfg["gradient_clip"])
+    else:
+        opt = FusedAdamW(model, lr=o["lr"], weight_decay=o["weight_decay"], eps=o.get("eps", 1e-8), betas=o.get("betas", (0.9, 0.999)),
+                         max_grad_norm=cfg["gradient_clip"])
     if a.resume_from and "optimizer" in sd:
         opt.load_state_dict(sd["optimizer"])
         start_step = int(os.path.basename(a.resume_from).split("_step_")[-1].split(".")[0]) if "_step_" in a.resume_from else sd.get("step", 0)
