@@ -1,0 +1,2 @@
+"""Callers' side of the hot path: batch formation for multi-aspect training."""
+from .sampler import AspectRatioBatchSampler, closest_ratio  # noqa: F401
