@@ -47,7 +47,8 @@ int pxa_device_info(int* cu_count, int* is_gfx950);
  * act 3: GELU(tanh) after bias with GELU'(pre-activation) stored to out2_bf16 (required) — the training forward of fc1:
  *        the derivative shares the sigmoid of the activation, so saving it costs 5 VALU ops where recomputing it in the
  *        backward epilogue costs 12 with every accumulator live;
- * act 4: multiply by aux[m][n] (aux = the derivative saved by act 3) — the fc1 backward input gradient of that path. */
+ * act 4: multiply by aux[m][n] (aux = the derivative saved by act 3) — the fc1 backward input gradient of that path;
+ * act 5: add aux[m][n] after bias — the residual connection of a ResnetBlock2D folded into its second convolution (VAE). */
 typedef struct {
   const void* A; const void* B;  /* bf16 */
   int lda, ldb;
@@ -55,7 +56,7 @@ typedef struct {
   int layout;
   const float* bias;             /* [N] or NULL */
   int act;
-  const void* aux; int ldaux;    /* bf16 [M][N], act == 2 or 4 */
+  const void* aux; int ldaux;    /* bf16 [M][N], act == 2, 4 or 5 */
   void* out_bf16; void* out2_bf16; int ld_out;
   float* out_f32; int ld_f32;
   int accumulate;                /* out_f32: 0 = store, 1 = atomicAdd (gradient accumulation / split-K) */

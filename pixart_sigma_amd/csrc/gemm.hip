@@ -134,12 +134,13 @@ __device__ __forceinline__ void epilogue(const GemmParams& p, const f32x16 (&acc
 #pragma unroll
           for (int e = 0; e < 4; e++) v[e] = gelu_tanh_both(v[e], g[e]);
           *reinterpret_cast<uint2*>(p.out2 + (size_t)m * p.ldo + n) = pack_bf16x4(g[0], g[1], g[2], g[3]);
-        } else if (p.act == 2 || p.act == 4) {
+        } else if (p.act == 2 || p.act == 4 || p.act == 5) {
           const uint2 a = *reinterpret_cast<const uint2*>(p.aux + (size_t)m * p.ldaux + n);
           float a0, a1, a2, a3;
           unpack_bf16x2(a.x, a0, a1); unpack_bf16x2(a.y, a2, a3);
           if (p.act == 2) { a0 = gelu_tanh_grad(a0); a1 = gelu_tanh_grad(a1); a2 = gelu_tanh_grad(a2); a3 = gelu_tanh_grad(a3); }
-          v[0] *= a0; v[1] *= a1; v[2] *= a2; v[3] *= a3;
+          if (p.act == 5) { v[0] += a0; v[1] += a1; v[2] += a2; v[3] += a3; }
+          else { v[0] *= a0; v[1] *= a1; v[2] *= a2; v[3] *= a3; }
         }
         if (p.out) *reinterpret_cast<uint2*>(p.out + (size_t)m * p.ldo + n) = pack_bf16x4(v[0], v[1], v[2], v[3]);
         if (p.outf) {
@@ -329,14 +330,15 @@ __device__ __forceinline__ void epilogue_staged(const GemmParams& p, f32x16 (&ac
             if (p.act == 1) {
 #pragma unroll
               for (int e = 0; e < 4; e++) v[e] = gelu_tanh(v[e]);
-            } else if (p.act == 2 || p.act == 4) {
+            } else if (p.act == 2 || p.act == 4 || p.act == 5) {
               const int m = mw + i * 32 + (lane & 31), n = nw + col;
               if (m < p.M && n < p.N) {
                 const uint2 a = *reinterpret_cast<const uint2*>(p.aux + (size_t)m * p.ldaux + n);
                 float a0, a1, a2, a3;
                 unpack_bf16x2(a.x, a0, a1); unpack_bf16x2(a.y, a2, a3);
                 if (p.act == 2) { a0 = gelu_tanh_grad(a0); a1 = gelu_tanh_grad(a1); a2 = gelu_tanh_grad(a2); a3 = gelu_tanh_grad(a3); }
-                v[0] *= a0; v[1] *= a1; v[2] *= a2; v[3] *= a3;
+                if (p.act == 5) { v[0] += a0; v[1] += a1; v[2] += a2; v[3] += a3; }
+                else { v[0] *= a0; v[1] *= a1; v[2] *= a2; v[3] *= a3; }
               }
             }
           }
@@ -392,12 +394,13 @@ __device__ __forceinline__ void epilogue_t(const GemmParams& p, const f32x16 (&a
 #pragma unroll
           for (int e = 0; e < 4; e++) v[e] = gelu_tanh_both(v[e], g[e]);
           *reinterpret_cast<uint2*>(p.out2 + (size_t)m * p.ldo + n) = pack_bf16x4(g[0], g[1], g[2], g[3]);
-        } else if (p.act == 2 || p.act == 4) {
+        } else if (p.act == 2 || p.act == 4 || p.act == 5) {
           const uint2 a = *reinterpret_cast<const uint2*>(p.aux + (size_t)m * p.ldaux + n);
           float a0, a1, a2, a3;
           unpack_bf16x2(a.x, a0, a1); unpack_bf16x2(a.y, a2, a3);
           if (p.act == 2) { a0 = gelu_tanh_grad(a0); a1 = gelu_tanh_grad(a1); a2 = gelu_tanh_grad(a2); a3 = gelu_tanh_grad(a3); }
-          v[0] *= a0; v[1] *= a1; v[2] *= a2; v[3] *= a3;
+          if (p.act == 5) { v[0] += a0; v[1] += a1; v[2] += a2; v[3] += a3; }
+          else { v[0] *= a0; v[1] *= a1; v[2] *= a2; v[3] *= a3; }
         }
         if (p.out) *reinterpret_cast<uint2*>(p.out + (size_t)m * p.ldo + n) = pack_bf16x4(v[0], v[1], v[2], v[3]);
         if (p.outf) {
@@ -912,7 +915,7 @@ __global__ __launch_bounds__(512) void gemm_pers_kernel(GemmParams p) {
       if (!more) break;
       continue;
     }
-    const int act = EPI == 0 ? 0 : EPI == 1 ? 3 : EPI == 2 ? 4 : p.act;
+    const int act = EPI == 0 ? 0 : EPI == 1 ? 3 : EPI == 2 ? 4 : EPI == 4 ? 5 : p.act;   // EPI 4: + aux (residual connection)
     const bool dual = EPI == 1 || (EPI == 3 && ((p.act == 1 && p.out2 != nullptr) || p.act == 3));
     const bool want_cs = EPI == 2 || (EPI == 3 && p.colsum != nullptr);
     // one column group of JW 32-wide tiles (JW = 2: 128-byte staging rows, 8 rows per store; JW = 1: 64-byte rows, 16 per store)
@@ -935,7 +938,7 @@ __global__ __launch_bounds__(512) void gemm_pers_kernel(GemmParams p) {
 #pragma unroll
       for (int e = 0; e < 8; e++) cs[e] = 0.f;
       // aux (saved pre-activation / saved GELU') of the NEXT row slice is requested before this slice is processed
-      const bool want_aux = (act == 2 || act == 4);
+      const bool want_aux = (act == 2 || act == 4 || act == 5);
       uint2 ax[2][JW][4];
       auto load_aux = [&](int i, uint2 (&dst)[JW][4]) {
         const int m = mw + i * 32 + srow;
@@ -970,11 +973,12 @@ __global__ __launch_bounds__(512) void gemm_pers_kernel(GemmParams p) {
                 if (act == 1) {
 #pragma unroll
                   for (int e = 0; e < 4; e++) v[e] = gelu_tanh(v[e]);
-                } else if (act == 2 || act == 4) {
+                } else if (act == 2 || act == 4 || act == 5) {
                   float a0, a1, a2, a3;
                   unpack_bf16x2(ax[i & 1][jj][q].x, a0, a1); unpack_bf16x2(ax[i & 1][jj][q].y, a2, a3);
                   if (act == 2) { a0 = gelu_tanh_grad(a0); a1 = gelu_tanh_grad(a1); a2 = gelu_tanh_grad(a2); a3 = gelu_tanh_grad(a3); }
-                  v[0] *= a0; v[1] *= a1; v[2] *= a2; v[3] *= a3;
+                  if (act == 5) { v[0] += a0; v[1] += a1; v[2] += a2; v[3] += a3; }
+                  else { v[0] *= a0; v[1] *= a1; v[2] *= a2; v[3] *= a3; }
                 }
               }
               const int ch = jj * 4 + q;               // 16-byte chunk of the staging row
@@ -1116,8 +1120,10 @@ int launch(GemmParams p, int split, hipStream_t s) {
   if (p.k_seg) {                                          // implicit 3x3 convolution (checked by pxa_gemm: NT, K and k_seg multiples of 64)
     if constexpr (LAYOUT == 0) {
       static const bool no_pers_seg = getenv("PXA_GEMM_NO_PERSISTENT") != nullptr;
-      if (p.out && !p.outf && p.act == 0 && p.M >= 1024 && p.N >= 128 && p.N % 128 == 0 && p.k_seg % 32 == 0 && !no_pers_seg)
+      if (p.out && !p.outf && (p.act == 0 || p.act == 5) && p.M >= 1024 && p.N >= 128 && p.N % 128 == 0 && p.k_seg % 32 == 0 && !no_pers_seg) {
+        if (p.act == 5) return pers_halfcol(p.N) ? launch_pers<0, 4, 2, true>(p, 1, s) : launch_pers<0, 4, 0, true>(p, 1, s);   // conv + residual
         return pers_halfcol(p.N) ? launch_pers<0, 0, 2, true>(p, 1, s) : launch_pers<0, 0, 0, true>(p, 1, s);
+      }
       if (p.out && !p.outf && p.act == 0) return launch_glds_e<0, 128, 128, 2, 2, 1, true>(p, 1, s);
       return launch_glds_e<0, 128, 128, 2, 2, 0, true>(p, 1, s);
     }
@@ -1167,8 +1173,8 @@ extern "C" int pxa_gemm(const pxa_gemm_args* a, hipStream_t stream) {
   PXA_CHECK(a->out_bf16 || a->out_f32, "pxa_gemm: no output");
   if (a->out_bf16 || a->out2_bf16) PXA_CHECK(a->ld_out % 4 == 0, "pxa_gemm: ld_out must be a multiple of 4");
   if (a->out_f32) PXA_CHECK(a->ld_f32 % 4 == 0, "pxa_gemm: ld_f32 must be a multiple of 4");
-  PXA_CHECK(a->act >= 0 && a->act <= 4, "pxa_gemm: bad act %d", a->act);
-  if (a->act == 2 || a->act == 4) PXA_CHECK(a->aux && a->ldaux % 4 == 0, "pxa_gemm: act=%d needs aux", a->act);
+  PXA_CHECK(a->act >= 0 && a->act <= 5, "pxa_gemm: bad act %d", a->act);
+  if (a->act == 2 || a->act == 4 || a->act == 5) PXA_CHECK(a->aux && a->ldaux % 4 == 0, "pxa_gemm: act=%d needs aux", a->act);
   if (a->act == 3) PXA_CHECK(a->out_bf16 && a->out2_bf16, "pxa_gemm: act=3 needs both bf16 outputs");
   if (a->colsum) PXA_CHECK(a->out_bf16 && !a->out_f32, "pxa_gemm: colsum needs a bf16 output");
   int split = a->split_k < 1 ? 1 : a->split_k;   // 0 = choose here (only for fp32 atomic-accumulate outputs)

@@ -12,7 +12,7 @@ from .lib import AttnArgs, GemmArgs, GridArg, call, ptr
 from .lib import OPERAND_DTYPE as BF16  # noqa: E402
 F32 = torch.float32
 NT, NN, TN = 0, 1, 2
-ACT_NONE, ACT_GELU, ACT_GELU_GRAD, ACT_GELU_SAVE_GRAD, ACT_MUL_AUX = 0, 1, 2, 3, 4
+ACT_NONE, ACT_GELU, ACT_GELU_GRAD, ACT_GELU_SAVE_GRAD, ACT_MUL_AUX, ACT_ADD_AUX = 0, 1, 2, 3, 4, 5
 _SPLITK_WS = {}
 
 
@@ -44,7 +44,7 @@ def gemm(a, b, layout=NT, bias=None, act=ACT_NONE, aux=None, out=None, out2=None
         _chk(bias, F32, "bias")
         assert bias.numel() == N
     g.bias, g.act = ptr(bias), act
-    if act in (ACT_GELU_GRAD, ACT_MUL_AUX):
+    if act in (ACT_GELU_GRAD, ACT_MUL_AUX, ACT_ADD_AUX):
         _chk(aux, BF16, "aux")
         g.aux, g.ldaux = ptr(aux), aux.stride(0)
     want_f32 = out_f32 is not None or out_dtype == F32

@@ -248,8 +248,9 @@ class AutoencoderKL(nn.Module):
         gamma, beta = self._packed[id(gn)]
         return (mean, rstd, gamma, beta, gn.num_groups)
 
-    def _conv3(self, x, conv, norm=None, silu=False, upsample=1, out_f32=False):
-        """3x3 stride-1 pad-1 convolution of act(norm(x)) (optionally 2x upsampled first)."""
+    def _conv3(self, x, conv, norm=None, silu=False, upsample=1, out_f32=False, residual=None):
+        """3x3 stride-1 pad-1 convolution of act(norm(x)) (optionally 2x upsampled first); `residual` (a grid) is added to the result -
+        inside the GEMM epilogue when it already has the output's padded-grid layout, by the add kernel otherwise."""
         w, b, _ = self._packed[id(conv)]
         B, H, W, C, dev = x.B, x.H * upsample, x.W * upsample, x.C, x.buf.device
         assert w.shape[1] == 9 * C
@@ -258,11 +259,15 @@ class AutoencoderKL(nn.Module):
             ip, rp = (H + 2) * (W + 2), W + 2
             ops.vae_gn_apply(x, Grid(buf, B, H, W, C, rp, ip, origin=(W + 3) + rp + 1), norm, silu, upsample)
             a = buf.as_strided((B * ip, 9 * C), (C, 1))
-            out = ops.gemm(a, w, ops.NT, bias=b, out_dtype=F32 if out_f32 else BF16, k_seg=3 * C, a_seg_stride=rp * C)
+            fused = (residual is not None and not out_f32 and residual.C == w.shape[0] and residual.row_pitch == rp and residual.img_pitch == ip
+                     and residual.origin == W + 3 and (residual.B, residual.H, residual.W) == (B, H, W))
+            out = ops.gemm(a, w, ops.NT, bias=b, out_dtype=F32 if out_f32 else BF16, k_seg=3 * C, a_seg_stride=rp * C,
+                           act=ops.ACT_ADD_AUX if fused else ops.ACT_NONE, aux=residual.rows() if fused else None)
             if out_f32:
                 return out.view(B, H + 2, W + 2, -1)[:, 1:-1, 1:-1]
-            return Grid(out, B, H, W, w.shape[0], rp, ip, origin=W + 3)
-        assert upsample == 1 and not out_f32
+            y = Grid(out, B, H, W, w.shape[0], rp, ip, origin=W + 3)
+            return y if fused or residual is None else ops.vae_add(y, residual, y)
+        assert upsample == 1 and not out_f32 and residual is None
         col = ops.vae_im2col3x3(x, 1, 1, H, W, norm, silu)      # stem convolutions: C = 8 (3 / 4 real channels)
         return Grid(ops.gemm(col, w, ops.NT, bias=b), B, H, W, w.shape[0])
 
@@ -281,9 +286,8 @@ class AutoencoderKL(nn.Module):
 
     def _resnet(self, x, r):
         h = self._conv3(x, r.conv1, self._norm(x, r.norm1), silu=True)
-        h = self._conv3(h, r.conv2, self._norm(h, r.norm2), silu=True)
         sc = x if r.conv_shortcut is None else self._conv1(x, r.conv_shortcut)
-        return ops.vae_add(h, sc, h)
+        return self._conv3(h, r.conv2, self._norm(h, r.norm2), silu=True, residual=sc)
 
     def _attention(self, x, at):
         B, HW, C, dev = x.B, x.H * x.W, x.C, x.buf.device

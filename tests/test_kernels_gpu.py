@@ -95,6 +95,8 @@ def test_gemm_persistent_kernel_epilogues(ops, M, N, K):
     assert rel_l2(out.float(), ref * aux.float()) < BF16_TOL
     assert rel_l2(part.sum(0), out.float().sum(0)) < 1e-4       # the column sums are taken over exactly the bf16 values that are stored
     assert rel_l2(part.sum(0), (ref * aux.float()).sum(0)) < 5e-3   # ... so they carry the bf16 rounding of the summands (2^-9 each)
+    out = ops.gemm(a, w, ops.NT, bias=b, act=ops.ACT_ADD_AUX, aux=aux)                         # residual add (VAE resnet), run-time flavour
+    assert rel_l2(out.float(), pre + aux.float()) < BF16_TOL
     g = bf(pre)
     out = ops.gemm(a, wt, ops.NN, act=ops.ACT_GELU_GRAD, aux=g)
     gx = g.float().clone().requires_grad_(True)

@@ -77,6 +77,10 @@ def test_implicit_conv3x3_is_conv2d(ops, B, C, Co, H, W):
     a = buf.as_strided((B * ip, 9 * C), (C, 1))
     out = ops.gemm(a, wk, ops.NT, bias=bias, k_seg=3 * C, a_seg_stride=rp * C)
     assert rel_l2(from_grid(ops.Grid(out, B, H, W, Co, rp, ip, origin=W + 3)), ref) < BF16_TOL
+    res = rnd(B * ip, Co, seed=4).to(ops.BF16)                                                                 # residual in the output's own layout
+    out = ops.gemm(a, wk, ops.NT, bias=bias, k_seg=3 * C, a_seg_stride=rp * C, act=ops.ACT_ADD_AUX, aux=res)
+    want = ref + from_grid(ops.Grid(res, B, H, W, Co, rp, ip, origin=W + 3))
+    assert rel_l2(from_grid(ops.Grid(out, B, H, W, Co, rp, ip, origin=W + 3)), want) < BF16_TOL
     outf = ops.gemm(a, wk, ops.NT, bias=bias, out_dtype=torch.float32, k_seg=3 * C, a_seg_stride=rp * C)      # fp32 output flavour
     assert rel_l2(outf.view(B, H + 2, W + 2, Co)[:, 1:-1, 1:-1].permute(0, 3, 1, 2), ref) < 2e-5
 
