@@ -209,7 +209,7 @@ def main():
         }
         roof = {"bound": "mfma", "achieved": flops_step / sec_per_step / 1e12, "peak": MFMA_PEAK / 1e12, "unit": "TFLOP/s",
                 "frac": flops_step / sec_per_step / MFMA_PEAK, "traffic": None, "scope": "whole training step (algorithmic FLOPs / wall time)"}
-        if not a.no_kernel_roofline and a.image_size == 1024:
+        if not a.no_kernel_roofline and a.image_size == 1024 and world == 1:   # per-kernel measurements and the CPU leg: N = 1 only
             ks = kernel_rooflines(B, N)
             # dominant kernel of the step by total time (profiles/: attn_bwd_dkv_kernel, 56 launches, ~17 % of the step)
             dom = ks["attn_bwd_dkv_kernel"]
@@ -221,7 +221,7 @@ def main():
                              "scope": "whole training step (algorithmic FLOPs / wall time)"},
                     "kernels": {k: {"TFLOP/s": round(v["tflops"], 1), "frac": round(v["frac"], 4), "ms": round(v["seconds"] * 1e3, 3)} for k, v in ks.items()}}
         out["roofline"] = roof
-        if not a.no_cpu_baseline:
+        if not a.no_cpu_baseline and world == 1:
             cdt, cflops, cores, desc = cpu_baseline()
             out["cpu_baseline"] = {"value": 1.0 / (cdt * flops_step / cflops), "unit": "steps/s", "cores": cores, "kind": "port",
                                    "sample": desc + f"; scaled by algorithmic FLOPs x{flops_step / cflops:.1f} to the {a.image_size}px batch-{B} step"}
