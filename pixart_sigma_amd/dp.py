@@ -90,6 +90,33 @@ class FusedAdamW:
         self.t, self.lr = sd["t"], sd.get("lr", self.lr)
 
 
+def came_tables(names, offset, shape, numel, tile_elems):
+    """Host-side tables of pxa_came_step (include/pixart_hip.h): per tensor its [batch][R][C] view and the offsets of its row /
+    column / row-mean / full second-moment state; the tile list (whole rows of one tensor, ~tile_elems elements each; 1-D tensors:
+    element ranges); 1/R per column-state entry.  Pure Python (tested on CPU)."""
+    tensors, tiles, inv_r, layout = [], [], [], {}
+    n_row = n_col = n_rm = n_nf = 0
+    for ti, name in enumerate(names):
+        shp, n = shape[name], numel[name]
+        if len(shp) >= 2:                                 # came_pytorch: factored second moments over the last two dims
+            R, Cc = shp[-2], shp[-1]
+            batch = n // (R * Cc)
+            pad = -(batch * Cc) % 4                       # keep every tensor's column state 16-byte aligned
+            tensors.append(dict(off=offset[name], batch=batch, R=R, C=Cc, factored=1, row_off=n_row, col_off=n_col, rm_off=n_rm, nf_off=0))
+            layout[name] = dict(factored=True, row=(n_row, batch * R), col=(n_col, batch * Cc))
+            inv_r += [1.0 / R] * (batch * Cc) + [0.0] * pad
+            rows = batch * R
+            per = max(4, tile_elems // Cc // 4 * 4)
+            tiles += [(ti, r0, min(per, rows - r0)) for r0 in range(0, rows, per)]
+            n_row, n_col, n_rm = n_row + rows, n_col + batch * Cc + pad, n_rm + batch
+        else:
+            tensors.append(dict(off=offset[name], batch=1, R=1, C=n, factored=0, row_off=0, col_off=0, rm_off=0, nf_off=n_nf))
+            layout[name] = dict(factored=False, nf=(n_nf, n))
+            tiles += [(ti, e0, min(tile_elems, n - e0)) for e0 in range(0, n, tile_elems)]
+            n_nf += n
+    return dict(tensors=tensors, tiles=tiles, col_inv_r=inv_r, layout=layout, n_row=n_row, n_col=n_col, n_rm=n_rm, n_nf=n_nf)
+
+
 class FusedCAME(FusedAdamW):
     """came_pytorch.CAME semantics (the reference's CAMEWrapper, diffusion/utils/optimizer.py:242-246; config defaults of
     configs/pixart_sigma_config/*.py: lr 2e-5, weight_decay 0, betas (0.9, 0.999, 0.9999), eps (1e-30, 1e-16)) + clip_grad_norm_ on
@@ -105,34 +132,14 @@ class FusedCAME(FusedAdamW):
         self.model, self.store = model, model._store
         self.lr, self.betas, self.eps, self.clip, self.wd, self.max_norm = lr, betas, eps, clip_threshold, weight_decay, max_grad_norm
         st, dev = self.store, self.store.device
-        tensors, tiles, inv_r = [], [], []
-        n_row = n_col = n_rm = n_nf = 0
-        self.layout = {}                                  # name -> dict(kind, offsets): for state_dict / tests
-        for ti, name in enumerate(st.names):
-            shape, numel = st.shape[name], st.numel[name]
+        tb = came_tables(st.names, st.offset, st.shape, st.numel, self.TILE_ELEMS)
+        self.layout = tb["layout"]                        # name -> dict(kind, offsets): for state_dict / tests
+        tiles, inv_r, n_row, n_col, n_rm, n_nf = tb["tiles"], tb["col_inv_r"], tb["n_row"], tb["n_col"], tb["n_rm"], tb["n_nf"]
+        tensors = []
+        for d in tb["tensors"]:
             t = CameTensor()
-            t.off = st.offset[name]
-            if len(shape) >= 2:
-                R, Cc = shape[-2], shape[-1]
-                batch = numel // (R * Cc)
-                t.batch, t.R, t.C, t.factored = batch, R, Cc, 1
-                t.row_off, t.col_off, t.rm_off, t.nf_off = n_row, n_col, n_rm, 0
-                self.layout[name] = dict(factored=True, row=(n_row, batch * R), col=(n_col, batch * Cc))
-                pad = -(batch * Cc) % 4                       # keep every tensor's column state 16-byte aligned
-                inv_r += [1.0 / R] * (batch * Cc) + [0.0] * pad
-                rows = batch * R
-                per = max(4, self.TILE_ELEMS // Cc // 4 * 4)
-                for r0 in range(0, rows, per):
-                    tiles.append((ti, r0, min(per, rows - r0)))
-                n_row, n_col, n_rm = n_row + rows, n_col + batch * Cc + pad, n_rm + batch
-            else:
-                t.batch, t.R, t.C, t.factored = 1, 1, numel, 0
-                t.row_off = t.col_off = t.rm_off = 0
-                t.nf_off = n_nf
-                self.layout[name] = dict(factored=False, nf=(n_nf, numel))
-                for e0 in range(0, numel, self.TILE_ELEMS):
-                    tiles.append((ti, e0, min(self.TILE_ELEMS, numel - e0)))
-                n_nf += numel
+            for k, v in d.items():
+                setattr(t, k, v)
             tensors.append(t)
         self.n_col, self.n_rm, self.n_tensors, self.n_tiles = n_col, n_rm, len(tensors), len(tiles)
         tarr = (CameTensor * len(tensors))(*tensors)

@@ -123,3 +123,34 @@ def test_model_refuses_cpu_forward():
     m = PixArtMS(depth=1, hidden_size=1152, num_heads=16, input_size=8, model_max_length=4)
     with pytest.raises(AssertionError, match="HIP kernels only"):
         m(torch.zeros(1, 4, 8, 8), torch.zeros(1), torch.zeros(1, 1, 4, 4096))
+
+
+def test_came_tables_cover_every_parameter_exactly_once():
+    """Host tables of pxa_came_step (dp.came_tables): tiles partition the rows / elements of every tensor, factored views follow
+    came_pytorch (last two dims; leading dims are a batch of matrices), state offsets do not overlap, column state is 16-byte aligned."""
+    from pixart_sigma_amd.dp import came_tables
+    shapes = {"w": (300, 200), "b": (300,), "table": (6, 1152), "conv": (48, 4, 2, 2), "odd": (33, 7), "long": (70000,), "fc": (1152, 4608)}
+    names, offset, numel, off = list(shapes), {}, {}, 0
+    for n, s in shapes.items():
+        numel[n] = int(torch.tensor(s).prod())
+        offset[n] = off
+        off += (numel[n] + 63) // 64 * 64
+    tb = came_tables(names, offset, shapes, numel, tile_elems=4096)
+    T = tb["tensors"]
+    assert [t["factored"] for t in T] == [1, 0, 1, 1, 1, 0, 1]
+    conv = T[names.index("conv")]
+    assert (conv["batch"], conv["R"], conv["C"]) == (192, 2, 2)
+    covered = {i: [] for i in range(len(T))}
+    for ti, first, count in tb["tiles"]:
+        covered[ti].append((first, count))
+    for i, t in enumerate(T):
+        total = t["batch"] * t["R"] if t["factored"] else t["C"]
+        runs = sorted(covered[i])
+        assert runs[0][0] == 0 and sum(c for _, c in runs) == total
+        assert all(a[0] + a[1] == b[0] for a, b in zip(runs, runs[1:]))
+        if t["factored"]:
+            assert all(c * t["C"] <= max(4096, 4 * t["C"]) for _, c in runs) and t["col_off"] % 4 == 0
+    rows = [(t["row_off"], t["batch"] * t["R"]) for t in T if t["factored"]]
+    assert all(a[0] + a[1] == b[0] for a, b in zip(rows, rows[1:])) and rows[-1][0] + rows[-1][1] == tb["n_row"]
+    assert len(tb["col_inv_r"]) == tb["n_col"] and tb["n_rm"] == sum(t["batch"] for t in T if t["factored"])
+    assert tb["n_nf"] == 300 + 70000 and tb["col_inv_r"][T[0]["col_off"]] == 1.0 / 300
