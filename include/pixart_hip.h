@@ -68,6 +68,11 @@ typedef struct {
   int k_seg;                     /* segmented-K A operand (layout NT only, 0 = plain): element k of row m is read from          */
   long a_seg_stride;             /*  A[m*lda + (k / k_seg)*a_seg_stride + k % k_seg]; k_seg a multiple of 64 dividing K.       */
                                  /*  The implicit 3x3 convolution of the VAE kernel set: see pxa_vae_* below.                  */
+  int k_tap;                     /* 0: K runs segment-major as above.  > 0 (= channels C of a 3x3 convolution; k_seg = 3*k_tap,  */
+                                 /*  K = 9*k_tap): K is ordered [C/64 chunks][3 kernel rows][3 taps][64] and element k is read   */
+                                 /*  from A[m*lda + row*a_seg_stride + tap*k_tap + chunk*64 + k%64] - the same patch, visited    */
+                                 /*  so that all nine reads of a pixel's 64-channel chunk happen within 18 k-units (L2-resident) */
+                                 /*  instead of up to K/3 apart; B's rows follow the same K order.                               */
 } pxa_gemm_args;
 /* Upper bound of the split-K workspace (in floats) pxa_gemm may use for an (M, N) fp32-accumulate output. */
 long pxa_gemm_splitk_ws_elems(int M, int N);

@@ -34,6 +34,8 @@ struct GemmParams {
   long colsum_stride;
   int k_seg;       // segmented-K A operand (implicit 3x3 convolution, layout NT): A[m][k] = A[m*lda + k + (k / k_seg) * seg_jump]
   long seg_jump;   // = a_seg_stride - k_seg
+  int k_tap;       // > 0: tap-interleaved K order of the 3x3 convolution (see pxa_gemm_args): [k_tap/64 chunks][3 rows][3 taps][64]
+  long tap_s;      // = a_seg_stride (elements between kernel rows)
 };
 
 // ---- global -> registers (4 x 16 B per thread per operand tile), zero-filled out of bounds
@@ -449,8 +451,20 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_glds_kernel(GemmParams p) {
 
   const bf16_t* Ab = p.A;                              // SEG: A base of the segment the next DMA reads from
   int seg_left = SEG ? p.k_seg : 0;                    // ... and the k elements left in it (split-K is not combined with SEG)
+  int kx = 0, ky = 0;                                  // tap-interleaved order: the tap the next DMA reads
   auto seg_advance = [&]() {
-    if (SEG) { seg_left -= BK; if (seg_left == 0) { Ab += p.seg_jump; seg_left = p.k_seg; } }
+    if (SEG) {
+      if (p.k_tap) {                                   // Ab + 64 t = A + offset of k-tile t: correct the linear +64 at every tap change
+        long adj;
+        if (kx < 2) { adj = p.k_tap - BK; kx++; }                                      // next tap of the kernel row: + C
+        else if (ky < 2) { adj = p.tap_s - 2L * p.k_tap - BK; kx = 0; ky++; }          // next kernel row, tap 0
+        else { adj = -2L * p.tap_s - 2L * p.k_tap; kx = 0; ky = 0; }                    // next 64-channel chunk, first tap
+        Ab += adj;
+      } else {
+        seg_left -= BK;
+        if (seg_left == 0) { Ab += p.seg_jump; seg_left = p.k_seg; }
+      }
+    }
   };
   if (nk > 0) {
     dma_tile<A_KC, TBM, NW>(smem, Ab, p.lda, m0, p.M, kbeg, wave, lane);
@@ -753,12 +767,24 @@ __global__ __launch_bounds__(512) void gemm_pers_kernel(GemmParams p) {
     pp[i] += st[i];
   };
   int seg_left = 0;                                    // SEG: k elements left in the A segment the next first-half issue reads
+  int tap_kx = 0, tap_ky = 0, tap_half = 0;            // SEG, tap-interleaved order: position of the next first-half issue
   auto issue_lo = [&]() {
 #pragma unroll
     for (int i = 0; i < H1; i++) piece(i, s_lo);
     if (SEG) {                                         // pieces 0 and 1 are the A pieces of every SEG instantiation (no pairing)
-      seg_left -= BKT;
-      if (seg_left == 0) { pp[0] += p.seg_jump; pp[1] += p.seg_jump; seg_left = p.k_seg; }
+      if (p.k_tap) {                                   // tap-interleaved order: 64 channels = two k-units per tap
+        if (tap_half) {
+          long adj;
+          if (tap_kx < 2) { adj = p.k_tap - 64; tap_kx++; }
+          else if (tap_ky < 2) { adj = p.tap_s - 2L * p.k_tap - 64; tap_kx = 0; tap_ky++; }
+          else { adj = -2L * p.tap_s - 2L * p.k_tap; tap_kx = 0; tap_ky = 0; }
+          pp[0] += adj; pp[1] += adj;
+        }
+        tap_half ^= 1;
+      } else {
+        seg_left -= BKT;
+        if (seg_left == 0) { pp[0] += p.seg_jump; pp[1] += p.seg_jump; seg_left = p.k_seg; }
+      }
     }
     s_lo = (s_lo + 1) & 3;
   };
@@ -786,7 +812,7 @@ __global__ __launch_bounds__(512) void gemm_pers_kernel(GemmParams p) {
       dof[i] = (is_a ? 0 : (vq ? 32768 : 16384)) + pid * 1024;
     }
     s_lo = s_hi = 0;
-    if (SEG) seg_left = p.k_seg;
+    if (SEG) { seg_left = p.k_seg; tap_kx = tap_ky = tap_half = 0; }
     issue_lo(); issue_hi(); issue_lo(); issue_hi();
     if (nk_pf > 2) issue_lo();
   };
@@ -1188,6 +1214,9 @@ extern "C" int pxa_gemm(const pxa_gemm_args* a, hipStream_t stream) {
   p.act = a->act; p.accumulate = a->accumulate;
   p.tile_hint = 0;
   p.k_seg = a->k_seg; p.seg_jump = a->k_seg ? a->a_seg_stride - a->k_seg : 0;
+  p.k_tap = a->k_seg ? a->k_tap : 0; p.tap_s = a->a_seg_stride;
+  if (a->k_seg && a->k_tap)
+    PXA_CHECK(a->k_tap % BK == 0 && a->k_seg == 3 * a->k_tap && a->K == 3 * a->k_seg, "pxa_gemm: k_tap=%d needs k_seg = 3 k_tap, K = 9 k_tap, k_tap a multiple of %d", a->k_tap, BK);
   if (a->k_seg) {
     PXA_CHECK(a->layout == 0 && split == 1 && !a->colsum, "pxa_gemm: k_seg needs layout NT, no split-K, no colsum");
     PXA_CHECK(a->k_seg > 0 && a->k_seg % BK == 0 && a->K % a->k_seg == 0 && a->a_seg_stride % 8 == 0, "pxa_gemm: k_seg=%d must be a multiple of %d dividing K=%d (segment stride a multiple of 8)", a->k_seg, BK, a->K);

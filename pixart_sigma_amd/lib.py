@@ -25,7 +25,7 @@ class GemmArgs(C.Structure):
                 ("out_bf16", c_void_p), ("out2_bf16", c_void_p), ("ld_out", c_int),
                 ("out_f32", c_void_p), ("ld_f32", c_int), ("accumulate", c_int), ("split_k", c_int),
                 ("splitk_ws", c_void_p), ("splitk_ws_elems", c_long), ("colsum", c_void_p), ("colsum_stride", c_long),
-                ("k_seg", c_int), ("a_seg_stride", c_long)]
+                ("k_seg", c_int), ("a_seg_stride", c_long), ("k_tap", c_int)]
 
 
 class GridArg(C.Structure):

@@ -21,10 +21,10 @@ def _chk(t, dtype, name):
 
 
 def gemm(a, b, layout=NT, bias=None, act=ACT_NONE, aux=None, out=None, out2=None, out_f32=None, accumulate=False,
-         split_k=1, out_dtype=BF16, colsum=None, k_seg=0, a_seg_stride=0):
+         split_k=1, out_dtype=BF16, colsum=None, k_seg=0, a_seg_stride=0, k_tap=0):
     """C = op(A) op(B) (see include/pixart_hip.h).  a, b: 2-D bf16 (row stride arbitrary multiple of 8).
     Returns the bf16 output (or fp32 when out_dtype is float32 / out_f32 is given).
-    k_seg / a_seg_stride: segmented-K A operand (the implicit 3x3 convolution of the VAE kernel set)."""
+    k_seg / a_seg_stride / k_tap: segmented-K A operand (the implicit 3x3 convolution of the VAE kernel set)."""
     _chk(a, BF16, "A")
     _chk(b, BF16, "B")
     if layout == NT:
@@ -64,7 +64,7 @@ def gemm(a, b, layout=NT, bias=None, act=ACT_NONE, aux=None, out=None, out2=None
         assert out is not None and out2.stride(0) == out.stride(0)
         g.out2_bf16 = ptr(out2)
     g.accumulate, g.split_k = int(accumulate), split_k
-    g.k_seg, g.a_seg_stride = k_seg, a_seg_stride
+    g.k_seg, g.a_seg_stride, g.k_tap = k_seg, a_seg_stride, k_tap
     if colsum is not None:               # (PXA_COLSUM_SLOTS, stride) partial buffer view: row 0 of the slice to accumulate
         g.colsum, g.colsum_stride = ptr(colsum), colsum.stride(0)
     if accumulate and split_k != 1:       # split-K partial slabs: caller-owned workspace, cached per device (max 16 slabs)

@@ -207,8 +207,10 @@ class AutoencoderKL(nn.Module):
                 w = mod.weight.detach().to(dev, F32)
                 co, ci = w.shape[:2]
                 w2 = torch.zeros(_c8(co), 3, 3, _c8(ci), device=dev)
-                w2[:co, :, :, :ci] = w.permute(0, 2, 3, 1)      # [Cout][ky][kx][Cin]: k index = tap * Cin + c
-                P[id(mod)] = (w2.view(_c8(co), -1).to(BF16).contiguous(), self._bias(mod.bias, co, dev), co)
+                w2[:co, :, :, :ci] = w.permute(0, 2, 3, 1)      # [Cout][ky][kx][Cin]: k index = tap * Cin + c (patch-matrix order)
+                if mod.stride == (1, 1) and ci % 64 == 0:       # implicit GEMM: tap-interleaved K order [Cin/64][ky][kx][64]
+                    w2 = w2.view(_c8(co), 3, 3, ci // 64, 64).permute(0, 3, 1, 2, 4)
+                P[id(mod)] = (w2.reshape(_c8(co), -1).to(BF16).contiguous(), self._bias(mod.bias, co, dev), co)
             elif isinstance(mod, (nn.Conv2d, nn.Linear)):
                 w = mod.weight.detach().to(dev, F32).flatten(1)
                 co, ci = w.shape
@@ -261,7 +263,7 @@ class AutoencoderKL(nn.Module):
             a = buf.as_strided((B * ip, 9 * C), (C, 1))
             fused = (residual is not None and not out_f32 and residual.C == w.shape[0] and residual.row_pitch == rp and residual.img_pitch == ip
                      and residual.origin == W + 3 and (residual.B, residual.H, residual.W) == (B, H, W))
-            out = ops.gemm(a, w, ops.NT, bias=b, out_dtype=F32 if out_f32 else BF16, k_seg=3 * C, a_seg_stride=rp * C,
+            out = ops.gemm(a, w, ops.NT, bias=b, out_dtype=F32 if out_f32 else BF16, k_seg=3 * C, a_seg_stride=rp * C, k_tap=C,
                            act=ops.ACT_ADD_AUX if fused else ops.ACT_NONE, aux=residual.rows() if fused else None)
             if out_f32:
                 return out.view(B, H + 2, W + 2, -1)[:, 1:-1, 1:-1]

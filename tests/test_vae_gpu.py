@@ -62,10 +62,12 @@ def test_groupnorm_stats_and_apply(ops, B, C, H, W, groups):
 
 @pytest.mark.parametrize("B,C,Co,H,W", [(2, 64, 128, 9, 13), (1, 128, 8, 20, 20), (2, 256, 256, 16, 8), (1, 512, 512, 8, 8),
                                          (2, 128, 128, 30, 30), (1, 256, 512, 40, 24), (2, 512, 256, 24, 24), (3, 64, 384, 20, 31)])
-def test_implicit_conv3x3_is_conv2d(ops, B, C, Co, H, W):
+@pytest.mark.parametrize("interleave", [False, True])
+def test_implicit_conv3x3_is_conv2d(ops, B, C, Co, H, W, interleave):
     """The zero-bordered padded grid + segmented-K GEMM (k_seg = 3C, a_seg_stride = (W+2)C) == Conv2d(3, padding=1).
     Fewer than 1024 padded pixels: the 128x128 two-stage kernel; more (and Cout a multiple of 128): the persistent 256x256 kernel
-    (Cout 128: half-width items only; 384: full + half; 256 / 512: full)."""
+    (Cout 128: half-width items only; 384: full + half; 256 / 512: full).  interleave: K ordered [C/64][ky][kx][64] (k_tap = C),
+    the order the VAE uses (all nine reads of a pixel chunk close in time), instead of [ky][kx][C]."""
     g, x = to_grid(ops, rnd(B, C, H, W, seed=1))
     w = rnd(Co, C, 3, 3, scale=(9 * C) ** -0.5, seed=2).to(ops.BF16)
     bias = rnd(Co, seed=3)
@@ -73,15 +75,17 @@ def test_implicit_conv3x3_is_conv2d(ops, B, C, Co, H, W):
     ip, rp = (H + 2) * (W + 2), W + 2
     buf = torch.zeros((B * ip + 2 * (W + 3)) * C, dtype=ops.BF16, device="cuda")
     ops.vae_gn_apply(g, ops.Grid(buf, B, H, W, C, rp, ip, origin=(W + 3) + rp + 1))
-    wk = w.permute(0, 2, 3, 1).reshape(Co, 9 * C).contiguous()
+    wk = w.permute(0, 2, 3, 1)                                                                                # [Co][ky][kx][C]
+    wk = (wk.reshape(Co, 3, 3, C // 64, 64).permute(0, 3, 1, 2, 4) if interleave else wk).reshape(Co, 9 * C).contiguous()
     a = buf.as_strided((B * ip, 9 * C), (C, 1))
-    out = ops.gemm(a, wk, ops.NT, bias=bias, k_seg=3 * C, a_seg_stride=rp * C)
+    seg = dict(k_seg=3 * C, a_seg_stride=rp * C, k_tap=C if interleave else 0)
+    out = ops.gemm(a, wk, ops.NT, bias=bias, **seg)
     assert rel_l2(from_grid(ops.Grid(out, B, H, W, Co, rp, ip, origin=W + 3)), ref) < BF16_TOL
     res = rnd(B * ip, Co, seed=4).to(ops.BF16)                                                                 # residual in the output's own layout
-    out = ops.gemm(a, wk, ops.NT, bias=bias, k_seg=3 * C, a_seg_stride=rp * C, act=ops.ACT_ADD_AUX, aux=res)
+    out = ops.gemm(a, wk, ops.NT, bias=bias, act=ops.ACT_ADD_AUX, aux=res, **seg)
     want = ref + from_grid(ops.Grid(res, B, H, W, Co, rp, ip, origin=W + 3))
     assert rel_l2(from_grid(ops.Grid(out, B, H, W, Co, rp, ip, origin=W + 3)), want) < BF16_TOL
-    outf = ops.gemm(a, wk, ops.NT, bias=bias, out_dtype=torch.float32, k_seg=3 * C, a_seg_stride=rp * C)      # fp32 output flavour
+    outf = ops.gemm(a, wk, ops.NT, bias=bias, out_dtype=torch.float32, **seg)                                # fp32 output flavour
     assert rel_l2(outf.view(B, H + 2, W + 2, Co)[:, 1:-1, 1:-1].permute(0, 3, 1, 2), ref) < 2e-5
 
 
