@@ -127,6 +127,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-roofline", action="store_true")
     ap.add_argument("--grad-checkpoint", action="store_true")
+    ap.add_argument("--optimizer", choices=["adamw", "came"], default="adamw",
+                    help="adamw = the BASELINE config (configs/PixArt_xl2_internal.py); came = the CAMEWrapper of the Sigma configs")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -140,7 +142,7 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
 
     from pixart_sigma_amd import IDDPM, PixArtMS_XL_2
-    from pixart_sigma_amd.dp import FusedAdamW
+    from pixart_sigma_amd.dp import FusedAdamW, FusedCAME
     from pixart_sigma_amd.model.utils import set_grad_checkpoint
 
     lat = a.image_size // 8
@@ -156,7 +158,10 @@ def main():
     if a.grad_checkpoint:
         set_grad_checkpoint(model)
     model.prepare(dev)
-    opt = FusedAdamW(model, lr=2e-5, weight_decay=3e-2, eps=1e-10, max_grad_norm=0.01)
+    if a.optimizer == "came":
+        opt = FusedCAME(model, lr=2e-5, weight_decay=0.0, betas=(0.9, 0.999, 0.9999), eps=(1e-30, 1e-16), max_grad_norm=0.01)
+    else:
+        opt = FusedAdamW(model, lr=2e-5, weight_decay=3e-2, eps=1e-10, max_grad_norm=0.01)
     diff = IDDPM(str(1000), learn_sigma=True, pred_sigma=True, snr=False)
 
     g = torch.Generator(device="cpu").manual_seed(1234 + rank)
@@ -201,9 +206,9 @@ def main():
             "value": 1.0 / sec_per_step, "unit": "steps/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": sec_per_step * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": f"PixArt-Sigma-XL/2 {a.image_size}px training step (fwd+bwd+clip+AdamW), batch {B}/GPU, L=300 text tokens, "
+            "config": {"workload": f"PixArt-Sigma-XL/2 {a.image_size}px training step (fwd+bwd+clip+{'CAME' if a.optimizer == 'came' else 'AdamW'}), batch {B}/GPU, L=300 text tokens, "
                                    f"DP={world} RCCL all-reduce", "model": "PixArtMS_XL_2", "global_batch": B * world, "seq_len": N,
-                       "parallelism": f"dp{world}", "grad_checkpoint": bool(a.grad_checkpoint)},
+                       "parallelism": f"dp{world}", "grad_checkpoint": bool(a.grad_checkpoint), "optimizer": a.optimizer},
             "images_per_s": B * world / sec_per_step, "final_loss": loss_v,
             "step_tflops_per_gpu": flops_step / sec_per_step / 1e12,
         }
