@@ -78,3 +78,32 @@ def test_vae_fails_loudly_without_gpu():
         pytest.skip("GPU present")
     with pytest.raises(AssertionError):
         AutoencoderKL(block_out_channels=(128, 256), layers_per_block=1).decode(torch.zeros(1, 4, 4, 4))
+
+
+def test_conv_weight_packing_follows_the_abi_k_order():
+    """The B operand of the implicit convolution (include/pixart_hip.h, pxa_gemm_args.k_tap): K ordered [Cin/64][ky][kx][64] for
+    the stride-1 convolutions with Cin % 64 == 0; patch-matrix order [ky][kx][Cin (padded to 8)] for the stems and the stride-2 ones."""
+    vae = AutoencoderKL(block_out_channels=(128, 256), layers_per_block=1)
+    randomize_(vae, seed=1)
+    vae._prepare()                                             # pure tensor plumbing: runs on the CPU
+    conv = vae.decoder.up_blocks[0].resnets[0].conv1           # 256 -> 256, stride 1: tap-interleaved
+    w, b, co = vae._packed[id(conv)]
+    assert w.shape == (256, 9 * 256) and co == 256 and b.shape == (256,)
+    ref = conv.weight.detach()
+    for k in (0, 63, 64, 200, 575, 576, 1000, 2303):
+        cc, r = divmod(k, 576)
+        ky, r = divmod(r, 192)
+        kx, c = divmod(r, 64)
+        assert torch.equal(w[:, k].float(), ref[:, cc * 64 + c, ky, kx].to(w.dtype).float()), k
+    stem = vae.decoder.conv_in                                 # 4 -> 256: explicit patch matrix, channels padded to 8
+    w, b, co = vae._packed[id(stem)]
+    assert w.shape == (256, 72)
+    for k in (0, 3, 4, 8, 35, 71):
+        tap, c = divmod(k, 8)
+        want = stem.weight.detach()[:, c, tap // 3, tap % 3] if c < 4 else torch.zeros(256)
+        assert torch.equal(w[:, k].float(), want.to(w.dtype).float()), k
+    down = vae.encoder.down_blocks[0].downsamplers[0].conv     # stride 2: patch-matrix order
+    w, _, _ = vae._packed[id(down)]
+    assert torch.equal(w[:, 128 * 5 + 7].float(), down.weight.detach()[:, 7, 1, 2].to(w.dtype).float())
+    qkv = vae._packed[("qkv", id(vae.decoder.mid_block.attentions[0]))]
+    assert qkv[0].shape == (3 * 256, 256) and qkv[2] == 3 * 256
