@@ -24,3 +24,21 @@ def test_f16_operand_build_meets_1e3_forward_parity():
     assert res["operand"] == "f16"
     for name, e in res["cases"].items():
         assert e < (F16_SAMPLE_TOL if name.endswith(":sample") else F16_FWD_TOL), (name, e)
+
+
+F16_VAE_TOL = 4e-3        # measured 1.5e-3 ... 2.0e-3 (bf16 build: 1.2e-2 ... 1.7e-2); the reference runs this network in fp16
+
+
+@pytest.mark.gpu
+def test_f16_operand_build_vae_parity():
+    """The VAE under the fp16-operand build - the like-for-like comparison with the reference's `.to(torch.float16)` VAE."""
+    env = dict(os.environ, PXA_OPERAND_DTYPE="f16")
+    env.pop("PXA_LIB_PATH", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "vae_parity.py")], capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    res = json.loads(r.stdout.strip().splitlines()[-1])
+    print("\n", res)
+    assert res["operand"] == "f16"
+    for px in ("64px", "128px"):
+        for name, e in res[px].items():
+            assert e < F16_VAE_TOL, (px, name, e)

@@ -1,8 +1,10 @@
 """GPU parity of the VAE conv-stack kernel set (csrc/vae.hip + the segmented-K pxa_gemm) through the C ABI.
 Kernel level: against plain PyTorch fp32 references of the same op on the same bf16-rounded inputs (one bf16 rounding -> 4e-3).
 Model level: encode / decode of the product AutoencoderKL against oracle/vae_ref.py (fp32, CPU) with the same random weights.
-Tolerance, stated: every activation between layers is stored as bf16 (the reference runs this network in fp16 storage), so the
-end-to-end rel-L2 is bounded at 2e-2 for the ~30-layer decoder; parity is unpinned for this row (no reference vectors exist)."""
+Tolerance, stated: every activation between layers is stored as bf16 (the reference runs this network in fp16 storage); measured
+end-to-end rel-L2 of the ~30-layer decoder / encoder is 1.2e-2 ... 1.7e-2 with bf16 operands (deterministic for fixed seeds) and
+1.5e-3 ... 2.0e-3 with the fp16-operand build (tests/test_f16_parity_gpu.py, tools/vae_parity.py) -> bound 2.5e-2 here.  Parity is
+unpinned for this row (no reference vectors exist)."""
 import pytest
 import torch
 import torch.nn.functional as F
@@ -12,7 +14,7 @@ pytestmark = pytest.mark.gpu
 from conftest import rel_l2  # noqa: E402
 
 BF16_TOL = 4e-3
-MODEL_TOL = 2e-2
+MODEL_TOL = 2.5e-2
 
 
 @pytest.fixture(scope="module")
