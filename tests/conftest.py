@@ -15,6 +15,22 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "slow: long CPU test")
 
 
+def pytest_collection_modifyitems(config, items):
+    """gpu-marked tests skip (not fail) on a box without a GPU — the CPU tier runs `-m "not gpu"`, but a bare `pytest tests`
+    must stay green there too."""
+    try:
+        import torch
+        has_gpu = torch.cuda.is_available()
+    except Exception:      # noqa: BLE001
+        has_gpu = False
+    if has_gpu:
+        return
+    skip = pytest.mark.skip(reason="needs a GPU (MI355X)")
+    for it in items:
+        if "gpu" in it.keywords:
+            it.add_marker(skip)
+
+
 def rel_l2(a, b):
     a, b = a.double(), b.double()
     return ((a - b).norm() / b.norm().clamp_min(1e-30)).item()
