@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define PXA_ABI_VERSION 2
+#define PXA_ABI_VERSION 3
 /* Kernels that fuse a bias-gradient column sum add into one of PXA_COLSUM_SLOTS partial rows ([slot][stride] fp32, caller-zeroed),
  * chosen per sample / row tile, so no address sees thousands of atomics; pxa_colsum_reduce folds the partials into the gradient. */
 #define PXA_COLSUM_SLOTS 16
@@ -174,6 +174,19 @@ int pxa_clip_coef(const float* sumsq, float* out2, float max_norm, float inv_wor
 int pxa_adamw_step(float* p, const float* g, float* m, float* v, void* p_bf16, long n, float lr, float beta1, float beta2,
                    float eps, float weight_decay, int step, const float* gscale, hipStream_t stream);
 int pxa_cast_f32_bf16(const float* x, void* y_bf16, long n, hipStream_t stream);
+/* Loss-scaled (fp16-operand) training: the reference's mixed_precision='fp16' (configs/PixArt_xl2_internal.py:57) runs accelerate's
+ * torch.cuda.amp.GradScaler around loss.backward() / clip_grad_norm_ / optimizer.step() (train_scripts/train.py:180-184).  Here the
+ * same protocol lives on the device in a 5-float record `scaler`:
+ *   [0] loss scale  [1] clean steps since the last scale change  [2] found_inf of the current step  [3] optimizer steps applied
+ *   [4] steps skipped.
+ * pxa_clip_coef_scaled: norm = sqrt(sumsq) * inv_world / scale.  Finite: out2 = {clip coefficient * inv_world / scale, norm}, the
+ * tracker advances and the scale grows by growth_factor every growth_interval clean steps.  Inf / nan: out2[0] = 0, found_inf = 1,
+ * scale *= backoff_factor (GradScaler.update semantics).  pxa_adamw_step_scaled / pxa_came_step (args->scaler) do nothing when
+ * found_inf is set; AdamW takes its bias-correction step count from scaler[3].                                                */
+int pxa_clip_coef_scaled(const float* sumsq, float* out2, float max_norm, float inv_world, float* scaler, float growth_factor,
+                         float backoff_factor, int growth_interval, hipStream_t stream);
+int pxa_adamw_step_scaled(float* p, const float* g, float* m, float* v, void* p_bf16, long n, float lr, float beta1, float beta2,
+                          float eps, float weight_decay, const float* gscale, const float* scaler, hipStream_t stream);
 
 /* ---------------------------------------------------------------------------------------------- CAME optimizer
  * came_pytorch.CAME.step() (un-vendored dependency; the reference's CAMEWrapper subclasses it unchanged:
@@ -201,6 +214,7 @@ typedef struct {
   long n_cols_total, n_rm_total;
   double lr, beta1, beta2, beta3, eps0, eps1, clip_threshold, weight_decay;   /* doubles: 1 - beta is formed in fp64 like torch's alpha */
   const float* gscale;
+  const float* scaler;   /* optional loss-scaler record of pxa_clip_coef_scaled: the step is skipped when scaler[2] != 0 */
 } pxa_came_args;
 long pxa_came_scratch_elems(long n_cols_total, long n_rm_total, int n_tensors);
 int pxa_came_step(const pxa_came_args* args, hipStream_t stream);

@@ -38,6 +38,22 @@ CASES = {
                       dict(B=2, Hl=16, Wl=16, L=20, lens=[20, 7])),
     "train_d2_qknorm": (dict(depth=2, input_size=16, model_max_length=20, qk_norm=True), dict(B=2, Hl=16, Wl=16, L=20, lens=[20, 9])),
     "dpms_d2": (dict(depth=2, input_size=16, model_max_length=20), dict(B=2, Hl=16, Wl=16, L=20, lens=[20, 11])),
+    # ---- BASELINE.json configs[1..4] at their real token geometry, depth 2 (round 2) ----
+    # configs[2]: 1024px training shapes: N = 4096 tokens, L = 300, pe_interpolation 2 (forward and the full training step)
+    "fwd_1024_b2": (dict(depth=2, input_size=128, model_max_length=300, pe_interpolation=2.0), dict(B=2, Hl=128, Wl=128, L=300, lens=[300, 77])),
+    "train_1024_b2": (dict(depth=2, input_size=128, model_max_length=300, pe_interpolation=2.0), dict(B=2, Hl=128, Wl=128, L=300, lens=[300, 131])),
+    # configs[3]: 2K latent with KV compression (conv, x2) on one of the two blocks: N = 16384 -> N_kv = 4096 (scripts/inference.py:157-172,
+    # configs/pixart_sigma_config/PixArt_sigma_xl2_img2K_internalms_kvcompress.py:44-49)
+    "fwd_2k_kv": (dict(depth=2, input_size=256, model_max_length=300, pe_interpolation=4.0, kv_sampling="conv", kv_scale_factor=2, kv_layers=(1,)),
+                  dict(B=1, Hl=256, Wl=256, L=300, lens=[211])),
+    # configs[1] / configs[4]: 512px, N = 1024; L = 300 (Sigma) and L = 120 (alpha-DMD), multi-aspect latent for the second
+    "fwd_512_l300": (dict(depth=2, input_size=64, model_max_length=300, pe_interpolation=1.0), dict(B=2, Hl=64, Wl=64, L=300, lens=[300, 12])),
+    "fwd_512_l120": (dict(depth=2, input_size=64, model_max_length=120, pe_interpolation=1.0), dict(B=3, Hl=48, Wl=80, L=120, lens=[120, 120, 33])),
+    # alpha-1024 micro-conditioning (SizeEmbedder on img_hw / aspect_ratio, PixArtMS.py:187-191): forward and a training step
+    "fwd_d2_micro": (dict(depth=2, input_size=16, model_max_length=20, micro_condition=True), dict(B=2, Hl=16, Wl=24, L=20, lens=[20, 7])),
+    "train_d2_micro": (dict(depth=2, input_size=16, model_max_length=20, micro_condition=True), dict(B=2, Hl=16, Wl=16, L=20, lens=[20, 9])),
+    # forward_with_cfg (PixArtMS.py:221-234): batch = [cond half ; uncond half] over one latent half, guidance on 3 channels
+    "cfg_d2": (dict(depth=2, input_size=16, model_max_length=20), dict(B=4, Hl=16, Wl=16, L=20, lens=[20, 9, 20, 20])),
     # BASELINE.json configs[0]: XL/2 256px, batch 2, 2 DPM-Solver steps, CFG 4.5, random-init, CPU
     "cfg1_xl2_256": (dict(depth=28, input_size=32, model_max_length=300, pe_interpolation=0.5), dict(B=2, Hl=32, Wl=32, L=300, lens=[300, 77])),
 }
@@ -51,7 +67,7 @@ def build_reference(cfg, sd):
         kvc = {"sampling": cfg.kv_sampling, "scale_factor": cfg.kv_scale_factor, "kv_compress_layer": list(cfg.kv_layers)}
     m = PixArtMS(depth=cfg.depth, hidden_size=cfg.hidden_size, patch_size=cfg.patch_size, num_heads=cfg.num_heads,
                  input_size=cfg.input_size, pe_interpolation=cfg.pe_interpolation, model_max_length=cfg.model_max_length,
-                 class_dropout_prob=0.0, qk_norm=cfg.qk_norm, kv_compress_config=kvc)
+                 class_dropout_prob=0.0, qk_norm=cfg.qk_norm, kv_compress_config=kvc, micro_condition=cfg.micro_condition)
     missing, unexpected = m.load_state_dict(sd, strict=False)
     assert [k for k in missing if k != "pos_embed"] == [] and unexpected == [], (missing, unexpected)
     return m
@@ -65,10 +81,20 @@ def gen_case(name):
     m = build_reference(cfg, sd).eval()
     hw = torch.tensor([[inp["x"].shape[-2] * 8.0, inp["x"].shape[-1] * 8.0]] * inp["x"].shape[0])
     data_info = {"img_hw": hw, "aspect_ratio": torch.ones(inp["x"].shape[0], 1)}
+    if cfg.micro_condition:       # per-sample original sizes / aspect ratios that differ, so a swapped or broadcast embedding shows
+        Bn = inp["x"].shape[0]
+        data_info = {"img_hw": torch.tensor([[1024.0, 768.0], [512.0, 1536.0], [640.0, 640.0], [2048.0, 1024.0]])[:Bn],
+                     "aspect_ratio": torch.tensor([[1.33], [0.33], [1.0], [2.0]])[:Bn]}
     mask = inp["mask"] if ikw.get("lens") is not None else None
     out = {"cfg": ckw, "inputs": ikw, "weights_seed": 0, "inputs_seed": 1}
+    if cfg.micro_condition:
+        out["data_info"] = data_info
     t0 = time.time()
-    if name.startswith("fwd"):
+    if name.startswith("cfg_"):
+        with torch.no_grad():
+            out["cfg_scale"] = 4.5
+            out["y"] = m.forward_with_cfg(inp["x"], inp["t"], inp["y"], 4.5, data_info, mask=mask).clone()
+    elif name.startswith("fwd"):
         with torch.no_grad():
             out["y"] = m(inp["x"], inp["t"], inp["y"], mask=mask, data_info=data_info).clone()
     elif name.startswith("train"):
@@ -85,6 +111,9 @@ def gen_case(name):
         for k, p in m.named_parameters():
             g = p.grad
             grads[k] = {"norm": g.norm().item(), "head": g.flatten()[:16].clone(), "sum": g.double().sum().item()}
+            if g.numel() > 8192:           # evenly strided sample of the big tensors (every row / column region is hit)
+                grads[k]["stride"] = g.numel() // 4096
+                grads[k]["sample"] = g.flatten()[:: g.numel() // 4096].clone()
             if g.numel() <= 8192:
                 grads[k]["full"] = g.clone()
         out["grads"] = grads

@@ -128,13 +128,19 @@ def memory_efficient_attention(query, key, value, attn_bias=None, p=0.0, scale=N
     q = query.permute(0, 2, 1, 3).float()
     k = key.permute(0, 2, 1, 3).float()
     v = value.permute(0, 2, 1, 3).float()
-    s = (q @ k.transpose(-1, -2)) * scale
+    bias = None
     if attn_bias is not None:
-        if isinstance(attn_bias, BlockDiagonalMask):
-            s = s + attn_bias.materialize(s.dtype, s.device)
-        else:
-            s = s + attn_bias.reshape(B, H, M, -1).float()
-    o = s.softmax(dim=-1) @ v
+        bias = attn_bias.materialize(torch.float32, q.device) if isinstance(attn_bias, BlockDiagonalMask) else attn_bias.reshape(B, H, M, -1).float()
+    # the same arithmetic head group by head group when the (B,H,M,N) score tensor would not fit comfortably in host memory
+    # (2K latents: 16 x 16384 x 16384 fp32 = 17 GB per copy); per-head results are independent, so chunking changes nothing
+    step = H if B * H * M * k.shape[2] <= (1 << 31) else max(1, (1 << 31) // (B * M * k.shape[2]))
+    outs = []
+    for h0 in range(0, H, step):
+        s = (q[:, h0:h0 + step] @ k[:, h0:h0 + step].transpose(-1, -2)) * scale
+        if bias is not None:
+            s = s + (bias if bias.dim() == 2 else bias[:, h0:h0 + step])
+        outs.append(s.softmax(dim=-1) @ v[:, h0:h0 + step])
+    o = outs[0] if len(outs) == 1 else torch.cat(outs, dim=1)
     return o.permute(0, 2, 1, 3).contiguous().to(query.dtype)
 
 

@@ -29,6 +29,10 @@ def param_shapes(cfg, caption_channels=4096):
         "final_layer.scale_shift_table": (2, D),
         "final_layer.linear.weight": (p * p * cfg.out_channels, D), "final_layer.linear.bias": (p * p * cfg.out_channels,),
     }
+    if getattr(cfg, "micro_condition", False):               # SizeEmbedder(hidden_size // 3) x 2 (PixArtMS.py:141-143)
+        d3 = D // 3
+        for e in ("csize_embedder", "ar_embedder"):
+            s.update({e + ".mlp.0.weight": (d3, 256), e + ".mlp.0.bias": (d3,), e + ".mlp.2.weight": (d3, d3), e + ".mlp.2.bias": (d3,)})
     for i in range(cfg.depth):
         b = f"blocks.{i}."
         s.update({
@@ -69,7 +73,7 @@ def make_state_dict(cfg, seed=0, dtype=torch.float32):
             v = n(0.05)
         elif k.endswith(".bias"):
             v = n(0.02)
-        elif any(t in k for t in ("t_embedder", "t_block", "y_proj", "cross_attn.proj", "final_layer.linear")):
+        elif any(t in k for t in ("t_embedder", "csize_embedder", "ar_embedder", "t_block", "y_proj", "cross_attn.proj", "final_layer.linear")):
             v = n(0.02)
         else:  # xavier-uniform on the (out, fan_in) matrix view
             fan_out, fan_in = shp[0], int(torch.tensor(shp[1:]).prod())

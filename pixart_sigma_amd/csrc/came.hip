@@ -30,6 +30,7 @@ struct CameParams {
   const float* col_inv_r;
   float lr, b1, b2, b3, omb1, omb2, omb3, eps0, eps1, clip, decay;   // omb = 1 - beta and decay = 1 - lr * wd, formed in fp64 on the host
   const float* gscale;
+  const float* scaler;     // optional loss-scaler record (optim.hip): [2] != 0 -> the whole step is skipped
 };
 
 constexpr int MAXC = 256 * 18;                        // widest row whose column partials are combined in registers / LDS
@@ -156,6 +157,7 @@ template <int PASS>   // 0 = A, 2 = C, 3 = D, 5 = F
 __global__ __launch_bounds__(256) void came_tile_kernel(CameParams a) {
   __shared__ float colsum[MAXC];
   __shared__ float red[4];
+  if (a.scaler && a.scaler[2] != 0.f) return;          // loss-scaled training: inf/nan in the gradients -> the step is skipped
   const pxa_came_tile tile = a.tiles[blockIdx.x];
   const pxa_came_tensor T = a.tensors[tile.tensor];
   const float gs = a.gscale ? *a.gscale : 1.f;
@@ -191,7 +193,9 @@ __global__ __launch_bounds__(256) void came_tile_kernel(CameParams a) {
   else came_rows<PASS, 0>(a, T, tile, tile.tensor, gs, colsum, red);
 }
 
-__global__ __launch_bounds__(256) void came_col_kernel(float* __restrict__ state, const float* __restrict__ sums, const float* __restrict__ inv_r, long n, float beta, float omb) {
+__global__ __launch_bounds__(256) void came_col_kernel(float* __restrict__ state, const float* __restrict__ sums, const float* __restrict__ inv_r, long n, float beta, float omb,
+                                                       const float* __restrict__ scaler) {
+  if (scaler && scaler[2] != 0.f) return;
   const long i = blockIdx.x * 256L + threadIdx.x;
   if (i < n) state[i] = beta * state[i] + omb * (sums[i] * inv_r[i]);
 }
@@ -213,14 +217,14 @@ extern "C" int pxa_came_step(const pxa_came_args* a, hipStream_t stream) {
   k.lr = (float)a->lr; k.b1 = (float)a->beta1; k.b2 = (float)a->beta2; k.b3 = (float)a->beta3;
   k.omb1 = (float)(1.0 - a->beta1); k.omb2 = (float)(1.0 - a->beta2); k.omb3 = (float)(1.0 - a->beta3);
   k.eps0 = (float)a->eps0; k.eps1 = (float)a->eps1; k.clip = (float)a->clip_threshold; k.decay = (float)(1.0 - a->lr * a->weight_decay);
-  k.gscale = a->gscale;
+  k.gscale = a->gscale; k.scaler = a->scaler;
   hipError_t e = hipMemsetAsync(a->scratch, 0, sizeof(float) * pxa_came_scratch_elems(a->n_cols_total, a->n_rm_total, a->n_tensors), stream);
   PXA_CHECK(e == hipSuccess, "pxa_came_step: memset failed: %s", hipGetErrorString(e));
   const dim3 grid(a->n_tiles), blk(256), cgrid((unsigned)((a->n_cols_total + 255) / 256));
   hipLaunchKernelGGL(came_tile_kernel<0>, grid, blk, 0, stream, k);
   PXA_LAUNCH_CHECK();
   if (a->n_cols_total) {
-    hipLaunchKernelGGL(came_col_kernel, cgrid, blk, 0, stream, k.sq_col, k.col_sum1, k.col_inv_r, a->n_cols_total, k.b2, k.omb2);
+    hipLaunchKernelGGL(came_col_kernel, cgrid, blk, 0, stream, k.sq_col, k.col_sum1, k.col_inv_r, a->n_cols_total, k.b2, k.omb2, k.scaler);
     PXA_LAUNCH_CHECK();
     hipLaunchKernelGGL(came_tile_kernel<2>, grid, blk, 0, stream, k);
     PXA_LAUNCH_CHECK();
@@ -228,7 +232,7 @@ extern "C" int pxa_came_step(const pxa_came_args* a, hipStream_t stream) {
   hipLaunchKernelGGL(came_tile_kernel<3>, grid, blk, 0, stream, k);
   PXA_LAUNCH_CHECK();
   if (a->n_cols_total) {
-    hipLaunchKernelGGL(came_col_kernel, cgrid, blk, 0, stream, k.res_col, k.col_sum2, k.col_inv_r, a->n_cols_total, k.b3, k.omb3);
+    hipLaunchKernelGGL(came_col_kernel, cgrid, blk, 0, stream, k.res_col, k.col_sum2, k.col_inv_r, a->n_cols_total, k.b3, k.omb3, k.scaler);
     PXA_LAUNCH_CHECK();
     hipLaunchKernelGGL(came_tile_kernel<5>, grid, blk, 0, stream, k);
     PXA_LAUNCH_CHECK();

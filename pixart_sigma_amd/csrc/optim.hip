@@ -4,6 +4,10 @@
 //   adamw_step   : torch.optim.AdamW update (configs/PixArt_xl2_internal.py:48: lr, weight_decay=3e-2, eps=1e-10) over the flat
 //                  fp32 master weights, fused with the bf16 shadow-weight refresh the MFMA GEMMs read
 //   cast         : fp32 -> bf16
+// fp16-operand training (the reference's own mixed precision: configs/PixArt_xl2_internal.py:57 mixed_precision='fp16' ->
+// accelerate's GradScaler around train_scripts/train.py:180-184): the loss is multiplied by a dynamic scale before backward; the
+// `_scaled` entry points fold 1/scale into the clip coefficient, detect inf/nan through the norm itself, skip the update and keep
+// torch.cuda.amp.GradScaler's growth/backoff bookkeeping in a 5-float device record - still no host synchronisation in the step.
 #include "common.h"
 #include "../../include/pixart_hip.h"
 
@@ -34,9 +38,35 @@ __global__ void clip_coef_kernel(const float* __restrict__ sumsq, float* __restr
   out[1] = norm;              // total norm of the averaged gradient (what clip_grad_norm_ returns)
 }
 
+// scaler record: [0] loss scale, [1] growth tracker (clean steps since the last change), [2] found_inf of this step (0/1),
+//                [3] number of optimizer steps actually applied, [4] number of skipped steps
+__global__ void clip_coef_scaled_kernel(const float* __restrict__ sumsq, float* __restrict__ out, float max_norm, float inv_world,
+                                        float* __restrict__ sc, float growth, float backoff, float interval) {
+  const float scale = sc[0];
+  const float norm = sqrtf(*sumsq) * inv_world / scale;           // norm of the averaged, UNSCALED gradient
+  if (!(fabsf(norm) <= 3.0e38f)) {                                 // inf or nan anywhere in the gradient buffer -> skip this step
+    out[0] = 0.f; out[1] = norm;
+    sc[0] = scale * backoff; sc[1] = 0.f; sc[2] = 1.f; sc[4] += 1.f;
+    return;
+  }
+  float coef = max_norm > 0.f ? max_norm / (norm + 1e-6f) : 1.f;
+  coef = coef > 1.f ? 1.f : coef;
+  out[0] = coef * inv_world / scale;
+  out[1] = norm;
+  float tr = sc[1] + 1.f;
+  if (tr >= interval) { sc[0] = scale * growth; tr = 0.f; }
+  sc[1] = tr; sc[2] = 0.f; sc[3] += 1.f;
+}
+
 __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
                                                     bf16_t* __restrict__ pb, long n, float lr, float b1, float b2, float eps, float wd,
-                                                    float bc1, float bc2_sqrt, const float* __restrict__ gscale) {
+                                                    float bc1, float bc2_sqrt, const float* __restrict__ gscale, const float* __restrict__ scaler) {
+  if (scaler) {                                                    // loss-scaled step: skip on overflow, bias correction from the applied-step count
+    if (scaler[2] != 0.f) return;
+    const float t = scaler[3];
+    bc1 = 1.f - powf(b1, t);
+    bc2_sqrt = sqrtf(1.f - powf(b2, t));
+  }
   const float gs = gscale ? gscale[0] : 1.f;
   const long n4 = n / 4;
   for (long i = blockIdx.x * 256L + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
@@ -89,7 +119,24 @@ extern "C" int pxa_adamw_step(float* p, const float* g, float* m, float* v, void
   PXA_CHECK(p && g && m && v && n > 0 && n % 4 == 0 && step >= 1, "pxa_adamw_step: bad args (n must be a multiple of 4)");
   const float bc1 = 1.f - powf(beta1, (float)step), bc2 = 1.f - powf(beta2, (float)step);
   hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n / 4)), dim3(256), 0, stream, p, g, m, v, (bf16_t*)p_bf16, n, lr, beta1, beta2, eps,
-                     weight_decay, bc1, sqrtf(bc2), gscale);
+                     weight_decay, bc1, sqrtf(bc2), gscale, (const float*)nullptr);
+  PXA_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int pxa_clip_coef_scaled(const float* sumsq, float* out2, float max_norm, float inv_world, float* scaler, float growth_factor,
+                                    float backoff_factor, int growth_interval, hipStream_t stream) {
+  PXA_CHECK(sumsq && out2 && scaler, "pxa_clip_coef_scaled: null pointer");
+  PXA_CHECK(growth_factor >= 1.f && backoff_factor > 0.f && backoff_factor <= 1.f && growth_interval > 0, "pxa_clip_coef_scaled: bad scaler constants");
+  hipLaunchKernelGGL(clip_coef_scaled_kernel, dim3(1), dim3(1), 0, stream, sumsq, out2, max_norm, inv_world, scaler, growth_factor, backoff_factor,
+                     (float)growth_interval);
+  PXA_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int pxa_adamw_step_scaled(float* p, const float* g, float* m, float* v, void* p_bf16, long n, float lr, float beta1, float beta2,
+                                     float eps, float weight_decay, const float* gscale, const float* scaler, hipStream_t stream) {
+  PXA_CHECK(p && g && m && v && gscale && scaler && n > 0 && n % 4 == 0, "pxa_adamw_step_scaled: bad args (n must be a multiple of 4)");
+  hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n / 4)), dim3(256), 0, stream, p, g, m, v, (bf16_t*)p_bf16, n, lr, beta1, beta2, eps,
+                     weight_decay, 1.f, 1.f, gscale, scaler);
   PXA_LAUNCH_CHECK();
   return 0;
 }

@@ -17,42 +17,123 @@ import torch.distributed as dist
 
 class GradReducer:
     """Bucketed, overlapped gradient all-reduce over the flat gradient buffer.  Backend-agnostic (nccl on GPUs, gloo in the
-    CPU tests)."""
+    CPU tests).
 
-    def __init__(self, store, group=None):
+    Gradient accumulation (the reference's `accelerator.accumulate(model)` / gradient_accumulation_steps, train.py:170,486): wrap the
+    non-final micro-steps in `no_sync()` - the engine's hooks are then ignored, gradients keep accumulating locally in the flat
+    buffer, and the buckets are reduced from the hooks of the LAST backward (or all of them in finish()).  A hook that fires for a
+    bucket already in flight in the same step would add local gradients on top of a reduced buffer: that is an error, not a no-op.
+
+    bucket_dtype=torch.bfloat16 (1.22 GB instead of 2.44 GB per step on the wire): a bucket is cast into a bf16
+    staging buffer, reduced there, and written back to the fp32 gradients in finish() (staging = one extra copy of the gradients
+    in bf16, 1.22 GB of 288 GB)."""
+
+    def __init__(self, store, group=None, bucket_dtype=None):
         self.store = store
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+        self.bucket_dtype = bucket_dtype
+        self.stage = torch.empty(store.total, dtype=bucket_dtype, device=store.device) if bucket_dtype not in (None, torch.float32) and self.world > 1 else None
         self.pending = []
-        self.launched = set()
+        self.launched = []          # bucket names in launch order (the order every rank must agree on)
+        self._sync = True
+
+    class _NoSync:
+        def __init__(self, r):
+            self.r = r
+
+        def __enter__(self):
+            self.prev, self.r._sync = self.r._sync, False
+
+        def __exit__(self, *exc):
+            self.r._sync = self.prev
+
+    def no_sync(self):
+        """Context manager for the non-final micro-steps of gradient accumulation (DDP.no_sync semantics)."""
+        return self._NoSync(self)
 
     def on_group_ready(self, name):
-        """Engine hook: gradients of parameter group `name` are final for this step."""
-        if self.world == 1 or name not in self.store.groups or name in self.launched:
+        """Engine hook: gradients of parameter group `name` are final for this backward."""
+        if self.world == 1 or not self._sync or name not in self.store.groups:
             return
+        if name in self.launched:
+            raise RuntimeError(f"gradient bucket {name!r} was completed twice before optimizer.step(): wrap the non-final micro-steps "
+                               "of gradient accumulation in reducer.no_sync()")
         s, e = self.store.groups[name]
-        self.launched.add(name)
-        self.pending.append(dist.all_reduce(self.store.grad[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        self.launched.append(name)
+        if self.stage is not None:
+            buf = self.stage[s:e]
+            buf.copy_(self.store.grad[s:e])
+        else:
+            buf = self.store.grad[s:e]
+        self.pending.append((dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True), s, e))
 
     def finish(self):
         """Reduce whatever was not launched from hooks (the 'cond' group, or everything if hooks are unused) and wait."""
         if self.world > 1:
+            launched = set(self.launched)
             for name in self.store.groups:
-                self.on_group_ready(name)
-            for w in self.pending:
+                if name not in launched:
+                    self.on_group_ready(name)
+            for w, s, e in self.pending:
                 w.wait()
-        self.pending, self.launched = [], set()
+                if self.stage is not None:
+                    self.store.grad[s:e].copy_(self.stage[s:e])
+        self.pending, self.launched = [], []
         return 1.0 / self.world     # multiplier that turns the summed gradient into the DDP average
+
+
+class LossScaler:
+    """Dynamic loss scaling for fp16-operand training - torch.cuda.amp.GradScaler's protocol (what accelerate runs for the reference's
+    mixed_precision='fp16', configs/PixArt_xl2_internal.py:57, train_scripts/train.py:180-184) kept entirely on the device:
+
+        loss = scaler.scale(terms['loss'].mean());  loss.backward();  opt.step()          # opt built with scaler=...
+
+    `scale()` multiplies by the current device-side scale; the fused optimizers fold 1/scale into the clip coefficient, skip the update
+    when the gradient norm is inf/nan and apply GradScaler.update()'s growth / backoff in the same tiny kernel (pxa_clip_coef_scaled).
+    Nothing synchronises with the host; `found_inf`, `value`, `skipped` read the record back on demand (logging only)."""
+
+    def __init__(self, device, init_scale=65536.0, growth_factor=2.0, backoff_factor=0.5, growth_interval=2000):
+        self.state = torch.tensor([init_scale, 0.0, 0.0, 0.0, 0.0], dtype=torch.float32, device=device)
+        self.growth_factor, self.backoff_factor, self.growth_interval = growth_factor, backoff_factor, growth_interval
+
+    def scale(self, loss):
+        return loss * self.state[0]
+
+    @property
+    def value(self):
+        return float(self.state[0].item())
+
+    @property
+    def found_inf(self):
+        return bool(self.state[2].item() != 0)
+
+    @property
+    def steps_applied(self):
+        return int(self.state[3].item())
+
+    @property
+    def steps_skipped(self):
+        return int(self.state[4].item())
+
+    def state_dict(self):
+        return {"state": self.state.clone(), "growth_factor": self.growth_factor, "backoff_factor": self.backoff_factor,
+                "growth_interval": self.growth_interval}
+
+    def load_state_dict(self, sd):
+        self.state.copy_(sd["state"])
+        self.growth_factor, self.backoff_factor, self.growth_interval = sd["growth_factor"], sd["backoff_factor"], sd["growth_interval"]
 
 
 class FusedAdamW:
     """torch.optim.AdamW semantics (configs/PixArt_xl2_internal.py:48) + clip_grad_norm_ (train.py:182) on the flat buffers,
     as HIP kernels.  step() never synchronises with the host; the gradient norm stays on the device (`.last_norm`)."""
 
-    def __init__(self, model, lr=2e-5, betas=(0.9, 0.999), eps=1e-10, weight_decay=3e-2, max_grad_norm=0.01, reducer=None):
+    def __init__(self, model, lr=2e-5, betas=(0.9, 0.999), eps=1e-10, weight_decay=3e-2, max_grad_norm=0.01, reducer=None, scaler=None):
         assert model._store is not None, "call model.prepare(device) (or run one forward) before building the optimizer"
         self.model, self.store = model, model._store
         self.lr, self.betas, self.eps, self.wd, self.max_norm = lr, betas, eps, weight_decay, max_grad_norm
+        self.scaler = scaler
         dev = self.store.device
         self.m = torch.zeros_like(self.store.master)
         self.v = torch.zeros_like(self.store.master)
@@ -75,11 +156,25 @@ class FusedAdamW:
         self.store.attach_grads()            # adopt gradients autograd may have allocated outside the flat buffer
         inv_world = self.reducer.finish()
         self.t += 1
+        self._clip(inv_world)
+        if self.scaler is not None:       # loss-scaled step: skipped on inf/nan, bias correction from the device-side applied-step count
+            ops.adamw_step_scaled(self.store.master, self.store.grad, self.m, self.v, self.store.shadow, self.lr, self.betas[0], self.betas[1],
+                                  self.eps, self.wd, self.coef, self.scaler.state)
+        else:
+            ops.adamw_step(self.store.master, self.store.grad, self.m, self.v, self.store.shadow, self.lr, self.betas[0], self.betas[1],
+                           self.eps, self.wd, self.t, gscale=self.coef)
+
+    def _clip(self, inv_world):
+        """sumsq -> device-side clip coefficient (x 1/world, x 1/loss-scale) in self.coef = [multiplier, total_norm]."""
+        from . import ops
         self.sumsq.zero_()
         ops.sumsq(self.store.grad, self.sumsq)
-        ops.clip_coef(self.sumsq, self.coef, self.max_norm if self.max_norm else 0.0, inv_world)
-        ops.adamw_step(self.store.master, self.store.grad, self.m, self.v, self.store.shadow, self.lr, self.betas[0], self.betas[1],
-                       self.eps, self.wd, self.t, gscale=self.coef)
+        mx = self.max_norm if self.max_norm else 0.0
+        if self.scaler is not None:
+            sc = self.scaler
+            ops.clip_coef_scaled(self.sumsq, self.coef, mx, inv_world, sc.state, sc.growth_factor, sc.backoff_factor, sc.growth_interval)
+        else:
+            ops.clip_coef(self.sumsq, self.coef, mx, inv_world)
 
     def state_dict(self):
         return {"m": self.m, "v": self.v, "t": self.t, "lr": self.lr}
@@ -125,12 +220,13 @@ class FusedCAME(FusedAdamW):
     TILE_ELEMS = 262144      # per workgroup: every tile ends in C same-address atomics on the column partials, so tiles are large
 
     def __init__(self, model, lr=2e-5, betas=(0.9, 0.999, 0.9999), eps=(1e-30, 1e-16), clip_threshold=1.0, weight_decay=0.0,
-                 max_grad_norm=0.01, reducer=None):
+                 max_grad_norm=0.01, reducer=None, scaler=None):
         from .lib import CameTensor, CameTile
         import ctypes as C
         assert model._store is not None, "call model.prepare(device) (or run one forward) before building the optimizer"
         self.model, self.store = model, model._store
         self.lr, self.betas, self.eps, self.clip, self.wd, self.max_norm = lr, betas, eps, clip_threshold, weight_decay, max_grad_norm
+        self.scaler = scaler
         st, dev = self.store, self.store.device
         tb = came_tables(st.names, st.offset, st.shape, st.numel, self.TILE_ELEMS)
         self.layout = tb["layout"]                        # name -> dict(kind, offsets): for state_dict / tests
@@ -164,9 +260,7 @@ class FusedCAME(FusedAdamW):
         self.store.attach_grads()
         inv_world = self.reducer.finish()
         self.t += 1
-        self.sumsq.zero_()
-        ops.sumsq(self.store.grad, self.sumsq)
-        ops.clip_coef(self.sumsq, self.coef, self.max_norm if self.max_norm else 0.0, inv_world)
+        self._clip(inv_world)
         a = CameArgs()
         a.p, a.g, a.exp_avg, a.p_bf16 = ptr(self.store.master), ptr(self.store.grad), ptr(self.m), ptr(self.store.shadow)
         a.sq_row, a.sq_col, a.res_row, a.res_col, a.nf_sq = ptr(self.sq_row), ptr(self.sq_col), ptr(self.res_row), ptr(self.res_col), ptr(self.nf_sq)
@@ -175,6 +269,7 @@ class FusedCAME(FusedAdamW):
         a.lr, a.beta1, a.beta2, a.beta3 = self.lr, self.betas[0], self.betas[1], self.betas[2]
         a.eps0, a.eps1, a.clip_threshold, a.weight_decay = self.eps[0], self.eps[1], self.clip, self.wd
         a.gscale = ptr(self.coef)
+        a.scaler = ptr(self.scaler.state) if self.scaler is not None else None
         call("pxa_came_step", a)                        # refreshes the bf16 shadow itself (no parameter version is bumped)
 
     def state_dict(self):

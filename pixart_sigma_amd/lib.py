@@ -13,7 +13,7 @@ OPERAND = os.environ.get("PXA_OPERAND_DTYPE", "bf16").lower()
 assert OPERAND in ("bf16", "f16"), f"PXA_OPERAND_DTYPE must be bf16 or f16, got {OPERAND!r}"
 OPERAND_DTYPE = torch.float16 if OPERAND == "f16" else torch.bfloat16
 LIB_PATH = os.environ.get("PXA_LIB_PATH") or os.path.join(_HERE, "libpixart_hip_f16.so" if OPERAND == "f16" else "libpixart_hip.so")   # env override: A/B kernel builds
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 c_void_p, c_int, c_long, c_float = C.c_void_p, C.c_int, C.c_long, C.c_float
 
@@ -49,7 +49,7 @@ class CameArgs(C.Structure):
                 ("scratch", c_void_p), ("tensors", c_void_p), ("n_tensors", c_int), ("tiles", c_void_p), ("n_tiles", c_int),
                 ("col_inv_r", c_void_p), ("n_cols_total", c_long), ("n_rm_total", c_long),
                 ("lr", C.c_double), ("beta1", C.c_double), ("beta2", C.c_double), ("beta3", C.c_double), ("eps0", C.c_double), ("eps1", C.c_double),
-                ("clip_threshold", C.c_double), ("weight_decay", C.c_double), ("gscale", c_void_p)]
+                ("clip_threshold", C.c_double), ("weight_decay", C.c_double), ("gscale", c_void_p), ("scaler", c_void_p)]
 
 
 class AttnArgs(C.Structure):
@@ -92,6 +92,8 @@ SIGNATURES = {
     "pxa_clip_coef": [_P, _P, _F, _F, _P],
     "pxa_adamw_step": [_P, _P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _I, _P, _P],
     "pxa_cast_f32_bf16": [_P, _P, _L, _P],
+    "pxa_clip_coef_scaled": [_P, _P, _F, _F, _P, _F, _F, _I, _P],
+    "pxa_adamw_step_scaled": [_P, _P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _P, _P, _P],
     "pxa_came_step": [C.POINTER(CameArgs), _P],
     "pxa_vae_gn_stats": [_G, _I, _F, _P, _P, _P, _P],
     "pxa_vae_gn_apply": [_G, _P, _P, _P, _P, _I, _I, _I, _G, _P],

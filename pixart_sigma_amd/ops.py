@@ -229,6 +229,15 @@ def clip_coef(sumsq_t, out2, max_norm, inv_world=1.0):
     call("pxa_clip_coef", ptr(sumsq_t), ptr(out2), float(max_norm), float(inv_world))
 
 
+def clip_coef_scaled(sumsq_t, out2, max_norm, inv_world, scaler_state, growth_factor, backoff_factor, growth_interval):
+    call("pxa_clip_coef_scaled", ptr(sumsq_t), ptr(out2), float(max_norm), float(inv_world), ptr(scaler_state), float(growth_factor),
+         float(backoff_factor), int(growth_interval))
+
+
+def adamw_step_scaled(p, g, m, v, p_bf16, lr, beta1, beta2, eps, weight_decay, gscale, scaler_state):
+    call("pxa_adamw_step_scaled", ptr(p), ptr(g), ptr(m), ptr(v), ptr(p_bf16), p.numel(), lr, beta1, beta2, eps, weight_decay, ptr(gscale), ptr(scaler_state))
+
+
 def adamw_step(p, g, m, v, p_bf16, lr, beta1, beta2, eps, weight_decay, step, gscale=None):
     call("pxa_adamw_step", ptr(p), ptr(g), ptr(m), ptr(v), ptr(p_bf16), p.numel(), lr, beta1, beta2, eps, weight_decay, step, ptr(gscale))
 

@@ -8,7 +8,9 @@ from conftest import rel_l2
 from oracle import pixart_oracle as po
 from oracle.weights import make_inputs, make_state_dict
 
-FWD_CASES = ["fwd_d2_sq", "fwd_d2_kvconv", "fwd_d2_kvuniform", "fwd_d2_kvave", "fwd_d2_nomask", "fwd_d2_qknorm"]
+FWD_CASES = ["fwd_d2_sq", "fwd_d2_kvconv", "fwd_d2_kvuniform", "fwd_d2_kvave", "fwd_d2_nomask", "fwd_d2_qknorm", "fwd_d2_micro",
+             # BASELINE.json configs[1..4] token geometries (depth 2): 512px L=300 / L=120 multi-aspect, 1024px, 2K with KV compression
+             "fwd_512_l300", "fwd_512_l120", "fwd_1024_b2", "fwd_2k_kv"]
 
 
 def _setup(g):
@@ -24,19 +26,39 @@ def test_forward_matches_reference(golden, name):
     g = golden(name)
     cfg, sd, inp, mask = _setup(g)
     with torch.no_grad():
-        y = po.forward(sd, cfg, inp["x"], inp["t"], inp["y"], mask)
+        y = po.forward(sd, cfg, inp["x"], inp["t"], inp["y"], mask, data_info=g.get("data_info"))
     assert y.shape == g["y"].shape
     assert g["y"].abs().mean() > 1e-3  # not the vacuous zero-init case
     assert rel_l2(y, g["y"]) < 2e-5
 
 
-@pytest.mark.parametrize("gname", ["train_d2", "train_d2_qknorm"])
+def test_forward_with_cfg_matches_reference(golden):
+    """PixArtMS.forward_with_cfg (PixArtMS.py:221-234): both halves share the latent, guidance on the first three channels only."""
+    g = golden("cfg_d2")
+    cfg, sd, inp, mask = _setup(g)
+    with torch.no_grad():
+        y = po.forward_with_cfg(sd, cfg, inp["x"], inp["t"], inp["y"], g["cfg_scale"], mask)
+    assert rel_l2(y, g["y"]) < 2e-5
+    assert torch.equal(y[:2, :3], y[2:, :3]) and not torch.equal(y[:2, 3:], y[2:, 3:])
+
+
+def test_micro_condition_changes_the_output(golden):
+    """The size / aspect-ratio embeddings really enter t (PixArtMS.py:187-191): other data_info -> other output."""
+    g = golden("fwd_d2_micro")
+    cfg, sd, inp, mask = _setup(g)
+    di = {k: v.flip(0) for k, v in g["data_info"].items()}
+    with torch.no_grad():
+        y = po.forward(sd, cfg, inp["x"], inp["t"], inp["y"], mask, data_info=di)
+    assert rel_l2(y, g["y"]) > 1e-3
+
+
+@pytest.mark.parametrize("gname", ["train_d2", "train_d2_qknorm", "train_d2_micro", "train_1024_b2"])
 def test_training_losses_and_grads_match_reference(golden, gname):
     g = golden(gname)
     cfg, sd, inp, mask = _setup(g)
     sd = {k: (v.clone().requires_grad_(True) if k != "y_embedder.y_embedding" else v) for k, v in sd.items()}
     diff = po.GaussianDiffusionOracle()
-    terms = diff.training_losses(lambda xt, t: po.forward(sd, cfg, xt, t, inp["y"], mask), inp["x"], g["t"], inp["noise"])
+    terms = diff.training_losses(lambda xt, t: po.forward(sd, cfg, xt, t, inp["y"], mask, data_info=g.get("data_info")), inp["x"], g["t"], inp["noise"])
     for k in ("loss", "mse", "vb"):
         assert torch.allclose(terms[k], g[k], rtol=2e-5, atol=1e-6), k
     terms["loss"].mean().backward()
@@ -50,6 +72,8 @@ def test_training_losses_and_grads_match_reference(golden, gname):
         assert rel_l2(gr.flatten()[:16], ref["head"]) < 1e-3 or ref["head"].norm() < 1e-7, k
         if "full" in ref:
             assert rel_l2(gr, ref["full"]) < 1e-4, k
+        if "sample" in ref:
+            assert rel_l2(gr.flatten()[:: ref["stride"]], ref["sample"]) < 1e-4, k
 
 
 def _sample(g, cfg, sd, inp, mask):
