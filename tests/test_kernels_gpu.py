@@ -428,3 +428,108 @@ def test_grad_norm_and_clip(ops):
     norm = math.sqrt(s.item()) * 0.5
     assert abs(out[1].item() - norm) / norm < 1e-5
     assert abs(out[0].item() - min(1.0, 0.01 / (norm + 1e-6)) * 0.5) < 1e-7
+
+
+# ------------------------------------------------------------------------------------------------ headline operand shapes (BASELINE configs 2-4)
+# The shapes bench.py and tools/bench_infer.py time: M = B*N = 65,536 token rows into K / N in {1152, 3456, 4608}; dW with K = 65,536 and
+# the library's own split-K choice; attention at N = 4096 (8192 workgroups per launch at batch 16) and N_q = 16384 against N_kv = 4096.
+# References: fp32 torch on the same bf16-rounded operands, computed on the GPU (per head for attention).  Each test prints its rel-L2.
+M_TOK = 65536
+
+
+def _gpu_rnd(*shape, scale=1.0, seed=0):
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    return torch.randn(*shape, generator=g, device="cuda") * scale
+
+
+@pytest.mark.parametrize("N,K,flavour", [(3456, 1152, "bias"), (1152, 1152, "bias"), (4608, 1152, "gelu_save_grad"), (1152, 4608, "bias"),
+                                         (1152, 4608, "add_aux")])
+def test_gemm_nt_headline_shapes(ops, N, K, flavour):
+    """qkv / proj / fc1 (+GELU, GELU' saved) / fc2 forward GEMMs at M = 65,536: persistent 256x256 kernel, 4.5 / 13.5 / 18 tile columns,
+    half-width remainder items with K = 1152 and K = 4608."""
+    a, w, b = bf(_gpu_rnd(M_TOK, K, seed=1)), bf(_gpu_rnd(N, K, scale=K ** -0.5, seed=2)), _gpu_rnd(N, seed=3)
+    pre = a.float() @ w.float().t() + b
+    if flavour == "bias":
+        e = rel_l2(ops.gemm(a, w, ops.NT, bias=b).float(), pre)
+    elif flavour == "add_aux":
+        aux = bf(_gpu_rnd(M_TOK, N, seed=5))
+        e = rel_l2(ops.gemm(a, w, ops.NT, bias=b, act=ops.ACT_ADD_AUX, aux=aux).float(), pre + aux.float())
+    else:
+        out2 = torch.empty(M_TOK, N, dtype=torch.bfloat16, device="cuda")
+        out = ops.gemm(a, w, ops.NT, bias=b, act=ops.ACT_GELU_SAVE_GRAD, out2=out2)
+        x = pre.clone().requires_grad_(True)
+        F.gelu(x, approximate="tanh").backward(torch.ones_like(x))
+        e = max(rel_l2(out.float(), F.gelu(pre, approximate="tanh")), rel_l2(out2.float(), x.grad))
+    print(f"\n[NT {M_TOK}x{N}x{K} {flavour}] rel-L2 {e:.2e} (bound {BF16_TOL:.0e})")
+    assert e < BF16_TOL
+
+
+@pytest.mark.parametrize("K,N,flavour", [(3456, 1152, "plain"), (1152, 1152, "plain"), (4608, 1152, "plain"), (1152, 4608, "mul_aux_colsum")])
+def test_gemm_nn_headline_shapes(ops, K, N, flavour):
+    """dX = dY W at M = 65,536: qkv / proj / fc1 input gradients and the fc2 input gradient times the saved GELU' with the fused fc1
+    bias-gradient column sums (K = reduction over the layer's output features)."""
+    dy, w = bf(_gpu_rnd(M_TOK, K, seed=1)), bf(_gpu_rnd(K, N, scale=K ** -0.5, seed=2))
+    ref = dy.float() @ w.float()
+    if flavour == "plain":
+        e = rel_l2(ops.gemm(dy, w, ops.NN).float(), ref)
+    else:
+        aux = bf(_gpu_rnd(M_TOK, N, seed=5))
+        part = torch.zeros(ops.COLSUM_SLOTS, N, device="cuda")
+        out = ops.gemm(dy, w, ops.NN, act=ops.ACT_MUL_AUX, aux=aux, colsum=part)
+        e = rel_l2(out.float(), ref * aux.float())
+        e_cs = rel_l2(part.sum(0), out.float().sum(0))
+        print(f"\n[NN colsum] rel-L2 vs column sums of the stored values {e_cs:.2e}")
+        assert e_cs < 1e-4
+    print(f"\n[NN {M_TOK}x{N}x{K} {flavour}] rel-L2 {e:.2e} (bound {BF16_TOL:.0e})")
+    assert e < BF16_TOL
+
+
+@pytest.mark.parametrize("M,N", [(3456, 1152), (1152, 1152), (4608, 1152), (1152, 4608), (2304, 1152)])
+def test_gemm_tn_weight_gradient_k65536(ops, M, N):
+    """dW[M][N] += sum over K = 65,536 tokens of dY[k][M] X[k][N], split_k = 0 (the library chooses tile shape and split; partial slabs +
+    one reduce launch), accumulated twice into the fp32 gradient.  Reference in fp64 on a 256-row band (fp32 torch beside it)."""
+    a, b = bf(_gpu_rnd(M_TOK, M, seed=1)), bf(_gpu_rnd(M_TOK, N, seed=2))
+    out = torch.zeros(M, N, device="cuda")
+    ops.gemm(a, b, ops.TN, out_f32=out, accumulate=True, split_k=0)
+    rows = slice(M // 2 - 128, M // 2 + 128)
+    ref64 = a[:, rows].double().t() @ b.double()
+    e64 = rel_l2(out[rows], ref64)
+    e32 = rel_l2(out, a.float().t() @ b.float())
+    ops.gemm(a, b, ops.TN, out_f32=out, accumulate=True, split_k=0)
+    e2 = rel_l2(out[rows], 2 * ref64)
+    print(f"\n[TN dW {M}x{N} K={M_TOK}] rel-L2 vs fp64 {e64:.2e}, vs torch fp32 {e32:.2e}, after 2nd accumulate {e2:.2e} (bound 2e-5)")
+    assert e64 < 2e-5 and e2 < 2e-5 and e32 < 5e-5
+
+
+def _attn_ref_heads(q, k, v, do):
+    """fp32 softmax attention + its gradients, one (batch, head) at a time.  q (B,Nq,H,72), k/v (B,Nk,H,72), do like q."""
+    B, Nq, H, Dh = q.shape
+    o, dq, dk, dv = torch.empty_like(q, dtype=torch.float32), torch.empty_like(q, dtype=torch.float32), torch.empty_like(k, dtype=torch.float32), torch.empty_like(v, dtype=torch.float32)
+    for b in range(B):
+        for h in range(H):
+            qq, kk, vv = (t[b, :, h].float().clone().requires_grad_(True) for t in (q, k, v))
+            p = torch.softmax((qq @ kk.t()) * Dh ** -0.5, dim=-1)
+            oo = p @ vv
+            oo.backward(do[b, :, h].float())
+            o[b, :, h], dq[b, :, h], dk[b, :, h], dv[b, :, h] = oo.detach(), qq.grad, kk.grad, vv.grad
+    return o, dq, dk, dv
+
+
+@pytest.mark.parametrize("B,H,Nq,Nk", [(2, 16, 4096, 4096), (1, 16, 16384, 4096)])
+def test_attention_headline_shapes(ops, B, H, Nq, Nk):
+    """Self-attention of the 1024px training step (N = 4096: 64 key tiles per query tile, 32 query... per key block in the backward
+    kernels) and the 2K KV-compressed layers (N_q = 16384 against N_kv = 4096), forward + backward, vs fp32 attention per head."""
+    C = H * 72
+    q, k, v, do = bf(_gpu_rnd(B, Nq, C, seed=1)), bf(_gpu_rnd(B, Nk, C, seed=2)), bf(_gpu_rnd(B, Nk, C, seed=3)), bf(_gpu_rnd(B, Nq, C, seed=4))
+    o = torch.empty(B, Nq, C, dtype=torch.bfloat16, device="cuda")
+    lse = torch.empty(B, H, Nq, device="cuda")
+    sq, sk = (Nq * C, C, 72), (Nk * C, C, 72)
+    ops.attention_fwd(q, k, v, o, lse, B, H, Nq, Nk, (sq, sk, sk, sq))
+    dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+    delta = torch.empty(B, H, Nq, device="cuda")
+    ops.attention_bwd(q, k, v, o, do, lse, delta, dq, dk, dv, B, H, Nq, Nk, (sq, sk, sk, sq), (sq, sk, sk))
+    ro, rdq, rdk, rdv = _attn_ref_heads(q.view(B, Nq, H, 72), k.view(B, Nk, H, 72), v.view(B, Nk, H, 72), do.view(B, Nq, H, 72))
+    errs = {n: rel_l2(t.float().view_as(r), r) for n, t, r in (("o", o, ro), ("dq", dq, rdq), ("dk", dk, rdk), ("dv", dv, rdv))}
+    print(f"\n[attention B{B} H{H} Nq{Nq} Nk{Nk}] rel-L2 " + " ".join(f"{n} {e:.2e}" for n, e in errs.items()) + f" (bounds {BF16_TOL:.0e} / {2 * BF16_TOL:.0e})")
+    assert errs["o"] < BF16_TOL
+    assert max(errs["dq"], errs["dk"], errs["dv"]) < 2 * BF16_TOL

@@ -1,9 +1,15 @@
 """Model-level parity of the HIP path (pixart_sigma_amd.PixArtMS on MI355X) against
-  (a) tests/golden/*.pt — outputs of the unmodified reference in fp32 (oracle/make_golden.py), and
-  (b) oracle/pixart_oracle.py evaluated on the host with bf16 rounding at the HIP path's rounding points (rp=True).
-Tolerances (rel-L2): vs (b) <= 1e-3 forward — the north-star bar, same rounding points; vs (a) <= 1e-2 forward — pure
-fp32 reference, dominated by the bf16 operand rounding both the reference's own AMP path and ours carry.  Gradients:
-<= 3e-2 per tensor vs the fp32 reference gradients, <= 5e-3 on the loss."""
+  (a) tests/golden/*.pt - outputs of the unmodified reference in fp32 (oracle/make_golden.py), and
+  (b) oracle/pixart_oracle.py evaluated on the host with 16-bit rounding at the HIP path's rounding points (rp=True).
+
+The file runs under either operand build (PXA_OPERAND_DTYPE, one library per type; tests/test_f16_parity_gpu.py re-runs it in a
+subprocess under f16).  Bounds, rel-L2, by build:
+
+  fp16 operands (the reference's own mixed precision, configs/PixArt_xl2_internal.py:57; the build BASELINE.json's <= 1e-3 is
+  stated for):   forward <= 1e-3 vs the fp32 reference; loss <= 1e-3; every parameter gradient <= GRAD_TOL_F16 (loss-scaled backward).
+  bf16 operands (default training build): one bf16 rounding of a tensor is 1.6e-3 by itself, so <= 1e-3 is unreachable by
+  construction: forward <= 3e-3 vs the same-rounding-point oracle and <= 1e-2 vs fp32; gradients <= 3e-2; loss <= 5e-3.
+Every test prints the measured error next to its bound."""
 import pytest
 import torch
 
@@ -12,8 +18,15 @@ pytestmark = pytest.mark.gpu
 from conftest import rel_l2  # noqa: E402
 from oracle import pixart_oracle as po  # noqa: E402
 from oracle.weights import make_inputs, make_state_dict  # noqa: E402
+from pixart_sigma_amd import lib as _lib  # noqa: E402
 
-FWD_RP_TOL, FWD_F32_TOL = 3e-3, 1e-2
+F16 = _lib.OPERAND == "f16"
+po.RP_DTYPE = _lib.OPERAND_DTYPE
+FWD_RP_TOL, FWD_F32_TOL = (1e-3, 1e-3) if F16 else (3e-3, 1e-2)
+FWD_DEEP_TOL = 1e-3 if F16 else 2e-2            # depth-28 XL/2 (error grows with depth)
+SAMPLE_TOL = 2e-3 if F16 else 2e-2              # 2-step CFG-4.5 sampler amplifies the forward error
+LOSS_TOL = 1e-3 if F16 else 5e-3
+GRAD_TOL = 2e-3 if F16 else 3e-2
 
 
 @pytest.fixture(scope="module", autouse=True)
@@ -32,7 +45,7 @@ def _build(g, train=False):
         kvc = {"sampling": cfg.kv_sampling, "scale_factor": cfg.kv_scale_factor, "kv_compress_layer": list(cfg.kv_layers)}
     m = build_model("PixArtMS", depth=cfg.depth, hidden_size=1152, num_heads=16, input_size=cfg.input_size,
                     pe_interpolation=cfg.pe_interpolation, model_max_length=cfg.model_max_length, class_dropout_prob=0.0,
-                    kv_compress_config=kvc, qk_norm=cfg.qk_norm)
+                    kv_compress_config=kvc, qk_norm=cfg.qk_norm, micro_condition=cfg.micro_condition)
     m.load_state_dict(sd)
     m = m.cuda()
     m.train(train)
@@ -40,18 +53,64 @@ def _build(g, train=False):
     return cfg, sd, inp, mask, m
 
 
-@pytest.mark.parametrize("name", ["fwd_d2_sq", "fwd_d2_nomask", "fwd_d2_kvconv", "fwd_d2_kvuniform", "fwd_d2_kvave", "fwd_d2_qknorm"])
+def _backward_scaled(make_loss, m):
+    """forward + loss.backward() for either build; returns (terms, scale).  fp16 operands: the loss is scaled by the largest power of
+    two <= 2^16 whose gradients stay finite (what the dynamic LossScaler converges to; the step is re-run on overflow exactly as a
+    skipped step would be) and the flat gradient buffer is unscaled afterwards."""
+    scale = 65536.0 if F16 else 1.0
+    while True:
+        if m._store is not None:
+            m._store.grad.zero_()
+        terms = make_loss()
+        (terms["loss"].mean() * scale).backward()
+        if not F16 or torch.isfinite(m._store.grad).all() or scale <= 1.0:
+            break
+        scale /= 2
+    if scale != 1.0:
+        m._store.grad.div_(scale)
+    return terms, scale
+
+
+@pytest.mark.parametrize("name", ["fwd_d2_sq", "fwd_d2_nomask", "fwd_d2_kvconv", "fwd_d2_kvuniform", "fwd_d2_kvave", "fwd_d2_qknorm", "fwd_d2_micro"])
 def test_forward_matches_reference_and_oracle(golden, name):
     g = golden(name)
     cfg, sd, inp, mask, m = _build(g)
+    di = g.get("data_info")       # micro-conditioning (SizeEmbedder on img_hw / aspect_ratio, PixArtMS.py:187-191)
     with torch.no_grad():
-        y = m(inp["x"].cuda(), inp["t"].cuda(), inp["y"].cuda(), mask=None if mask is None else mask.cuda()).cpu()
-        y_rp = po.forward(sd, cfg, inp["x"], inp["t"], inp["y"], mask, rp=True)
+        y = m(inp["x"].cuda(), inp["t"].cuda(), inp["y"].cuda(), mask=None if mask is None else mask.cuda(), data_info=di).cpu()
+        y_rp = po.forward(sd, cfg, inp["x"], inp["t"], inp["y"], mask, rp=True, data_info=di)
     e_rp, e_f32 = rel_l2(y, y_rp), rel_l2(y, g["y"])
     print(f"\n[{name}] rel-L2 vs rounding-point oracle {e_rp:.2e}, vs fp32 reference {e_f32:.2e} (oracle-rp vs fp32 {rel_l2(y_rp, g['y']):.2e})")
     assert y.shape == g["y"].shape and torch.isfinite(y).all()
     assert e_rp < FWD_RP_TOL
     assert e_f32 < FWD_F32_TOL
+
+
+@pytest.mark.parametrize("name", ["fwd_512_l300", "fwd_512_l120", "fwd_1024_b2", "fwd_2k_kv"])
+def test_forward_at_baseline_token_geometries(golden, name):
+    """BASELINE.json configs[1..4] at their real token counts (depth 2): N = 1024 (512px, L = 300 and the multi-aspect L = 120
+    alpha-DMD shape), N = 4096 (1024px training shape), N = 16384 with KV compression to 4096 on one block (2K).  These are the
+    grids the benchmarks time: attention with 32-128 key tiles per query tile, persistent GEMMs with M = B*N >= 2048."""
+    g = golden(name)
+    cfg, sd, inp, mask, m = _build(g)
+    with torch.no_grad():
+        y = m(inp["x"].cuda(), inp["t"].cuda(), inp["y"].cuda(), mask=mask.cuda()).cpu()
+    e = rel_l2(y, g["y"])
+    print(f"\n[{name}] N={(inp['x'].shape[-1] // 2) * (inp['x'].shape[-2] // 2)} rel-L2 vs fp32 reference {e:.2e} (bound {FWD_F32_TOL:.0e})")
+    assert y.shape == g["y"].shape and torch.isfinite(y).all()
+    assert e < FWD_F32_TOL
+
+
+def test_forward_with_cfg_matches_reference(golden):
+    """PixArtMS.forward_with_cfg (reference PixArtMS.py:221-234)."""
+    g = golden("cfg_d2")
+    cfg, sd, inp, mask, m = _build(g)
+    with torch.no_grad():
+        y = m.forward_with_cfg(inp["x"].cuda(), inp["t"].cuda(), inp["y"].cuda(), g["cfg_scale"], None, mask=mask.cuda()).cpu()
+    e = rel_l2(y, g["y"])
+    print(f"\nforward_with_cfg rel-L2 vs fp32 reference {e:.2e}")
+    assert e < FWD_F32_TOL
+    assert torch.equal(y[:2, :3], y[2:, :3]) and not torch.equal(y[:2, 3:], y[2:, 3:])
 
 
 def test_fixed_resolution_pixart_forward(golden):
@@ -74,32 +133,41 @@ def test_fixed_resolution_pixart_forward(golden):
         m(inp["x"][..., :8].cuda(), inp["t"].cuda(), inp["y"].cuda())
 
 
-@pytest.mark.parametrize("gname", ["train_d2_plain", "train_d2", "train_d2_qknorm"])
+@pytest.mark.parametrize("gname", ["train_d2_plain", "train_d2", "train_d2_qknorm", "train_d2_micro", "train_1024_b2"])
 def test_training_step_loss_and_grads(golden, gname):
-    """train_d2 has KV compression ('conv', x2) on block 1: exercises kv_compress_bwd and the shared sr/norm gradients."""
+    """IDDPM training_losses + backward vs the reference's loss and EVERY parameter gradient.  train_d2 has KV compression ('conv', x2)
+    on block 1 (kv_compress_bwd, shared sr/norm gradients); train_d2_micro the SizeEmbedders; train_1024_b2 is the benchmark's token
+    geometry (N = 4096, L = 300: the dW GEMMs reduce over K = 8192 tokens, attention backward runs 32 key blocks x 64 query tiles)."""
     from pixart_sigma_amd import IDDPM
     g = golden(gname)
     cfg, sd, inp, mask, m = _build(g, train=True)
     diff = IDDPM(str(1000), learn_sigma=True, pred_sigma=True, snr=False)
-    kw = dict(y=inp["y"].cuda(), mask=mask[:, None, None, :].cuda(), data_info=None)
-    terms = diff.training_losses(m, inp["x"].cuda(), g["t"].cuda(), model_kwargs=kw, noise=inp["noise"].cuda())
-    terms["loss"].mean().backward()
-    print("\nloss", terms["loss"].tolist(), "ref", g["loss"].tolist())
-    assert rel_l2(terms["loss"].cpu(), g["loss"]) < 5e-3
+    kw = dict(y=inp["y"].cuda(), mask=mask[:, None, None, :].cuda(), data_info=g.get("data_info"))
+    terms, scale = _backward_scaled(lambda: diff.training_losses(m, inp["x"].cuda(), g["t"].cuda(), model_kwargs=kw, noise=inp["noise"].cuda()), m)
+    e_loss = rel_l2(terms["loss"].cpu(), g["loss"])
+    print(f"\n[{gname}] loss {terms['loss'].tolist()} ref {g['loss'].tolist()} rel-L2 {e_loss:.2e} (bound {LOSS_TOL:.0e}); loss scale {scale:g}")
+    assert e_loss < LOSS_TOL
     worst = []
+    gmax = max(r["norm"] for r in g["grads"].values())
     for k, p in m.named_parameters():
         ref = g["grads"][k]
         gr = p.grad.detach().float().cpu()
-        if ref["norm"] < 1e-9:            # mathematically zero gradient (k_norm.bias cancels in the softmax): only bf16 noise may remain
-            assert gr.norm().item() < 1e-3 * max(r["norm"] for r in g["grads"].values()), k
+        if ref["norm"] < 1e-9:            # mathematically zero gradient (k_norm.bias cancels in the softmax): only rounding noise may remain
+            assert gr.norm().item() < 1e-3 * gmax, k
             continue
         e_norm = abs(gr.norm().item() - ref["norm"]) / (ref["norm"] + 1e-12)
-        e_full = rel_l2(gr, ref["full"]) if "full" in ref else rel_l2(gr.flatten()[:16], ref["head"])
-        worst.append((max(e_norm, e_full if "full" in ref else 0.0), e_norm, e_full, k))
+        if "full" in ref:
+            e_el = rel_l2(gr, ref["full"])
+        elif "sample" in ref:
+            e_el = rel_l2(gr.flatten()[:: ref["stride"]], ref["sample"])
+        else:
+            e_el = 0.0                    # round-1 goldens keep 16 leading elements only: checked loosely below
+            assert rel_l2(gr.flatten()[:16], ref["head"]) < 10 * GRAD_TOL or ref["head"].norm() < 1e-6 * ref["norm"], k
+        worst.append((max(e_norm, e_el), e_norm, e_el, k))
     worst.sort(reverse=True)
     for w in worst[:8]:
-        print("grad err (max, norm, full/head) %.2e %.2e %.2e %s" % w)
-    assert worst[0][0] < 3e-2, worst[0]
+        print("grad err (max, norm, elementwise) %.2e %.2e %.2e %s" % w)
+    assert worst[0][0] < GRAD_TOL, worst[0]
     # gradients live in the flat buffer the fused optimizer / all-reduce work on
     st = m._store
     assert all(p.grad.data_ptr() == st.grad.data_ptr() + 4 * st.offset[n] for n, p in st.params.items())
@@ -119,7 +187,8 @@ def test_grad_checkpointing_matches_saved_activations(golden):
             set_grad_checkpoint(m)
         if m._store is not None:
             m._store.grad.zero_()
-        diff.training_losses(m, inp["x"].cuda(), g["t"].cuda(), model_kwargs=kw, noise=inp["noise"].cuda())["loss"].mean().backward()
+        loss = diff.training_losses(m, inp["x"].cuda(), g["t"].cuda(), model_kwargs=kw, noise=inp["noise"].cuda())["loss"].mean()
+        (loss * (1024.0 if F16 else 1.0)).backward()
         grads.append(m._store.grad.clone())
     assert rel_l2(grads[1], grads[0]) < 1e-4
 
@@ -134,7 +203,7 @@ def test_dpm_solver_sampling_matches_reference(golden):
              model_kwargs=dict(data_info=None, mask=mask.cuda())).sample(inp["x"].cuda(), steps=2, order=2, skip_type="time_uniform", method="multistep")
     e = rel_l2(s.cpu(), g["sample"])
     print(f"\n2-step DPM-Solver++ sample rel-L2 vs reference {e:.2e}")
-    assert e < FWD_F32_TOL
+    assert e < (SAMPLE_TOL if F16 else FWD_F32_TOL)
 
 
 def test_dpm_solver_graphed_loop_replays_bit_exact(golden):
@@ -177,8 +246,8 @@ def test_block_api_matches_oracle_block():
     for a, b, nm in ((xg, xr, "dx"), (yg, yr, "dy"), (tg, tr, "dt")):
         e = rel_l2(a.grad.cpu(), b.grad)
         print(f"block {nm} rel-L2 {e:.2e}")
-        assert e < 2e-2, nm
-    assert rel_l2(blk.scale_shift_table.grad.cpu(), sd["blocks.0.scale_shift_table"].grad) < 2e-2
+        assert e < (3e-3 if F16 else 2e-2), nm
+    assert rel_l2(blk.scale_shift_table.grad.cpu(), sd["blocks.0.scale_shift_table"].grad) < (3e-3 if F16 else 2e-2)
 
 
 def test_config1_xl2_256_full_depth(golden):
@@ -190,11 +259,11 @@ def test_config1_xl2_256_full_depth(golden):
         y = m(inp["x"].cuda(), inp["t"].cuda(), inp["y"].cuda(), mask=mask.cuda()).cpu()
     e = rel_l2(y, g["fwd"])
     print(f"\nXL/2 256px forward rel-L2 vs fp32 reference {e:.2e}")
-    assert e < 2e-2
+    assert e < FWD_DEEP_TOL
     gen = torch.Generator().manual_seed(g["null_seed"])
     null_y = torch.randn(1, 1, 300, 4096, generator=gen).repeat(2, 1, 1, 1).cuda()
     s = DPMS(m.forward_with_dpmsolver, condition=inp["y"].cuda(), uncondition=null_y, cfg_scale=4.5,
              model_kwargs=dict(data_info=None, mask=mask.cuda())).sample(inp["x"].cuda(), steps=2, order=2)
     e = rel_l2(s.cpu(), g["sample"])
     print(f"XL/2 256px 2-step sample rel-L2 vs fp32 reference {e:.2e}")
-    assert e < 2e-2
+    assert e < SAMPLE_TOL
