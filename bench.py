@@ -28,9 +28,23 @@ sys.path.insert(0, ROOT)
 
 D, H, DFF, DEPTH, LTXT = 1152, 16, 4608, 28, 300
 MFMA_PEAK = 2.5e15   # dense bf16, MI355X (MI355X_MICROARCH.md)
-# HBM bytes per launch of the dominant kernel (attn_bwd_dkv_kernel, self-attention B16 H16 N4096), from the PMC passes committed under
-# profiles/r01_pmc_attention.txt (rocprofv3 cannot run inside the benchmark): 2 x 1,359,963 KB fetched + 296,308 KB written
-DKV_HBM_BYTES_PER_LAUNCH = 2 * 1359963.0e3 + 296308.2e3
+PMC_FILES = ["profiles/r02_pmc_attention.json", "profiles/r01_pmc_attention.json"]   # newest first (tools/pmc_query.py --json)
+
+
+def pmc_traffic(kernel_substr, grid):
+    """HBM bytes per launch of a kernel from the committed PMC passes (rocprofv3 cannot run inside the benchmark): separate --pmc
+    passes for FETCH_SIZE / WRITE_SIZE (KB per launch); FETCH_SIZE doubled per the gfx950 note of MI355X_MICROARCH.md.
+    Returns (bytes | None, source)."""
+    for rel in PMC_FILES:
+        path = os.path.join(ROOT, rel)
+        if not os.path.exists(path):
+            continue
+        with open(path) as f:
+            rows = json.load(f)["kernels"]
+        for r in rows:
+            if kernel_substr in r["kernel"] and r.get("grid") == grid and "FETCH_SIZE" in r["counters"] and "WRITE_SIZE" in r["counters"]:
+                return 2 * r["counters"]["FETCH_SIZE"] * 1e3 + r["counters"]["WRITE_SIZE"] * 1e3, f"{rel}: 2 x FETCH_SIZE (gfx950 correction) + WRITE_SIZE, separate --pmc passes, bytes per launch"
+    return None, "no PMC file for this kernel / grid under profiles/"
 
 
 def fwd_flops_per_sample(N, L=LTXT, n_kv=None):
@@ -60,28 +74,28 @@ def kernel_rooflines(B, N):
     from pixart_sigma_amd import ops
     dev = "cuda"
     R = B * N
-    x = torch.randn(R, D, device=dev).to(torch.bfloat16)
-    w1 = (torch.randn(DFF, D, device=dev) * D ** -0.5).to(torch.bfloat16)
+    x = torch.randn(R, D, device=dev).to(ops.BF16)
+    w1 = (torch.randn(DFF, D, device=dev) * D ** -0.5).to(ops.BF16)
     b1 = torch.zeros(DFF, device=dev)
-    out, out2 = torch.empty(R, DFF, dtype=torch.bfloat16, device=dev), torch.empty(R, DFF, dtype=torch.bfloat16, device=dev)
+    out, out2 = torch.empty(R, DFF, dtype=ops.BF16, device=dev), torch.empty(R, DFF, dtype=ops.BF16, device=dev)
     res = {}
     t = timed(lambda: ops.gemm(x, w1, ops.NT, bias=b1, act=ops.ACT_GELU, out=out, out2=out2), 40, warm=5)
     res["gemm_nt_fc1_gelu"] = dict(flops=2.0 * R * DFF * D, seconds=t)
-    dy = torch.randn(R, DFF, device=dev).to(torch.bfloat16)
-    dxo = torch.empty(R, D, dtype=torch.bfloat16, device=dev)
+    dy = torch.randn(R, DFF, device=dev).to(ops.BF16)
+    dxo = torch.empty(R, D, dtype=ops.BF16, device=dev)
     t = timed(lambda: ops.gemm(dy, w1, ops.NN, out=dxo), 40, warm=5)
     res["gemm_nn_fc1_dx"] = dict(flops=2.0 * R * DFF * D, seconds=t)
     dw = torch.zeros(DFF, D, device=dev)
     t = timed(lambda: ops.gemm(dy, x, ops.TN, out_f32=dw, accumulate=True, split_k=0), 40, warm=5)
     res["gemm_tn_fc1_dw"] = dict(flops=2.0 * R * DFF * D, seconds=t)
-    qkv = torch.randn(R, 3 * D, device=dev).to(torch.bfloat16)
-    a = torch.empty(R, D, dtype=torch.bfloat16, device=dev)
+    qkv = torch.randn(R, 3 * D, device=dev).to(ops.BF16)
+    a = torch.empty(R, D, dtype=ops.BF16, device=dev)
     lse = torch.empty(B, H, N, device=dev)
     s3 = (N * 3 * D, 3 * D, 72)
     st = (s3, s3, s3, (N * D, D, 72))
     t = timed(lambda: ops.attention_fwd(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], a, lse, B, H, N, N, st), 30, warm=5)
     res["attn_fwd_self"] = dict(flops=4.0 * B * N * N * D, seconds=t)
-    da, dqkv, delta = torch.randn(R, D, device=dev).to(torch.bfloat16), torch.empty_like(qkv), torch.empty(B, H, N, device=dev)
+    da, dqkv, delta = torch.randn(R, D, device=dev).to(ops.BF16), torch.empty_like(qkv), torch.empty(B, H, N, device=dev)
     t = timed(lambda: ops.attention_bwd(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], a, da, lse, delta, dqkv[:, :D], dqkv[:, D:2 * D],
                                         dqkv[:, 2 * D:], B, H, N, N, st, (s3, s3, s3)), 15, warm=3)
     res["attn_bwd_self"] = dict(flops=10.0 * B * N * N * D, seconds=t)     # delta + dQ + dK/dV kernels, algorithmic 2.5x forward
@@ -95,16 +109,18 @@ def kernel_rooflines(B, N):
     return res
 
 
-def cpu_baseline(budget_px=256):
-    """oracle/ (CPU port of the reference path) fwd+bwd of the full-depth XL/2 on the host cores, bounded sample:
-    one sample at `budget_px` resolution, scaled to the benchmark step by algorithmic FLOPs.  Threads are capped at 32:
-    on the 256-thread GPU host an uncapped torch pool ran this op mix ~40x slower (measured round 1)."""
+def cpu_baseline(px=1024):
+    """oracle/ (CPU port of the reference path, fp32, attention through torch's CPU scaled_dot_product_attention) fwd+bwd of the
+    FULL-DEPTH XL/2 on the host cores at the benchmark's own resolution, batch 1 (~45 s on 8 cores); the step
+    at batch 16 is 16 x that (samples are independent: no cross-sample op).  Threads are capped at 32: on the 256-thread GPU host an
+    uncapped torch pool ran this op mix ~40x slower (measured round 1)."""
     from oracle import pixart_oracle as po
     from oracle.weights import make_inputs, make_state_dict
     cores = min(os.cpu_count() or 1, 32)
     torch.set_num_threads(cores)
-    lat = budget_px // 8
-    cfg = po.OracleCfg(depth=DEPTH, input_size=lat, model_max_length=LTXT, pe_interpolation=budget_px / 512)
+    po.SDPA = True
+    lat = px // 8
+    cfg = po.OracleCfg(depth=DEPTH, input_size=lat, model_max_length=LTXT, pe_interpolation=px / 512)
     sd = make_state_dict(cfg, seed=0)
     sd = {k: (v.requires_grad_(True) if k != "y_embedder.y_embedding" else v) for k, v in sd.items()}
     inp = make_inputs(B=1, Hl=lat, Wl=lat, L=LTXT, seed=1)
@@ -113,8 +129,66 @@ def cpu_baseline(budget_px=256):
     terms = diff.training_losses(lambda xt, t: po.forward(sd, cfg, xt, t, inp["y"], inp["mask"]), inp["x"], inp["t"], inp["noise"])
     terms["loss"].mean().backward()
     dt = time.time() - t0
-    n = (lat // 2) ** 2
-    return dt, 3 * fwd_flops_per_sample(n), cores, f"oracle (CPU port of the reference path, fp32) fwd+bwd XL/2 {budget_px}px batch 1: {dt:.1f} s"
+    po.SDPA = False
+    return dt, cores, f"oracle (CPU port of the reference path, fp32, SDPA attention) fwd+bwd of the full-depth XL/2 at {px}px, batch 1: {dt:.1f} s on {cores} threads"
+
+
+def torch_rocm_baseline(B, lat, px, steps=3, warmup=1):
+    """The 'reference PyTorch path on the same GPU' bar: the restated reference modules
+    (oracle/, same arithmetic as the reference's nn.Modules) on this MI355X through stock PyTorch-ROCm - bf16 autocast (hipBLASLt
+    linears), F.scaled_dot_product_attention, torch.optim.AdamW(fused), clip_grad_norm_ - on the same synthetic training step.
+    Falls back to per-block activation checkpointing (the reference's own 1024px setting, configs/...img1024_internalms.py) if the
+    stored activations do not fit."""
+    from torch.utils.checkpoint import checkpoint
+    from oracle import pixart_oracle as po
+    from oracle.weights import make_state_dict
+    dev = torch.device("cuda")
+    po.SDPA = True
+    cfg = po.OracleCfg(depth=DEPTH, input_size=lat, model_max_length=LTXT, pe_interpolation=px / 512)
+    sd = {k: v.to(dev) for k, v in make_state_dict(cfg, seed=0).items()}
+    params = [v.requires_grad_(True) for k, v in sd.items() if k != "y_embedder.y_embedding"]
+    opt = torch.optim.AdamW(params, lr=2e-5, weight_decay=3e-2, eps=1e-10, fused=True)
+    diff = po.GaussianDiffusionOracle()
+    g = torch.Generator(device="cpu").manual_seed(1234)
+    x0, noise = torch.randn(B, 4, lat, lat, generator=g).to(dev), torch.randn(B, 4, lat, lat, generator=g).to(dev)
+    y, t = torch.randn(B, 1, LTXT, 4096, generator=g).to(dev), torch.randint(0, 1000, (B,), generator=g).to(dev)
+    mask = torch.ones(B, LTXT, dtype=torch.int64, device=dev)
+    mode = {"ckpt": False}
+    orig_block = po.block_forward
+
+    def block_ckpt(sd_, i, x, yp, t0, yl, HW, cfg_, rp=False):
+        return checkpoint(lambda xx, yy, tt: orig_block(sd_, i, xx, yy, tt, yl, HW, cfg_, rp), x, yp, t0, use_reentrant=False)
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            terms = diff.training_losses(lambda xt, tt: po.forward(sd, cfg, xt, tt, y, mask).float(), x0, t, noise)
+        terms["loss"].mean().backward()
+        torch.nn.utils.clip_grad_norm_(params, 0.01)
+        opt.step()
+
+    try:
+        try:
+            for _ in range(warmup):
+                step()
+        except torch.OutOfMemoryError:
+            torch.cuda.empty_cache()
+            mode["ckpt"] = True
+            po.block_forward = block_ckpt
+            for _ in range(warmup):
+                step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+    finally:
+        po.block_forward = orig_block
+        po.SDPA = False
+    del opt, params, sd
+    torch.cuda.empty_cache()
+    return dt, mode["ckpt"]
 
 
 def main():
@@ -127,9 +201,15 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-roofline", action="store_true")
     ap.add_argument("--grad-checkpoint", action="store_true")
+    ap.add_argument("--dtype", choices=["bf16", "fp16"], default="bf16",
+                    help="MFMA operand type: bf16 (default build) or fp16 = the reference's own mixed precision (configs/PixArt_xl2_internal.py:57) "
+                         "with dynamic loss scaling; selects libpixart_hip_f16.so for the whole process")
+    ap.add_argument("--no-torch-baseline", action="store_true", help="skip the stock-PyTorch-ROCm leg (N = 1 only)")
     ap.add_argument("--optimizer", choices=["adamw", "came"], default="adamw",
                     help="adamw = the BASELINE config (configs/PixArt_xl2_internal.py); came = the CAMEWrapper of the Sigma configs")
     a = ap.parse_args()
+    if a.dtype == "fp16":                      # must be decided before pixart_sigma_amd is imported: one library per operand type
+        os.environ["PXA_OPERAND_DTYPE"] = "f16"
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -142,7 +222,7 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
 
     from pixart_sigma_amd import IDDPM, PixArtMS_XL_2
-    from pixart_sigma_amd.dp import FusedAdamW, FusedCAME
+    from pixart_sigma_amd.dp import FusedAdamW, FusedCAME, LossScaler
     from pixart_sigma_amd.model.utils import set_grad_checkpoint
 
     lat = a.image_size // 8
@@ -158,10 +238,11 @@ def main():
     if a.grad_checkpoint:
         set_grad_checkpoint(model)
     model.prepare(dev)
+    scaler = LossScaler(dev) if a.dtype == "fp16" else None      # GradScaler protocol on the device (accelerate's fp16 mode)
     if a.optimizer == "came":
-        opt = FusedCAME(model, lr=2e-5, weight_decay=0.0, betas=(0.9, 0.999, 0.9999), eps=(1e-30, 1e-16), max_grad_norm=0.01)
+        opt = FusedCAME(model, lr=2e-5, weight_decay=0.0, betas=(0.9, 0.999, 0.9999), eps=(1e-30, 1e-16), max_grad_norm=0.01, scaler=scaler)
     else:
-        opt = FusedAdamW(model, lr=2e-5, weight_decay=3e-2, eps=1e-10, max_grad_norm=0.01)
+        opt = FusedAdamW(model, lr=2e-5, weight_decay=3e-2, eps=1e-10, max_grad_norm=0.01, scaler=scaler)
     diff = IDDPM(str(1000), learn_sigma=True, pred_sigma=True, snr=False)
 
     g = torch.Generator(device="cpu").manual_seed(1234 + rank)
@@ -175,7 +256,7 @@ def main():
         opt.zero_grad()
         terms = diff.training_losses(model, x0, t, model_kwargs=dict(y=y, mask=mask, data_info=None), noise=noise)
         loss = terms["loss"].mean()
-        loss.backward()
+        (scaler.scale(loss) if scaler is not None else loss).backward()
         opt.step()
         return loss
 
@@ -205,11 +286,12 @@ def main():
             "metric": "denoising steps/sec (fwd+bwd) PixArt-Sigma-XL/2 1024px bs16 @1/2/4/8 GPU",
             "value": 1.0 / sec_per_step, "unit": "steps/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": sec_per_step * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "bf16", "data": "synthetic",
+            "dtype": a.dtype, "data": "synthetic",
             "config": {"workload": f"PixArt-Sigma-XL/2 {a.image_size}px training step (fwd+bwd+clip+{'CAME' if a.optimizer == 'came' else 'AdamW'}), batch {B}/GPU, L=300 text tokens, "
                                    f"DP={world} RCCL all-reduce", "model": "PixArtMS_XL_2", "global_batch": B * world, "seq_len": N,
                        "parallelism": f"dp{world}", "grad_checkpoint": bool(a.grad_checkpoint), "optimizer": a.optimizer},
             "images_per_s": B * world / sec_per_step, "final_loss": loss_v,
+            **({"loss_scale": scaler.value, "steps_skipped": scaler.steps_skipped} if scaler is not None else {}),
             "step_tflops_per_gpu": flops_step / sec_per_step / 1e12,
         }
         roof = {"bound": "mfma", "achieved": flops_step / sec_per_step / 1e12, "peak": MFMA_PEAK / 1e12, "unit": "TFLOP/s",
@@ -218,18 +300,31 @@ def main():
             ks = kernel_rooflines(B, N)
             # dominant kernel of the step by total time (profiles/: attn_bwd_dkv_kernel, 56 launches, ~17 % of the step)
             dom = ks["attn_bwd_dkv_kernel"]
+            traffic, tsrc = pmc_traffic("attn_bwd_dkv_kernel", B * H * (N // 128))
             roof = {"bound": "mfma", "kernel": "attn_bwd_dkv_kernel (self-attention, B16 H16 N4096 d72)", "achieved": dom["tflops"], "peak": MFMA_PEAK / 1e12,
-                    "unit": "TFLOP/s", "frac": dom["frac"], "traffic": DKV_HBM_BYTES_PER_LAUNCH,
-                    "traffic_source": "profiles/r01_pmc_attention.txt: 2 x FETCH_SIZE (gfx950 correction) + WRITE_SIZE, separate --pmc passes, bytes per launch",
+                    "unit": "TFLOP/s", "frac": dom["frac"], "traffic": traffic, "traffic_source": tsrc,
                     "flops_per_launch": dom["flops"], "ms_per_launch": dom["seconds"] * 1e3,
                     "step": {"achieved": flops_step / sec_per_step / 1e12, "frac": flops_step / sec_per_step / MFMA_PEAK,
                              "scope": "whole training step (algorithmic FLOPs / wall time)"},
                     "kernels": {k: {"TFLOP/s": round(v["tflops"], 1), "frac": round(v["frac"], 4), "ms": round(v["seconds"] * 1e3, 3)} for k, v in ks.items()}}
         out["roofline"] = roof
+        if not a.no_torch_baseline and world == 1 and a.dtype == "bf16":
+            del opt
+            model._store = model._engine = None
+            del model
+            torch.cuda.empty_cache()
+            try:
+                tdt, ckpt = torch_rocm_baseline(B, lat, a.image_size)
+                out["torch_rocm_baseline"] = {"value": 1.0 / tdt, "unit": "steps/s", "ms_per_step": tdt * 1e3, "speedup_of_this_repo": tdt / sec_per_step,
+                                              "what": "restated reference modules (oracle/) on this GPU through stock PyTorch-ROCm: bf16 autocast linears (hipBLASLt), "
+                                                      "F.scaled_dot_product_attention, fused torch AdamW, clip_grad_norm_; same synthetic step, batch "
+                                                      f"{B}" + ("; per-block activation checkpointing (activations did not fit)" if ckpt else "; no recompute")}
+            except Exception as e:   # noqa: BLE001 - the baseline leg must never take the headline number down with it
+                out["torch_rocm_baseline"] = {"value": None, "error": f"{type(e).__name__}: {e}"[:300]}
         if not a.no_cpu_baseline and world == 1:
-            cdt, cflops, cores, desc = cpu_baseline()
-            out["cpu_baseline"] = {"value": 1.0 / (cdt * flops_step / cflops), "unit": "steps/s", "cores": cores, "kind": "port",
-                                   "sample": desc + f"; scaled by algorithmic FLOPs x{flops_step / cflops:.1f} to the {a.image_size}px batch-{B} step"}
+            cdt, cores, desc = cpu_baseline(a.image_size)
+            out["cpu_baseline"] = {"value": 1.0 / (cdt * B), "unit": "steps/s", "cores": cores, "kind": "port",
+                                   "sample": desc + f"; x{B} in batch to the {a.image_size}px batch-{B} step (samples are independent)"}
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

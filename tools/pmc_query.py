@@ -1,6 +1,13 @@
 """Summarise a rocprofv3 --pmc sqlite database: per-kernel mean of each counter (+ launch geometry / registers / LDS).
-Usage: python tools/pmc_query.py <results.db> [name-regex]"""
-import re, sqlite3, sys
+Usage: python tools/pmc_query.py <results.db> [name-regex] [--json out.json]
+--json merges the per-(kernel, grid) counter means into out.json ({"kernels": [{"kernel", "grid", "counters": {...}}]}): the file
+bench.py reads roofline.traffic from (one --pmc pass per counter group, merged over calls)."""
+import json, os, re, sqlite3, sys
+jout = None
+if "--json" in sys.argv:
+    i = sys.argv.index("--json")
+    jout = sys.argv[i + 1]
+    del sys.argv[i:i + 2]
 db = sqlite3.connect(sys.argv[1])
 pat = re.compile(sys.argv[2] if len(sys.argv) > 2 else r"gemm|attn|ln_mod|gate|colsum|Cijk")
 cur = db.cursor()
@@ -27,6 +34,21 @@ except sqlite3.Error as e:
 by = {}
 for k, c, v, n in rows:
     by.setdefault(k, {})[c] = (v, n)
+if jout:
+    doc = json.load(open(jout)) if os.path.exists(jout) else {"unit": "counter means per launch; FETCH_SIZE / WRITE_SIZE in KB as rocprofv3 reports them", "kernels": []}
+    for k, d in by.items():
+        if not pat.search(k):
+            continue
+        name, _, g = k.partition("  [grid ")
+        name = re.sub(r"\(anonymous namespace\)::", "", name)
+        grid = int(g.rstrip("]")) // 256 if g else None          # workgroups (all these kernels run 256-thread workgroups) ... see wg below
+        ent = next((e for e in doc["kernels"] if e["kernel"] == name and e.get("grid_threads") == (int(g.rstrip("]")) if g else None)), None)
+        if ent is None:
+            ent = {"kernel": name, "grid_threads": int(g.rstrip("]")) if g else None, "grid": grid, "counters": {}}
+            doc["kernels"].append(ent)
+        for c, (v, n) in d.items():
+            ent["counters"][c] = v
+    json.dump(doc, open(jout, "w"), indent=1)
 for k, d in by.items():
     if not pat.search(k):
         continue
