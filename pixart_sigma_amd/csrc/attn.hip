@@ -445,6 +445,9 @@ __global__ __launch_bounds__(256, 2) void attn_fwd2_kernel(AttnParams p) {
 #ifndef ATTN_BWD_WAVES
 #define ATTN_BWD_WAVES 2
 #endif
+#ifndef ATTN_ABL
+#define ATTN_ABL 0      // ablation study of the dK/dV kernel (tools/build_variant.py; results in profiles/r02_attention_bwd_experiments.md):
+#endif                  // 1 no softmax VALU, 2 no dV/dK MFMAs, 4 no S/dP MFMAs, 8 no LDS fragment reads, 16 no LDS-DMA.  0 = the product kernel.
 __global__ __launch_bounds__(256, ATTN_BWD_WAVES) void attn_bwd_dq_kernel(AttnParams p) {
   __shared__ __attribute__((aligned(16))) char smem[4 * TILE_B];   // 2 stages x {K, V}
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), hi = lane >> 5;
@@ -585,7 +588,7 @@ __global__ __launch_bounds__(256, ATTN_BWD_WAVES) void attn_bwd_dkv_kernel(AttnP
     float* sL = ldsL + (t & 1) * 2 * BKV;
     if (tid < BKV) { sL[tid] = rl; sL[BKV + tid] = rdl; }   // buffer (t&1) was last read two iterations ago
     __syncthreads();
-    if (t + 1 < T) issue(t + 1);
+    if (!(ATTN_ABL & 16) && t + 1 < T) issue(t + 1);
 #pragma unroll
     for (int sub = 0; sub < 2; sub++) {
       f32x16 s, dp;
@@ -593,8 +596,15 @@ __global__ __launch_bounds__(256, ATTN_BWD_WAVES) void attn_bwd_dkv_kernel(AttnP
       for (int g = 0; g < 16; g++) { s[g] = 0.f; dp[g] = 0.f; }
 #pragma unroll
       for (int ks = 0; ks < KSTEPS; ks++) {
-        s = mfma32(rowfrag(sQ, fa, sub, ks), kf[ks], s);    // S[q][kv], col = kv (lane), rows = q
-        dp = mfma32(rowfrag(sD, fa, sub, ks), vf[ks], dp);  // dP[q][kv]
+        const bf16x8 qa = (ATTN_ABL & 8) ? vf[(ks + sub) % KSTEPS] : rowfrag(sQ, fa, sub, ks);
+        const bf16x8 da = (ATTN_ABL & 8) ? kf[(ks + sub) % KSTEPS] : rowfrag(sD, fa, sub, ks);
+        if (ATTN_ABL & 4) {
+          s[ks] += (float)qa[0] + (float)kf[ks][1];
+          dp[ks] += (float)da[0] + (float)vf[ks][1];
+        } else {
+          s = mfma32(qa, kf[ks], s);    // S[q][kv], col = kv (lane), rows = q
+          dp = mfma32(da, vf[ks], dp);  // dP[q][kv]
+        }
       }
 #pragma unroll
       for (int qd = 0; qd < 4; qd++) {
@@ -604,6 +614,7 @@ __global__ __launch_bounds__(256, ATTN_BWD_WAVES) void attn_bwd_dkv_kernel(AttnP
         const float Lv[4] = {L4.x, L4.y, L4.z, L4.w}, Dv[4] = {D4.x, D4.y, D4.z, D4.w};
 #pragma unroll
         for (int e = 0; e < 4; e++) {
+          if (ATTN_ABL & 1) continue;        // ablation: no softmax arithmetic (packs S, dP as they are)
           const float pr = __builtin_amdgcn_exp2f(s[qd * 4 + e] * c - Lv[e]);
           s[qd * 4 + e] = pr;
           dp[qd * 4 + e] = pr * (dp[qd * 4 + e] - Dv[e]);
@@ -615,8 +626,15 @@ __global__ __launch_bounds__(256, ATTN_BWD_WAVES) void attn_bwd_dkv_kernel(AttnP
         const int u = sub * 2 + uu;
 #pragma unroll
         for (int dt = 0; dt < 3; dt++) {
-          dv[dt] = mfma32(trfrag(sD, fa, dt, u), pb, dv[dt]);
-          dk[dt] = mfma32(trfrag(sQ, fa, dt, u), db, dk[dt]);
+          const bf16x8 dot = (ATTN_ABL & 8) ? kf[dt + uu] : trfrag(sD, fa, dt, u);
+          const bf16x8 qt = (ATTN_ABL & 8) ? vf[dt + uu] : trfrag(sQ, fa, dt, u);
+          if (ATTN_ABL & 2) {
+            dv[dt][u] += (float)dot[0] * (float)pb[dt];
+            dk[dt][u] += (float)qt[0] * (float)db[dt];
+          } else {
+            dv[dt] = mfma32(dot, pb, dv[dt]);
+            dk[dt] = mfma32(qt, db, dk[dt]);
+          }
         }
       }
     }
