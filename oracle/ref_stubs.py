@@ -201,9 +201,29 @@ def install():
     ml.logger_initialized = {}
     mr.get_dist_info = lambda: (0, 1)
 
+    mm.build_from_cfg = lambda cfg, registry, default_args=None: registry.build(cfg, default_args)
+
     tvm = _module("torchvision")
     tvt = _module("torchvision.transforms")
     tvm.transforms = tvt
+    # data-side imports of the reference (diffusion/data/*): names only, the feature-file path never calls them
+    tvd = _module("torchvision.datasets")
+    tvf = _module("torchvision.datasets.folder")
+    tvm.datasets, tvd.folder = tvd, tvf
+    tvf.default_loader = lambda path: (_ for _ in ()).throw(RuntimeError("image loading is outside the stub's scope"))
+    tvf.IMG_EXTENSIONS = (".jpg", ".jpeg", ".png", ".webp")
+    for n in ("Compose", "Lambda", "Resize", "CenterCrop", "ToTensor", "Normalize", "RandomHorizontalFlip", "RandomCrop"):
+        setattr(tvt, n, type(n, (), {"__init__": lambda self, *a, **k: None}))
+    tff = _module("torchvision.transforms.functional")
+    tvt.functional = tff
+    tff.InterpolationMode = type("InterpolationMode", (), {"BICUBIC": "bicubic", "LANCZOS": "lanczos", "BILINEAR": "bilinear"})
+    dfs = _module("diffusers")
+    dfu = _module("diffusers.utils")
+    dft = _module("diffusers.utils.torch_utils")
+    dfs.utils, dfu.torch_utils = dfu, dft
+    dft.randn_tensor = lambda shape, generator=None, device=None, dtype=None: torch.randn(tuple(shape), generator=generator, device=device, dtype=dtype)
+    for n in ("AutoencoderKL", "DPMSolverMultistepScheduler", "Transformer2DModel", "PixArtAlphaPipeline", "PixArtSigmaPipeline"):
+        setattr(dfs, n, type(n, (), {}))
     if REFERENCE_ROOT not in sys.path:
         sys.path.insert(0, REFERENCE_ROOT)
 

@@ -1,0 +1,60 @@
+"""Learning-rate schedules and batch-size scaling of the reference's training loop, as host scalars: the fused optimizers take `lr` as a
+plain float per step (no parameter groups to walk), so a schedule is a pure function of the step count.
+
+  * `auto_scale_lr`  - reference diffusion/utils/optimizer.py:18-28 (`auto_lr = dict(rule='sqrt'|'linear')`, base batch 256; the effective
+    batch is train_batch_size x world_size x gradient_accumulation_steps, train_scripts/train.py:448-452)
+  * `LRSchedule`     - reference diffusion/utils/lr_scheduler.py:10-40: 'constant' (diffusers get_constant_schedule_with_warmup: linear
+    warm-up over num_warmup_steps, then 1), 'cosine' (get_cosine_schedule_with_warmup) and 'cosine_decay_to_constant' (lines 43-88).
+    `step()` is called once per optimizer step, like `lr_scheduler.step()` at train.py:184; state = the step count (checkpointed).
+"""
+import math
+
+
+def auto_scale_lr(effective_bs, base_lr, rule="linear", base_batch_size=256):
+    if rule not in ("linear", "sqrt"):
+        raise ValueError(f"auto_lr rule must be 'linear' or 'sqrt', got {rule!r}")
+    ratio = math.sqrt(effective_bs / base_batch_size) if rule == "sqrt" else effective_bs / base_batch_size
+    return base_lr * ratio, ratio
+
+
+class LRSchedule:
+    def __init__(self, base_lr, schedule="constant", num_warmup_steps=0, num_training_steps=None, lr_scale_ratio=1.0, num_decay=0.667,
+                 num_cycles=0.5):
+        if schedule not in ("constant", "cosine", "cosine_decay_to_constant"):
+            raise RuntimeError(f"Unrecognized lr schedule {schedule}.")          # same error as lr_scheduler.py:39
+        if schedule != "constant" and not num_training_steps:
+            raise ValueError(f"lr schedule {schedule!r} needs num_training_steps")
+        self.base_lr, self.schedule = base_lr, schedule
+        self.warmup, self.total = int(num_warmup_steps), num_training_steps
+        self.final = 1.0 / lr_scale_ratio
+        self.num_decay, self.num_cycles = num_decay, num_cycles
+        self.last_step = 0
+
+    def factor(self, step):
+        if step < self.warmup:
+            return float(step) / float(max(1, self.warmup))
+        if self.schedule == "constant":
+            return 1.0
+        if self.schedule == "cosine":
+            prog = float(step - self.warmup) / float(max(1, self.total - self.warmup))
+            return max(0.0, 0.5 * (1.0 + math.cos(math.pi * float(self.num_cycles) * 2.0 * prog)))
+        decay_steps = int(self.total * self.num_decay)
+        if step > decay_steps:
+            return self.final
+        prog = float(step - self.warmup) / float(max(1, decay_steps - self.warmup))
+        return max(0.0, 0.5 * (1.0 + math.cos(math.pi * float(self.num_cycles) * 2.0 * prog))) * (1 - self.final) + self.final
+
+    @property
+    def lr(self):
+        """learning rate of the NEXT optimizer step (torch LambdaLR semantics: lr after k scheduler steps = base * factor(k))"""
+        return self.base_lr * self.factor(self.last_step)
+
+    def step(self):
+        self.last_step += 1
+        return self.lr
+
+    def state_dict(self):
+        return {"last_step": self.last_step, "base_lr": self.base_lr}
+
+    def load_state_dict(self, sd):
+        self.last_step = int(sd.get("last_step", sd.get("last_epoch", 0)))     # 'last_epoch' = torch LambdaLR's name for the same counter
