@@ -217,7 +217,8 @@ def main():
     assert world == a.gpus, f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {a.gpus}"
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    use_pg = world > 1 or "RANK" in os.environ            # under torch.distributed.run a one-rank job still builds its RCCL group
+    if use_pg:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
 
@@ -261,7 +262,7 @@ def main():
         return loss
 
     def barrier():
-        if world > 1:
+        if use_pg:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -273,7 +274,7 @@ def main():
         loss = step()
     barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if use_pg:
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = tt.item()
@@ -290,7 +291,7 @@ def main():
             "config": {"workload": f"PixArt-Sigma-XL/2 {a.image_size}px training step (fwd+bwd+clip+{'CAME' if a.optimizer == 'came' else 'AdamW'}), batch {B}/GPU, L=300 text tokens, "
                                    f"DP={world} RCCL all-reduce", "model": "PixArtMS_XL_2", "global_batch": B * world, "seq_len": N,
                        "parallelism": f"dp{world}", "grad_checkpoint": bool(a.grad_checkpoint), "optimizer": a.optimizer},
-            "images_per_s": B * world / sec_per_step, "final_loss": loss_v,
+            "images_per_s": B * world / sec_per_step, "final_loss": loss_v, "process_group": "nccl" if use_pg else None,
             **({"loss_scale": scaler.value, "steps_skipped": scaler.steps_skipped} if scaler is not None else {}),
             "step_tflops_per_gpu": flops_step / sec_per_step / 1e12,
         }
@@ -326,7 +327,7 @@ def main():
             out["cpu_baseline"] = {"value": 1.0 / (cdt * B), "unit": "steps/s", "cores": cores, "kind": "port",
                                    "sample": desc + f"; x{B} in batch to the {a.image_size}px batch-{B} step (samples are independent)"}
         print(json.dumps(out))
-    if world > 1:
+    if use_pg:
         dist.destroy_process_group()
 
 

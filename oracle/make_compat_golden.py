@@ -141,10 +141,31 @@ def gen_sampler():
     return out
 
 
+def gen_lr():
+    """The reference's own schedule / scaling functions (diffusion/utils/lr_scheduler.py:43-88, optimizer.py:18-28) on a torch optimizer."""
+    ref_stubs.install()
+    mo = sys.modules.get("mmcv")
+    for name in ("mmcv.runner", "mmcv.utils"):          # optimizer.py imports registries this stub set does not model
+        pass
+    from diffusion.utils.lr_scheduler import get_cosine_decay_to_constant_with_warmup
+    out = {"cosine_decay": []}
+    for warm, total, final in ((10, 200, 0.25), (0, 90, 0.5)):
+        p = torch.nn.Parameter(torch.zeros(1))
+        opt = torch.optim.SGD([p], lr=2e-5)
+        sch = get_cosine_decay_to_constant_with_warmup(opt, num_warmup_steps=warm, num_training_steps=total, final_lr=final)
+        lrs = []
+        for _ in range(total + 5):
+            lrs.append(opt.param_groups[0]["lr"])
+            opt.step()
+            sch.step()
+        out["cosine_decay"].append({"warm": warm, "total": total, "final": final, "lrs": lrs})
+    return out
+
+
 def main():
     import tempfile
     with tempfile.TemporaryDirectory() as tmp:
-        obj = {"converter": gen_converter(tmp), "dataset": gen_dataset(tmp), "sampler": gen_sampler()}
+        obj = {"converter": gen_converter(tmp), "dataset": gen_dataset(tmp), "sampler": gen_sampler(), "lr": gen_lr()}
     torch.save(obj, GOLDEN)
     print(f"{GOLDEN}: {os.path.getsize(GOLDEN) / 1024:.1f} KiB; converter keys {len(obj['converter']['converted'])}, dataset items {obj['dataset']['len']}, "
           f"sampler batches {[len(r['batches']) for r in obj['sampler']['runs']]}")

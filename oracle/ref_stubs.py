@@ -222,7 +222,8 @@ def install():
     dft = _module("diffusers.utils.torch_utils")
     dfs.utils, dfu.torch_utils = dfu, dft
     dft.randn_tensor = lambda shape, generator=None, device=None, dtype=None: torch.randn(tuple(shape), generator=generator, device=device, dtype=dtype)
-    for n in ("AutoencoderKL", "DPMSolverMultistepScheduler", "Transformer2DModel", "PixArtAlphaPipeline", "PixArtSigmaPipeline"):
+    for n in ("AutoencoderKL", "DPMSolverMultistepScheduler", "Transformer2DModel", "PixArtAlphaPipeline", "PixArtSigmaPipeline",
+              "get_cosine_schedule_with_warmup", "get_constant_schedule_with_warmup"):
         setattr(dfs, n, type(n, (), {}))
     if REFERENCE_ROOT not in sys.path:
         sys.path.insert(0, REFERENCE_ROOT)

@@ -11,6 +11,8 @@ Replaces what the reference gets from accelerate's DDP wrapper + torch AdamW (tr
   * averaging (1/world), global-norm clipping and AdamW are one pass: sumsq -> clip_coef (device scalar) -> adamw_step,
     which also refreshes the bf16 shadow weights the GEMMs read.  No host synchronisation anywhere in the step.
 """
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -32,8 +34,11 @@ class GradReducer:
         self.store = store
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+        # PXA_DP_FORCE_COLLECTIVES=1: run the bucket collectives even in a one-rank group (a real RCCL all-reduce of every bucket from
+        # the engine's hooks on a single GPU - the only multi-GPU code path a one-GPU box can execute; tests/test_dp_nccl_gpu.py)
+        self.active = self.world > 1 or (dist.is_available() and dist.is_initialized() and os.environ.get("PXA_DP_FORCE_COLLECTIVES") == "1")
         self.bucket_dtype = bucket_dtype
-        self.stage = torch.empty(store.total, dtype=bucket_dtype, device=store.device) if bucket_dtype not in (None, torch.float32) and self.world > 1 else None
+        self.stage = torch.empty(store.total, dtype=bucket_dtype, device=store.device) if bucket_dtype not in (None, torch.float32) and self.active else None
         self.pending = []
         self.launched = []          # bucket names in launch order (the order every rank must agree on)
         self._sync = True
@@ -54,7 +59,7 @@ class GradReducer:
 
     def on_group_ready(self, name):
         """Engine hook: gradients of parameter group `name` are final for this backward."""
-        if self.world == 1 or not self._sync or name not in self.store.groups:
+        if not self.active or not self._sync or name not in self.store.groups:
             return
         if name in self.launched:
             raise RuntimeError(f"gradient bucket {name!r} was completed twice before optimizer.step(): wrap the non-final micro-steps "
@@ -70,7 +75,7 @@ class GradReducer:
 
     def finish(self):
         """Reduce whatever was not launched from hooks (the 'cond' group, or everything if hooks are unused) and wait."""
-        if self.world > 1:
+        if self.active:
             launched = set(self.launched)
             for name in self.store.groups:
                 if name not in launched:
@@ -176,10 +181,21 @@ class FusedAdamW:
         else:
             ops.clip_coef(self.sumsq, self.coef, mx, inv_world)
 
+    def _layout(self):
+        """(name, offset, shape) of every parameter in the flat buffers: saved with the state and checked on load, so a changed
+        parameter order / alignment cannot silently shift the moments onto other parameters."""
+        st = self.store
+        return [(n, st.offset[n], tuple(st.shape[n])) for n in st.names]
+
+    def _check_layout(self, sd):
+        if "layout" in sd and [tuple(x) if not isinstance(x, tuple) else x for x in sd["layout"]] != self._layout():
+            raise RuntimeError("optimizer state was saved for a different flat parameter layout (parameter set, order or alignment changed)")
+
     def state_dict(self):
-        return {"m": self.m, "v": self.v, "t": self.t, "lr": self.lr}
+        return {"m": self.m, "v": self.v, "t": self.t, "lr": self.lr, "layout": self._layout()}
 
     def load_state_dict(self, sd):
+        self._check_layout(sd)
         self.m.copy_(sd["m"])
         self.v.copy_(sd["v"])
         self.t, self.lr = sd["t"], sd.get("lr", self.lr)
@@ -273,9 +289,10 @@ class FusedCAME(FusedAdamW):
         call("pxa_came_step", a)                        # refreshes the bf16 shadow itself (no parameter version is bumped)
 
     def state_dict(self):
-        return {k: getattr(self, k) for k in ("m", "sq_row", "sq_col", "res_row", "res_col", "nf_sq")} | {"t": self.t, "lr": self.lr}
+        return {k: getattr(self, k) for k in ("m", "sq_row", "sq_col", "res_row", "res_col", "nf_sq")} | {"t": self.t, "lr": self.lr, "layout": self._layout()}
 
     def load_state_dict(self, sd):
+        self._check_layout(sd)
         for k in ("m", "sq_row", "sq_col", "res_row", "res_col", "nf_sq"):
             getattr(self, k).copy_(sd[k])
         self.t, self.lr = sd["t"], sd.get("lr", self.lr)

@@ -114,6 +114,11 @@ class ParamStore:
     def owns(self, p, name):
         return p.data_ptr() == self.master.data_ptr() + 4 * self.offset[name] and p.device == self.master.device
 
+    def owns_all(self, named_params):
+        """True iff EVERY parameter still lives at its offset of this store's master buffer (a stand-alone block engine, .to(),
+        or an assignment to p.data re-points parameters one by one; checking only the first one would keep reading stale copies)."""
+        return all(n in self.offset and self.owns(p, n) for n, p in named_params)
+
     def refresh_shadow(self, force=False):
         """Re-cast master -> bf16 shadow if any parameter was modified by torch ops since the last cast (the fused AdamW
         kernel refreshes the shadow itself and does not bump versions)."""

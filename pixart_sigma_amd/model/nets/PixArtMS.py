@@ -199,8 +199,9 @@ class PixArtMSBlock(nn.Module):
 
     def _engine_for_standalone(self):
         dev = self.scale_shift_table.device
-        if self._standalone is None or self._standalone.S.device != dev:
-            named = [("blocks.0." + n, p) for n, p in self.named_parameters()]
+        named0 = [("blocks.0." + n, p) for n, p in self.named_parameters()]
+        if self._standalone is None or self._standalone.S.device != dev or not self._standalone.S.owns_all(named0):
+            named = named0
             named = [t for t in named if not t[0].endswith(".bias")] + [t for t in named if t[0].endswith(".bias")]
             store = ParamStore(named, dev)
             a = self.attn
@@ -332,8 +333,7 @@ class PixArtMS(nn.Module):
 
     def _prepare(self, device):
         named = self._ordered_named_params()
-        first_name, first_p = named[0]
-        if self._store is None or self._store.device != device or not self._store.owns(first_p, first_name):
+        if self._store is None or self._store.device != device or not self._store.owns_all(named):
             if any(p.dtype != F32 for _, p in named):
                 raise RuntimeError("pixart_sigma_amd keeps fp32 master weights (bf16 shadows are maintained internally); "
                                    "do not call .half()/.bfloat16() on the model")

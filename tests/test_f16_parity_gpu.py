@@ -52,6 +52,6 @@ def test_f16_operand_build_vae_parity():
     res = json.loads(r.stdout.strip().splitlines()[-1])
     print("\n", res)
     assert res["operand"] == "f16"
-    for px in ("64px", "128px"):
+    for px in ("64px", "128px", "512px_b2"):
         for name, e in res[px].items():
             assert e < F16_VAE_TOL, (px, name, e)

@@ -1,6 +1,8 @@
 """CPU tests of the host-side logic around the HIP path: the diffusion loss and DPM-Solver loop (run here with the
 oracle denoiser as the model callable, against the reference-generated goldens), the positional table, the registry,
 state-dict compatibility, and the flat parameter store."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -154,3 +156,27 @@ def test_came_tables_cover_every_parameter_exactly_once():
     assert all(a[0] + a[1] == b[0] for a, b in zip(rows, rows[1:])) and rows[-1][0] + rows[-1][1] == tb["n_row"]
     assert len(tb["col_inv_r"]) == tb["n_col"] and tb["n_rm"] == sum(t["batch"] for t in T if t["factored"])
     assert tb["n_nf"] == 300 + 70000 and tb["col_inv_r"][T[0]["col_off"]] == 1.0 / 300
+
+
+def test_store_notices_parameters_moved_out_by_a_standalone_block(monkeypatch):
+    """a block used stand-alone re-points ITS parameters into a private flat store; the model's store must notice (every
+    parameter is checked, not just the first) and rebuild from the current values instead of training stale copies."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import fake_ops
+    from pixart_sigma_amd import engine
+    monkeypatch.setattr(engine, "ops", fake_ops)
+    from pixart_sigma_amd.model.nets.PixArtMS import PixArtMS
+    m = PixArtMS(depth=2, input_size=8, model_max_length=8)
+    m._prepare(torch.device("cpu"))
+    st = m._store
+    assert st.owns_all(m._ordered_named_params())
+    blk = m.blocks[1]
+    blk._engine_for_standalone()                                  # moves blocks.1.* into the block's own store
+    assert st.owns(m.x_embedder.proj.weight, "x_embedder.proj.weight")      # the first parameter alone would not have shown it
+    assert not st.owns_all(m._ordered_named_params())
+    with torch.no_grad():
+        blk.attn.proj.weight.fill_(0.25)
+    m._prepare(torch.device("cpu"))                               # what the next forward does
+    assert m._store is not st and m._store.owns_all(m._ordered_named_params())
+    assert float(m._store.f("blocks.1.attn.proj.weight").mean()) == 0.25

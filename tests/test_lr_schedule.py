@@ -1,0 +1,72 @@
+"""Learning-rate plumbing of the training entry point: schedule values equal torch's LambdaLR running the reference's /
+diffusers' lambdas, auto-lr equals reference diffusion/utils/optimizer.py:18-28, state round-trips."""
+import math
+
+import torch
+
+from pixart_sigma_amd.lr_schedule import LRSchedule, auto_scale_lr
+
+
+def _torch_lrs(lmbda, base, n):
+    p = torch.nn.Parameter(torch.zeros(1))
+    opt = torch.optim.SGD([p], lr=base)
+    sch = torch.optim.lr_scheduler.LambdaLR(opt, lmbda)
+    out = []
+    for _ in range(n):
+        out.append(opt.param_groups[0]["lr"])
+        opt.step()
+        sch.step()
+    return out
+
+
+def test_constant_with_warmup_equals_diffusers_lambda():
+    warm = 500          # configs/PixArt_xl2_internal.py:50
+    s = LRSchedule(2e-5, "constant", num_warmup_steps=warm)
+    ref = _torch_lrs(lambda k: float(k) / float(max(1.0, warm)) if k < warm else 1.0, 2e-5, 620)      # diffusers get_constant_schedule_with_warmup
+    mine = []
+    for _ in range(620):
+        mine.append(s.lr)
+        s.step()
+    assert mine == ref and mine[0] == 0.0 and mine[warm] == 2e-5
+
+
+def test_cosine_equals_diffusers_lambda():
+    warm, total = 10, 100
+    s = LRSchedule(1e-4, "cosine", num_warmup_steps=warm, num_training_steps=total)
+
+    def lam(k):
+        if k < warm:
+            return float(k) / float(max(1, warm))
+        prog = float(k - warm) / float(max(1, total - warm))
+        return max(0.0, 0.5 * (1.0 + math.cos(math.pi * 0.5 * 2.0 * prog)))
+    ref = _torch_lrs(lam, 1e-4, total)
+    assert [s.base_lr * s.factor(k) for k in range(total)] == ref
+
+
+def test_cosine_decay_to_constant_equals_reference(golden):
+    for case in golden("compat")["lr"]["cosine_decay"]:
+        s = LRSchedule(2e-5, "cosine_decay_to_constant", num_warmup_steps=case["warm"], num_training_steps=case["total"], lr_scale_ratio=1.0 / case["final"])
+        mine = []
+        for _ in case["lrs"]:
+            mine.append(s.lr)
+            s.step()
+        assert all(abs(a - b) <= 1e-12 * max(abs(b), 1e-30) + 1e-18 for a, b in zip(mine, case["lrs"])), case["warm"]
+
+
+def test_auto_scale_lr_rules():
+    # reference: lr *= sqrt(effective_bs / 256) or effective_bs / 256, effective_bs = train_batch_size * world * accumulation
+    lr, r = auto_scale_lr(16 * 8 * 1, 2e-5, rule="sqrt")
+    assert r == math.sqrt(128 / 256) and lr == 2e-5 * r
+    lr, r = auto_scale_lr(64 * 8 * 2, 1e-4, rule="linear")
+    assert r == 4.0 and lr == 4e-4
+
+
+def test_state_roundtrip_and_reference_checkpoint_key():
+    s = LRSchedule(2e-5, "constant", num_warmup_steps=100)
+    for _ in range(37):
+        s.step()
+    t = LRSchedule(2e-5, "constant", num_warmup_steps=100)
+    t.load_state_dict(s.state_dict())
+    assert t.lr == s.lr and t.last_step == 37
+    t.load_state_dict({"last_epoch": 50})          # torch LambdaLR state of a reference checkpoint
+    assert t.last_step == 50 and t.lr == 1e-5

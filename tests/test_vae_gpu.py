@@ -166,3 +166,16 @@ def test_autoencoder_decode_and_encode_match_oracle(ops, cfg, B, H, W):
     assert dist.sample(generator=g).shape == mean.shape
     half = vae.decode(z.cuda().half()).sample                            # the reference calls it with fp16 latents (inference.py:136)
     assert half.dtype == torch.float16 and rel_l2(half.float().cpu(), want) < MODEL_TOL
+
+
+def test_full_architecture_decode_512px_batch2(ops):
+    """BASELINE config 5's VAE half at its real shape: full SD / SDXL architecture, latent (2, 4, 64, 64) -> (2, 3, 512, 512): the persistent
+    implicit-conv kernel with 256-wide tiles at every resolution of the decoder, GroupNorm over 512^2 pixels.  fp32 restatement on the GPU."""
+    ref, vae = _pair(dict(), seed=5)
+    z = rnd(2, 4, 64, 64, seed=6)
+    with torch.no_grad():
+        want = ref.cuda().decode(z)
+    got = vae.decode(z).sample
+    e = rel_l2(got, want)
+    print(f"\n512px batch-2 decode rel-L2 vs fp32 restatement {e:.2e} (bound {MODEL_TOL:.1e}, bf16 operands)")
+    assert got.shape == (2, 3, 512, 512) and e < MODEL_TOL

@@ -29,4 +29,10 @@ for px in (64, 128):
         want, (mean, logvar) = ref.decode(z), ref.encode_moments(x)
     d = vae.encode(x.cuda()).latent_dist
     out[f"{px}px"] = {"decode": rel(vae.decode(z.cuda()).sample, want), "encode_mean": rel(d.mean, mean), "encode_logvar": rel(d.logvar, logvar)}
+# BASELINE config 5's VAE shape: full-architecture 512px decode, batch 2, against the fp32 restatement evaluated on the same GPU
+z = torch.randn(2, 4, 64, 64, generator=g)
+ref = ref.cuda()
+with torch.no_grad():
+    want = ref.decode(z.cuda()).cpu()
+out["512px_b2"] = {"decode": rel(vae.decode(z.cuda()).sample, want)}
 print(json.dumps(out))
