@@ -587,6 +587,12 @@ __device__ __forceinline__ void wait_vm_upto(int n) {      // n (wave-uniform) i
   else wait_vmcnt<0>();
 }
 #define PXA_SB() __builtin_amdgcn_sched_barrier(0)
+#ifndef GEMM_ABL
+#define GEMM_ABL 0          // ablation bits (tools/build_variant.py; wrong results on purpose): 1 = every k-unit re-fetches the item's FIRST unit (cache-hot DMA)
+#endif
+#ifndef GEMM_PHASE16
+#define GEMM_PHASE16 -1     // matrix phases per k-unit: -1 = per layout (below), 0 = two 8-MFMA phases everywhere, 1 = one 16-MFMA phase everywhere
+#endif
 
 // =====================================================================================================================
 // Persistent ping-pong kernel for the big token GEMMs with bf16 outputs (NT forward, NN dX): one 512-thread workgroup per CU
@@ -671,6 +677,10 @@ template <int LAYOUT, int EPI, int RM, bool SEG = false>
 __global__ __launch_bounds__(512) void gemm_pers_kernel(GemmParams p) {
   constexpr bool A_KC = (LAYOUT != 2), B_KC = (LAYOUT == 0);
   constexpr int NW = 8, TM = 4, TN = 2, BKT = 32, H1 = 2;
+  // One 16-MFMA matrix phase per k-unit (2 barriers) instead of two 8-MFMA phases (4 barriers) wherever an operand is read through the
+  // LDS transpose (NN: B, TN: both): those read phases are twice as long in instructions and did not fit under the partner's 8 MFMAs.
+  // Measured at M = 65,536 (profiles/r02_gemm_phase16.txt): TN +18-20 %, NN +3-6 %, NT +-0 (keeps the finer interleave).
+  constexpr bool PH16 = GEMM_PHASE16 < 0 ? (LAYOUT != 0) : (GEMM_PHASE16 != 0);
   constexpr int UNIT = 40960;                          // ring slot: A image at 0 (16 KiB; 32 KiB paired), B image behind it (16 KiB; 8 KiB paired)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), wm = wave >> 2, wn = wave & 3, hi = lane >> 5;
@@ -764,7 +774,9 @@ __global__ __launch_bounds__(512) void gemm_pers_kernel(GemmParams p) {
   auto piece = [&](int i, int slot) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)pp[i],
                                      (__attribute__((address_space(3))) void*)(smem + slot * UNIT + dof[i]), 16, 0, 0);
+#if !(GEMM_ABL & 1)
     pp[i] += st[i];
+#endif
   };
   int seg_left = 0;                                    // SEG: k elements left in the A segment the next first-half issue reads
   int tap_kx = 0, tap_ky = 0, tap_half = 0;            // SEG, tap-interleaved order: position of the next first-half issue
@@ -814,7 +826,7 @@ __global__ __launch_bounds__(512) void gemm_pers_kernel(GemmParams p) {
     s_lo = s_hi = 0;
     if (SEG) { seg_left = p.k_seg; tap_kx = tap_ky = tap_half = 0; }
     issue_lo(); issue_hi(); issue_lo(); issue_hi();
-    if (nk_pf > 2) issue_lo();
+    if (nk_pf > 2) { issue_lo(); if (PH16) issue_hi(); }      // PH16: three whole units ahead; else 2.5
   };
   prefetch();
 
@@ -840,8 +852,41 @@ __global__ __launch_bounds__(512) void gemm_pers_kernel(GemmParams p) {
     __builtin_amdgcn_s_barrier();
     if (DYN) nxt = receive();
     if (late) __builtin_amdgcn_s_barrier();            // stagger the second wave of each SIMD by one barrier interval
+    // one k-unit = ONE read phase + ONE matrix phase of 16 MFMAs (two barriers per unit instead of four: half as many hand-overs of the
+    // matrix pipe between the two waves of a SIMD).  R: all 12 fragment reads of unit t, the 4 (5 / 3) LDS-DMA pieces of unit t+3, the
+    // counted wait (unit t+1 landed; t+2, t+3 in flight) and lgkmcnt(0) - reads are COMPLETE at the barrier, so one barrier separates
+    // the late group's last read of a ring slot from its refill by the early group.  REM = units that follow this one.
+    auto unit16 = [&](int t, auto rem_c, auto th_c) {
+      constexpr int REM = decltype(rem_c)::value, TH = decltype(th_c)::value;   // 2 * TH row tiles (4; 2 for half items)
+      const char* sA = smem + (t & 3) * UNIT;
+      const char* sB = sA + boff;
+      bf16x8 af[2][2 * TH], bf[2][TN];
+#pragma unroll
+      for (int ks = 0; ks < 2; ks++)
+#pragma unroll
+        for (int j = 0; j < TN; j++) bf[ks][j] = frag_rt<B_KC>(sB, b_rb + j * 32, ks, lane, rlb);
+#pragma unroll
+      for (int ks = 0; ks < 2; ks++)
+#pragma unroll
+        for (int i = 0; i < 2 * TH; i++) af[ks][i] = frag_rt<A_KC>(sA, a_rb + i * 32, ks, lane, rla);
+      if (REM >= 3) { issue_lo(); issue_hi(); }
+      if (REM >= 3) { if (vtc) wait_vmcnt<10>(); else if (TH == 1) wait_vmcnt<6>(); else wait_vmcnt<8>(); }
+      else if (REM == 2) { if (vtc) wait_vmcnt<5>(); else if (TH == 1) wait_vmcnt<3>(); else wait_vmcnt<4>(); }
+      else if (REM == 1) wait_vmcnt<0>();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      PXA_SB(); __builtin_amdgcn_s_barrier(); PXA_SB();
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int ks = 0; ks < 2; ks++)
+#pragma unroll
+        for (int i = 0; i < 2 * TH; i++)
+#pragma unroll
+          for (int j = 0; j < TN; j++) acc[i][j] = mfma32(bf[ks][j], af[ks][i], acc[i][j]);
+      __builtin_amdgcn_s_setprio(0);
+      PXA_SB(); __builtin_amdgcn_s_barrier(); PXA_SB();
+    };
     // one k-unit = two phases; REM = units that follow it (3 = steady state: both DMA halves issued, 6-7 instructions left in flight)
-    auto unit = [&](int t, auto rem_c, auto th_c) {
+    auto unit8 = [&](int t, auto rem_c, auto th_c) {
       constexpr int REM = decltype(rem_c)::value, TH = decltype(th_c)::value;   // TH row tiles per phase (2; 1 for half items)
       const char* sA = smem + (t & 3) * UNIT;
       const char* sB = sA + boff;
@@ -876,6 +921,9 @@ __global__ __launch_bounds__(512) void gemm_pers_kernel(GemmParams p) {
         __builtin_amdgcn_s_setprio(0);
         PXA_SB(); __builtin_amdgcn_s_barrier(); PXA_SB();
       }
+    };
+    auto unit = [&](int t, auto rem_c, auto th_c) {
+      if constexpr (PH16) unit16(t, rem_c, th_c); else unit8(t, rem_c, th_c);
     };
     auto run_units = [&](auto th_c) {
       int t = 0;

@@ -16,6 +16,13 @@ import sys
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+# The reference samples with fp16 weights for both the denoiser and the VAE (scripts/inference.py:191-196 `weight_dtype = torch.float16`),
+# so this entry point defaults to the fp16-operand build of the kernels (forward parity <= 1e-3 incl. the VAE at 1.5e-3..2.0e-3; the bf16
+# build sits at 3e-3 / 1.4e-2).  The operand type is a per-process choice made before the package is imported: --dtype bf16 overrides.
+_dt = sys.argv[sys.argv.index("--dtype") + 1] if "--dtype" in sys.argv[:-1] else "fp16"
+if _dt not in ("fp16", "bf16"):
+    raise SystemExit(f"--dtype must be fp16 or bf16, got {_dt!r}")
+os.environ["PXA_OPERAND_DTYPE"] = "f16" if _dt == "fp16" else "bf16"
 from pixart_sigma_amd import DPMS, PixArtMS_XL_2  # noqa: E402
 
 
@@ -41,6 +48,7 @@ def get_args():
     p.add_argument("--kv_compress_scale", default=2, type=int)
     p.add_argument("--kv_compress_layers", default="14-27")
     p.add_argument("--synthetic", action="store_true", help="random caption features (plumbing check without T5 weights)")
+    p.add_argument("--dtype", default="fp16", choices=["fp16", "bf16"], help="MFMA operand type of the whole process (reference: fp16)")
     return p.parse_args()
 
 

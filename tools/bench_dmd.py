@@ -8,6 +8,8 @@ import os
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+# like the reference app (fp16 pipeline, app/app_pixart_dmd.py) the default is the fp16-operand build; --dtype bf16 selects the other library
+os.environ["PXA_OPERAND_DTYPE"] = "bf16" if ("--dtype" in sys.argv[:-1] and sys.argv[sys.argv.index("--dtype") + 1] == "bf16") else "f16"
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
@@ -21,6 +23,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=64)
     ap.add_argument("--iters", type=int, default=3)
+    ap.add_argument("--dtype", choices=["fp16", "bf16"], default="fp16")
     a = ap.parse_args()
     from oracle.vae_ref import AutoencoderKLRef, randomize_
     B, lat, L = a.batch, 64, 120
