@@ -301,7 +301,7 @@ def main():
             ks = kernel_rooflines(B, N)
             # dominant kernel of the step by total time (profiles/: attn_bwd_dkv_kernel, 56 launches, ~17 % of the step)
             dom = ks["attn_bwd_dkv_kernel"]
-            traffic, tsrc = pmc_traffic("attn_bwd_dkv_kernel", B * H * (N // 128))
+            traffic, tsrc = pmc_traffic("attn_bwd_dkv_kernel", N // 128)     # x-dimension of the launch grid: 32 key blocks = the self-attention launch
             roof = {"bound": "mfma", "kernel": "attn_bwd_dkv_kernel (self-attention, B16 H16 N4096 d72)", "achieved": dom["tflops"], "peak": MFMA_PEAK / 1e12,
                     "unit": "TFLOP/s", "frac": dom["frac"], "traffic": traffic, "traffic_source": tsrc,
                     "flops_per_launch": dom["flops"], "ms_per_launch": dom["seconds"] * 1e3,

@@ -188,6 +188,18 @@ int pxa_clip_coef_scaled(const float* sumsq, float* out2, float max_norm, float 
 int pxa_adamw_step_scaled(float* p, const float* g, float* m, float* v, void* p_bf16, long n, float lr, float beta1, float beta2,
                           float eps, float weight_decay, const float* gscale, const float* scaler, hipStream_t stream);
 
+/* ---------------------------------------------------------------------------------------------- fused diffusion loss
+ * GaussianDiffusion.training_losses for IDDPM(learn_sigma=True, pred_sigma=True) = MSE + VB with the learned-range variance
+ * (diffusion/model/gaussian_diffusion.py:744-855, :711-742, :280-361; diffusion_utils.py:10-88).  model_out (B, 2C, H, W), x0 / noise
+ * (B, C, H, W), all fp32 contiguous; coef8: per sample the 8 schedule entries at its timestep { sqrt(abar), sqrt(1-abar), posterior_mean_coef1,
+ * posterior_mean_coef2, posterior_log_variance_clipped, log(beta), sqrt(1/abar), sqrt(1/abar - 1) }; t_is_zero: 1 where t == 0 (decoder NLL
+ * instead of the KL).  fwd: mse[b], vb[b] (bits per dimension; loss = mse + vb).  bwd: d_model_out = g_mse[b] d mse_b + g_vb[b] d vb_b with respect to
+ * model_out (eps half from the MSE only - the VB term sees a detached eps -, variance half from the VB only).  H*W % 4 == 0.            */
+int pxa_iddpm_loss_fwd(const float* model_out, const float* x0, const float* noise, const float* coef8, const int* t_is_zero, int B, int C,
+                       int HW, float* mse, float* vb, hipStream_t stream);
+int pxa_iddpm_loss_bwd(const float* model_out, const float* x0, const float* noise, const float* coef8, const int* t_is_zero, int B, int C,
+                       int HW, const float* g_mse, const float* g_vb, float* d_model_out, hipStream_t stream);
+
 /* ---------------------------------------------------------------------------------------------- CAME optimizer
  * came_pytorch.CAME.step() (un-vendored dependency; the reference's CAMEWrapper subclasses it unchanged:
  * diffusion/utils/optimizer.py:15,242-246; used by every PixArt-Sigma config, e.g.

@@ -6,8 +6,27 @@ reference's per-call numpy->device table copies (`_extract_into_tensor`, gaussia
 schedule tables cached on the device.  Supported configuration = what train_scripts/train.py builds:
 IDDPM(str(N), learn_sigma=True, pred_sigma=True, snr=False) -> EPSILON mean, LEARNED_RANGE variance, MSE loss.
 """
+import os
+
 import numpy as np
 import torch
+
+
+class _FusedLoss(torch.autograd.Function):
+    """MSE + VB terms of training_losses as one HIP launch each way (csrc/loss.hip).  Only model_output is differentiable."""
+
+    @staticmethod
+    def forward(ctx, out, x0, noise, coef8, tzero):
+        from .. import ops
+        out = out.contiguous()
+        ctx.save_for_backward(out, x0, noise, coef8, tzero)
+        return ops.iddpm_loss_fwd(out, x0, noise, coef8, tzero)
+
+    @staticmethod
+    def backward(ctx, g_mse, g_vb):
+        from .. import ops
+        out, x0, noise, coef8, tzero = ctx.saved_tensors
+        return ops.iddpm_loss_bwd(out, x0, noise, coef8, tzero, g_mse.contiguous().float(), g_vb.contiguous().float()), None, None, None, None
 
 
 def get_named_beta_schedule(schedule_name, num_diffusion_timesteps):
@@ -94,6 +113,14 @@ class SpacedDiffusion:
         out = model(x_t, timestep=T["tmap"][t].to(t.dtype), **model_kwargs)       # _WrappedModel, respace.py:128-134
         B, C = x_t.shape[:2]
         assert out.shape == (B, C * 2, *x_t.shape[2:])
+        if out.is_cuda and not skip_noise and out.dtype == torch.float32 and x_t[0, 0].numel() % 4 == 0 and os.environ.get("PXA_FUSED_LOSS", "1") != "0":
+            # the same arithmetic as below in one HIP launch per direction (csrc/loss.hip); the torch expressions remain the host-side
+            # statement of the objective (CPU tests, PXA_FUSED_LOSS=0 for A/B)
+            if "coef8" not in T:
+                T["coef8"] = torch.stack([T[k].float() for k in ("sqrt_ac", "sqrt_1mac", "post_c1", "post_c2", "post_logvar", "log_betas",
+                                                                 "sqrt_recip_ac", "sqrt_recipm1_ac")], dim=1).contiguous()
+            mse, vb = _FusedLoss.apply(out, x_start.float().contiguous(), noise.float().contiguous(), T["coef8"][t].contiguous(), (t == 0).to(torch.int32))
+            return {"loss": mse + vb, "mse": mse, "vb": vb}
         eps, var_v = torch.split(out, C, dim=1)
         e = eps.detach()                                                           # vb does not train the mean (line 800)
         true_lv = self._ex(T["post_logvar"], t, nd)

@@ -95,6 +95,8 @@ SIGNATURES = {
     "pxa_clip_coef_scaled": [_P, _P, _F, _F, _P, _F, _F, _I, _P],
     "pxa_adamw_step_scaled": [_P, _P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _P, _P, _P],
     "pxa_came_step": [C.POINTER(CameArgs), _P],
+    "pxa_iddpm_loss_fwd": [_P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P],
+    "pxa_iddpm_loss_bwd": [_P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P],
     "pxa_vae_gn_stats": [_G, _I, _F, _P, _P, _P, _P],
     "pxa_vae_gn_apply": [_G, _P, _P, _P, _P, _I, _I, _I, _G, _P],
     "pxa_vae_im2col3x3": [_G, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P],

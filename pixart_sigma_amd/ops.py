@@ -221,6 +221,20 @@ def kv_pick(src, dst, full_bs, full_ts, B, H, W, Cc, sr, backward=False):
     call("pxa_kv_pick", int(backward), ptr(src), ptr(dst), full_bs, full_ts, B, H, W, Cc, sr)
 
 
+def iddpm_loss_fwd(model_out, x0, noise, coef8, tzero):
+    B, C, H, W = x0.shape
+    mse, vb = torch.empty(B, dtype=F32, device=x0.device), torch.empty(B, dtype=F32, device=x0.device)
+    call("pxa_iddpm_loss_fwd", ptr(model_out), ptr(x0), ptr(noise), ptr(coef8), ptr(tzero), B, C, H * W, ptr(mse), ptr(vb))
+    return mse, vb
+
+
+def iddpm_loss_bwd(model_out, x0, noise, coef8, tzero, g_mse, g_vb):
+    B, C, H, W = x0.shape
+    d = torch.empty_like(model_out)
+    call("pxa_iddpm_loss_bwd", ptr(model_out), ptr(x0), ptr(noise), ptr(coef8), ptr(tzero), B, C, H * W, ptr(g_mse), ptr(g_vb), ptr(d))
+    return d
+
+
 def sumsq(x, out):
     call("pxa_sumsq_f32", ptr(x), x.numel(), ptr(out))
 

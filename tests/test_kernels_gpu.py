@@ -533,3 +533,33 @@ def test_attention_headline_shapes(ops, B, H, Nq, Nk):
     print(f"\n[attention B{B} H{H} Nq{Nq} Nk{Nk}] rel-L2 " + " ".join(f"{n} {e:.2e}" for n, e in errs.items()) + f" (bounds {BF16_TOL:.0e} / {2 * BF16_TOL:.0e})")
     assert errs["o"] < BF16_TOL
     assert max(errs["dq"], errs["dk"], errs["dv"]) < 2 * BF16_TOL
+
+
+# ------------------------------------------------------------------------------------------------ fused diffusion loss
+def test_fused_iddpm_loss_matches_torch_expressions(ops, monkeypatch):
+    """csrc/loss.hip (one launch per direction) against the elementwise torch statement of GaussianDiffusion.training_losses in
+    pixart_sigma_amd/diffusion/iddpm.py (itself pinned to the reference by the CPU golden tests): loss terms and d loss / d model_output,
+    including a t = 0 sample whose x0 covers the three branches of the discretized-Gaussian log-likelihood."""
+    from pixart_sigma_amd import IDDPM
+    diff = IDDPM(str(1000), learn_sigma=True, pred_sigma=True, snr=False)
+    B, C, H, W = 4, 4, 16, 24
+    g = torch.Generator().manual_seed(3)
+    x0 = torch.randn(B, C, H, W, generator=g).cuda()
+    x0[0] = (torch.rand(C, H, W, generator=g) * 2.4 - 1.2).cuda()           # t = 0 sample: values below -0.999, inside, above 0.999
+    noise = torch.randn(B, C, H, W, generator=g).cuda()
+    t = torch.tensor([0, 1, 500, 999]).cuda()
+    fixed = (torch.randn(B, 2 * C, H, W, generator=g) * 0.7).cuda()
+    res = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("PXA_FUSED_LOSS", mode)
+        out = fixed.clone().requires_grad_(True)
+        terms = diff.training_losses(lambda x, timestep, **kw: out, x0, t, noise=noise)
+        w = torch.tensor([0.3, 1.0, 2.0, 0.5]).cuda()
+        (terms["loss"] * w).sum().backward()
+        res[mode] = (terms["mse"].detach(), terms["vb"].detach(), out.grad.clone())
+    for name, a, b in zip(("mse", "vb", "d_out"), res["1"], res["0"]):
+        e = rel_l2(a, b)
+        print(f"fused loss {name}: rel-L2 vs torch expressions {e:.2e}")
+        assert e < 2e-5, name
+    assert (res["1"][2][:, C:].abs().sum() > 0) and (res["1"][2][:, :C].abs().sum() > 0)
+    assert float(res["1"][1][0]) != float(res["0"][1][1])                  # the t = 0 (NLL) sample differs from the KL samples
