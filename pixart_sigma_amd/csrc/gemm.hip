@@ -588,7 +588,10 @@ __device__ __forceinline__ void wait_vm_upto(int n) {      // n (wave-uniform) i
 }
 #define PXA_SB() __builtin_amdgcn_sched_barrier(0)
 #ifndef GEMM_ABL
-#define GEMM_ABL 0          // ablation bits (tools/build_variant.py; wrong results on purpose): 1 = every k-unit re-fetches the item's FIRST unit (cache-hot DMA)
+#define GEMM_ABL 0          // ablation bits (tools/build_variant.py; wrong results on purpose): 1 = every k-unit re-fetches the item's FIRST unit (cache-hot DMA), 2 = no bf16 epilogue
+#endif
+#ifndef GEMM_STORE_OVERLAP
+#define GEMM_STORE_OVERLAP 1   // next item's main loop starts over the draining epilogue stores (counted vmcnt); 0 = wait for them (A/B)
 #endif
 #ifndef GEMM_PHASE16
 #define GEMM_PHASE16 -1     // matrix phases per k-unit: -1 = per layout (below), 0 = two 8-MFMA phases everywhere, 1 = one 16-MFMA phase everywhere
@@ -829,6 +832,7 @@ __global__ __launch_bounds__(512) void gemm_pers_kernel(GemmParams p) {
     if (nk_pf > 2) { issue_lo(); if (PH16) issue_hi(); }      // PH16: three whole units ahead; else 2.5
   };
   prefetch();
+  int prev_stores = 0;                                 // epilogue store instructions of the previous item still allowed in flight (0: none)
 
   while (true) {
     f32x16 acc[TM][TN];
@@ -845,7 +849,18 @@ __global__ __launch_bounds__(512) void gemm_pers_kernel(GemmParams p) {
     const int mw = hfc ? m0a + a_rb : ((vtc && (wn >> 1)) ? m0b : m0a) + wm * 128, nw = n0 + b_rb;   // this wave's output origin
     const int tm_eff = hfc ? 2 : TM;                    // row tiles of this wave's output
     const int zw = z_;                                  // this item's k-slice (fp32 slab index)
-    wait_vmcnt<0>();                                   // this item's first units have landed; last item's stores are out
+    // This item's first units (and the cursor fetch) have landed once only the previous item's epilogue stores - issued after them, and
+    // vmcnt retires in issue order - are still in flight: interior tiles of the plain / dual-output bf16 epilogues issue exactly
+    // `prev_stores` of them per wave (4 per 32-row slice and output), so the main loop starts while 128 KiB of stores drain instead of
+    // behind them (K = 1152 tiles: the store drain was most of a 16 % epilogue cost).  Anything else waits for everything.
+    if (GEMM_STORE_OVERLAP && LAYOUT != 2 && (EPI == 0 || EPI == 1)) {
+      if (prev_stores == 32) wait_vmcnt<32>();
+      else if (prev_stores == 16) wait_vmcnt<16>();
+      else if (prev_stores == 8) wait_vmcnt<8>();
+      else wait_vmcnt<0>();
+    } else {
+      wait_vmcnt<0>();                                 // this item's first units have landed; last item's stores are out
+    }
     if (DYN && wave == 0) {                            // ... and so has the cursor fetch issued at the last hand-over
       publish(fetch_resolve());
     }
@@ -1089,9 +1104,22 @@ __global__ __launch_bounds__(512) void gemm_pers_kernel(GemmParams p) {
         }
       }
     };
+    if (GEMM_ABL & 2) {                                  // ablation: no epilogue (one store keeps the accumulators alive)
+      float sacc = 0.f;
 #pragma unroll
-    for (int j0 = 0; j0 + 1 < TN; j0 += 2) emit(j0, IntC<2>{});
-    if (TN % 2) emit(TN - 1, IntC<1>{});
+      for (int i = 0; i < TM; i++)
+#pragma unroll
+        for (int j = 0; j < TN; j++) sacc += acc[i][j][0] + acc[i][j][7] + acc[i][j][15];
+      if (sacc == 123.456f) p.out[lane] = (bf16_t)sacc;
+    } else {
+#pragma unroll
+      for (int j0 = 0; j0 + 1 < TN; j0 += 2) emit(j0, IntC<2>{});
+      if (TN % 2) emit(TN - 1, IntC<1>{});
+    }
+    {   // stores this wave has just issued, if every one of them was a full (unpredicated) 16-byte row segment
+      const bool interior = mw + tm_eff * 32 <= p.M && nw + 64 <= p.N;
+      prev_stores = (interior && !want_cs && p.out) ? tm_eff * 4 * (dual ? 2 : 1) : 0;
+    }
     nk = nk_pf;
     if (!more) break;
   }
