@@ -29,7 +29,7 @@ def test_f16_operand_build_meets_1e3_forward_parity():
 @pytest.mark.gpu
 def test_f16_operand_build_model_suite():
     """tests/test_model_gpu.py re-run under the fp16-operand build: there its bounds are the north-star ones (forward <= 1e-3 at every
-    BASELINE token geometry, loss <= 1e-3, loss-scaled gradients <= 2e-3 per tensor; see that file's header)."""
+    BASELINE token geometry, loss <= 1e-3, loss-scaled gradients <= 1.2e-3 per tensor; see that file's header)."""
     env = dict(os.environ, PXA_OPERAND_DTYPE="f16")
     env.pop("PXA_LIB_PATH", None)
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_model_gpu.py"), "-q", "-m", "gpu", "-s", "-x",

@@ -6,7 +6,8 @@ The file runs under either operand build (PXA_OPERAND_DTYPE, one library per typ
 subprocess under f16).  Bounds, rel-L2, by build:
 
   fp16 operands (the reference's own mixed precision, configs/PixArt_xl2_internal.py:57; the build BASELINE.json's <= 1e-3 is
-  stated for):   forward <= 1e-3 vs the fp32 reference; loss <= 1e-3; every parameter gradient <= GRAD_TOL_F16 (loss-scaled backward).
+  stated for):   forward <= 1e-3 vs the fp32 reference; loss <= 1e-3; every parameter gradient <= 1.2e-3 (loss-scaled backward; all but the
+  cross-attention query projection measure <= 9.8e-4 - DESIGN.md section 2 says why that one sits at 1.08e-3).
   bf16 operands (default training build): one bf16 rounding of a tensor is 1.6e-3 by itself, so <= 1e-3 is unreachable by
   construction: forward <= 3e-3 vs the same-rounding-point oracle and <= 1e-2 vs fp32; gradients <= 3e-2; loss <= 5e-3.
 Every test prints the measured error next to its bound."""
@@ -26,7 +27,7 @@ FWD_RP_TOL, FWD_F32_TOL = (1e-3, 1e-3) if F16 else (3e-3, 1e-2)
 FWD_DEEP_TOL = 1e-3 if F16 else 2e-2            # depth-28 XL/2 (error grows with depth)
 SAMPLE_TOL = 2e-3 if F16 else 2e-2              # 2-step CFG-4.5 sampler amplifies the forward error
 LOSS_TOL = 1e-3 if F16 else 5e-3
-GRAD_TOL = 2e-3 if F16 else 3e-2
+GRAD_TOL = 1.2e-3 if F16 else 3e-2          # fp16: worst tensor measured 1.08e-3 (cross-attention q gradient: dP - delta cancellation)
 
 
 @pytest.fixture(scope="module", autouse=True)
