@@ -664,6 +664,15 @@ __device__ __forceinline__ bf16x8 frag_rt(const char* lds, int rbase, int ks, in
 // other XCDs' ranges.  The cursor fetch for item i+2 is issued at the hand-over i -> i+1 and resolved after the next vmcnt(0), so its
 // latency is never waited for.  Cursors live in a 64-slot global table (one slot per launch, round robin); the last workgroup to
 // retire zeroes its slot.
+#ifndef GEMM_TRACE
+#define GEMM_TRACE 0        // diagnostics build (tools/build_variant.py): workgroup 8 / wave 0 records s_memtime at 6 points of its first 12 items
+#endif
+#if GEMM_TRACE
+__device__ unsigned long long g_trace[12][8];
+#define PXA_TR(k) do { if (blockIdx.x == 8 && tid == 0 && tr_i < 12) g_trace[tr_i][k] = __builtin_readcyclecounter(); } while (0)
+#else
+#define PXA_TR(k) do {} while (0)
+#endif
 __device__ unsigned g_sched[64][16];                   // [slot][0..7] per-XCD cursors, [8] retired workgroups
 __device__ unsigned g_sched_word[64][512];             // paired-tile instances (no spare LDS): per-workgroup broadcast word
 
@@ -832,6 +841,7 @@ __global__ __launch_bounds__(512) void gemm_pers_kernel(GemmParams p) {
     if (nk_pf > 2) { issue_lo(); if (PH16) issue_hi(); }      // PH16: three whole units ahead; else 2.5
   };
   prefetch();
+  int tr_i = 0; (void)tr_i;
   int prev_stores = 0;                                 // epilogue store instructions of the previous item still allowed in flight (0: none)
 
   while (true) {
@@ -849,6 +859,7 @@ __global__ __launch_bounds__(512) void gemm_pers_kernel(GemmParams p) {
     const int mw = hfc ? m0a + a_rb : ((vtc && (wn >> 1)) ? m0b : m0a) + wm * 128, nw = n0 + b_rb;   // this wave's output origin
     const int tm_eff = hfc ? 2 : TM;                    // row tiles of this wave's output
     const int zw = z_;                                  // this item's k-slice (fp32 slab index)
+    PXA_TR(0);
     // This item's first units (and the cursor fetch) have landed once only the previous item's epilogue stores - issued after them, and
     // vmcnt retires in issue order - are still in flight: interior tiles of the plain / dual-output bf16 epilogues issue exactly
     // `prev_stores` of them per wave (4 per 32-row slice and output), so the main loop starts while 128 KiB of stores drain instead of
@@ -867,6 +878,7 @@ __global__ __launch_bounds__(512) void gemm_pers_kernel(GemmParams p) {
     __builtin_amdgcn_s_barrier();
     if (DYN) nxt = receive();
     if (late) __builtin_amdgcn_s_barrier();            // stagger the second wave of each SIMD by one barrier interval
+    PXA_TR(1);
     // one k-unit = ONE read phase + ONE matrix phase of 16 MFMAs (two barriers per unit instead of four: half as many hand-overs of the
     // matrix pipe between the two waves of a SIMD).  R: all 12 fragment reads of unit t, the 4 (5 / 3) LDS-DMA pieces of unit t+3, the
     // counted wait (unit t+1 landed; t+2, t+3 in flight) and lgkmcnt(0) - reads are COMPLETE at the barrier, so one barrier separates
@@ -948,7 +960,9 @@ __global__ __launch_bounds__(512) void gemm_pers_kernel(GemmParams p) {
       unit(t++, IntC<0>{}, th_c);
     };
     if (HALF && hfc) run_units(IntC<1>{}); else run_units(IntC<2>{});
+    PXA_TR(2);
     if (!late) __builtin_amdgcn_s_barrier();           // every wave has executed the same number of barriers; the ring is idle
+    PXA_TR(3);
 
     // ---- hand-over: prefetch the next item's first units, then this item's epilogue
     bool more;
@@ -969,6 +983,7 @@ __global__ __launch_bounds__(512) void gemm_pers_kernel(GemmParams p) {
         prefetch();
       }
     }
+    PXA_TR(4);
     const int srow = lane & 31;
     if constexpr (LAYOUT == 2) {
       // fp32 weight-gradient tile: each 32 x 32 accumulator tile is parked in the wave's staging slice (128-byte rows, 16-byte
@@ -1116,6 +1131,10 @@ __global__ __launch_bounds__(512) void gemm_pers_kernel(GemmParams p) {
       for (int j0 = 0; j0 + 1 < TN; j0 += 2) emit(j0, IntC<2>{});
       if (TN % 2) emit(TN - 1, IntC<1>{});
     }
+    PXA_TR(5);
+#if GEMM_TRACE
+    tr_i++;
+#endif
     {   // stores this wave has just issued, if every one of them was a full (unpredicated) 16-byte row segment
       const bool interior = mw + tm_eff * 32 <= p.M && nw + 64 <= p.N;
       prev_stores = (interior && !want_cs && p.out) ? tm_eff * 4 * (dual ? 2 : 1) : 0;
@@ -1341,3 +1360,9 @@ extern "C" int pxa_gemm(const pxa_gemm_args* a, hipStream_t stream) {
 }
 
 extern "C" long pxa_gemm_splitk_ws_elems(int M, int N) { return 16L * M * N; }
+
+#if GEMM_TRACE
+extern "C" int pxa_gemm_trace(unsigned long long* host_out) {       // 12 x 8 counters of the last traced launch
+  return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_trace), sizeof(unsigned long long) * 96) == hipSuccess ? 0 : -1;
+}
+#endif
