@@ -5,6 +5,7 @@
 //   colsum     : bias gradients  db[n] += sum_rows dY[r][n]
 // One 32-lane half-wave owns a row: D/128 float4 per lane, 512-byte coalesced segments, fp32 statistics
 // (two-pass mean / centered variance in registers), one HBM pass per tensor.
+#include <cstdlib>
 #include "common.h"
 #include "../../include/pixart_hip.h"
 
@@ -455,9 +456,13 @@ extern "C" int pxa_colsum_reduce(const float* part, long stride, float* out, lon
 
 extern "C" int pxa_colsum_bf16(const void* dy_bf16, int ld, float* out, int R, int N, hipStream_t stream) {
   PXA_CHECK(dy_bf16 && out && R > 0 && N % 8 == 0 && ld % 8 == 0, "pxa_colsum_bf16: bad args");
-  // ~1024 workgroups: enough to fill 256 CUs several times over while every output address sees at most a few hundred atomics
+  // ~80 row blocks per column group: every output address then receives ~80 same-address atomics.  That contention, not the streaming, set
+  // the time: at R = 65,536 a 1152-wide sum took 78 us with 1024 workgroups (328 atomics per address) and 34-36 us with 192-256, a 3456-wide
+  // one 77-79 us anywhere between 384 and 1024 (profiles/r02_elementwise.txt).
   const int bx = (N / 8 + CS_CT - 1) / CS_CT;
-  int rpb = (int)(((long)R * bx + 1023) / 1024);
+  static const int forced = getenv("PXA_COLSUM_BLOCKS") ? atoi(getenv("PXA_COLSUM_BLOCKS")) : 0;         // A/B: workgroups per launch
+  const int target = forced > 0 ? forced : (80 * bx < 192 ? 192 : (80 * bx > 1024 ? 1024 : 80 * bx));
+  int rpb = (int)(((long)R * bx + target - 1) / target);
   rpb = (rpb + 8 * CS_RL - 1) / (8 * CS_RL) * (8 * CS_RL);
   dim3 grid(bx, (R + rpb - 1) / rpb);
   hipLaunchKernelGGL(colsum_kernel, grid, dim3(CS_CT * CS_RL), 0, stream, (const bf16_t*)dy_bf16, ld, out, R, N, rpb);
