@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define PXA_ABI_VERSION 3
+#define PXA_ABI_VERSION 4
 /* Kernels that fuse a bias-gradient column sum add into one of PXA_COLSUM_SLOTS partial rows ([slot][stride] fp32, caller-zeroed),
  * chosen per sample / row tile, so no address sees thousands of atomics; pxa_colsum_reduce folds the partials into the gradient. */
 #define PXA_COLSUM_SLOTS 16
@@ -73,6 +73,14 @@ typedef struct {
                                  /*  from A[m*lda + row*a_seg_stride + tap*k_tap + chunk*64 + k%64] - the same patch, visited    */
                                  /*  so that all nine reads of a pixel's 64-channel chunk happen within 18 k-units (L2-resident) */
                                  /*  instead of up to K/3 apart; B's rows follow the same K order.                               */
+  float* gn_part;                /* optional, implicit convolutions (k_seg) with a bf16 output only: GroupNorm statistics of the  */
+  int gn_img_rows;               /*  output folded into the epilogue.  Output row m is the padded-grid pixel pix = m % gn_img_rows */
+  int gn_row_pitch, gn_h, gn_w;  /*  of image m / gn_img_rows (gn_img_rows a multiple of 256, >= (gn_h+2)*gn_row_pitch,            */
+                                 /*  gn_row_pitch = gn_w+2); the interior pixels (1 <= pix / pitch <= gn_h, 1 <= pix % pitch       */
+                                 /*  <= gn_w) add their stored (rounded) outputs and squares, per quad of adjacent channels, into   */
+                                 /*  gn_part[slot][image][N/4][2] fp32 (PXA_COLSUM_SLOTS slots, caller-zeroed);                    */
+                                 /*  pxa_vae_gn_finalize turns the partials into mean / rstd (groups are multiples of 4 channels).  */
+                                 /*  Replaces the separate statistics pass over the output.                                        */
 } pxa_gemm_args;
 /* Upper bound of the split-K workspace (in floats) pxa_gemm may use for an (M, N) fp32-accumulate output. */
 long pxa_gemm_splitk_ws_elems(int M, int N);
@@ -246,6 +254,8 @@ typedef struct { void* ptr; int B, H, W, C; int row_pitch; long img_pitch; long 
 /* GroupNorm statistics over the interior pixels: mean / rstd [B*groups] (torch.nn.GroupNorm(groups, C, eps): biased variance).
  * ws: B*groups*2 doubles of scratch (zeroed by the call).  C/groups must be a multiple of 4, C = 8 * 2^n. */
 int pxa_vae_gn_stats(const pxa_grid* x, int groups, float eps, double* ws, float* mean, float* rstd, hipStream_t stream);
+/* The same (mean, rstd) from statistics a convolution's epilogue already accumulated (pxa_gemm_args.gn_part [slot][B][C/4][2]); pixels = H*W. */
+int pxa_vae_gn_finalize(const float* part, int B, int C, int groups, long pixels, float eps, float* mean, float* rstd, hipStream_t stream);
 /* y[b, yo, xo] = act(norm(x[b, yo/upsample, xo/upsample])): GroupNorm affine when mean != NULL, SiLU when silu, nearest-neighbour
  * 2x upsampling when upsample == 2 (diffusers Upsample2D).  Writes the interior of y only. */
 int pxa_vae_gn_apply(const pxa_grid* x, const float* mean, const float* rstd, const float* gamma, const float* beta, int groups,

@@ -59,6 +59,23 @@ __device__ __forceinline__ void unpack_bf16x8(const uint4& u, float (&f)[8]) {
   unpack_bf16x2(u.z, f[4], f[5]); unpack_bf16x2(u.w, f[6], f[7]);
 }
 
+// c + a.lo*b.lo + a.hi*b.hi on packed operand pairs (v_dot2c_f32_bf16 / v_dot2c_f32_f16): sums and sums of squares of stored outputs
+// without unpacking them.  OPERAND_ONE_X2 = (1, 1).
+__device__ __forceinline__ float dot2_acc(uint32_t a, uint32_t b, float c) {
+#ifdef PXA_OPERAND_F16
+  typedef _Float16 h16x2 __attribute__((ext_vector_type(2)));
+  return __builtin_amdgcn_fdot2(__builtin_bit_cast(h16x2, a), __builtin_bit_cast(h16x2, b), c, false);
+#else
+  typedef __bf16 b16x2 __attribute__((ext_vector_type(2)));
+  return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(b16x2, a), __builtin_bit_cast(b16x2, b), c, false);
+#endif
+}
+#ifdef PXA_OPERAND_F16
+constexpr uint32_t OPERAND_ONE_X2 = 0x3c003c00u;
+#else
+constexpr uint32_t OPERAND_ONE_X2 = 0x3f803f80u;
+#endif
+
 // LDS transpose read: 4 bf16 (see layout note above). `p` must be 8-byte aligned.
 __device__ __forceinline__ s16x4 lds_tr_read(const char* p) {
   return __builtin_amdgcn_ds_read_tr16_b64_v4i16(LDS_PTR(s16x4, p));

@@ -36,6 +36,10 @@ struct GemmParams {
   long seg_jump;   // = a_seg_stride - k_seg
   int k_tap;       // > 0: tap-interleaved K order of the 3x3 convolution (see pxa_gemm_args): [k_tap/64 chunks][3 rows][3 taps][64]
   long tap_s;      // = a_seg_stride (elements between kernel rows)
+  // GroupNorm statistics of an implicit-convolution output (persistent SEG instances, EPI 5 / 6): per-channel sum and sum of squares of
+  // the bf16 output over the INTERIOR pixels of each image, per QUAD of adjacent channels (GroupNorm groups are multiples of 4 channels
+  // wide), added into gn_part[slot][image][N/4][2] (slot = 128-row block % PXA_COLSUM_SLOTS)
+  float* gn_part; int gn_img_rows, gn_rp, gn_h, gn_w, gn_B; float gn_inv_rp;
 };
 
 // ---- global -> registers (4 x 16 B per thread per operand tile), zero-filled out of bounds
@@ -864,9 +868,11 @@ __global__ __launch_bounds__(512) void gemm_pers_kernel(GemmParams p) {
     // vmcnt retires in issue order - are still in flight: interior tiles of the plain / dual-output bf16 epilogues issue exactly
     // `prev_stores` of them per wave (4 per 32-row slice and output), so the main loop starts while 128 KiB of stores drain instead of
     // behind them (K = 1152 tiles: the store drain was most of a 16 % epilogue cost).  Anything else waits for everything.
-    if (GEMM_STORE_OVERLAP && LAYOUT != 2 && (EPI == 0 || EPI == 1)) {
+    if (GEMM_STORE_OVERLAP && LAYOUT != 2 && (EPI == 0 || EPI == 1 || EPI == 4 || EPI == 5 || EPI == 6)) {
       if (prev_stores == 32) wait_vmcnt<32>();
+      else if (prev_stores == 20) wait_vmcnt<20>();
       else if (prev_stores == 16) wait_vmcnt<16>();
+      else if (prev_stores == 12) wait_vmcnt<12>();
       else if (prev_stores == 8) wait_vmcnt<8>();
       else wait_vmcnt<0>();
     } else {
@@ -1019,7 +1025,8 @@ __global__ __launch_bounds__(512) void gemm_pers_kernel(GemmParams p) {
       if (!more) break;
       continue;
     }
-    const int act = EPI == 0 ? 0 : EPI == 1 ? 3 : EPI == 2 ? 4 : EPI == 4 ? 5 : p.act;   // EPI 4: + aux (residual connection)
+    const int act = (EPI == 0 || EPI == 5) ? 0 : EPI == 1 ? 3 : EPI == 2 ? 4 : (EPI == 4 || EPI == 6) ? 5 : p.act;   // EPI 4 / 6: + aux (residual connection)
+    constexpr bool want_st = (EPI == 5 || EPI == 6);   // + GroupNorm statistics of the output (implicit convolutions of the VAE)
     const bool dual = EPI == 1 || (EPI == 3 && ((p.act == 1 && p.out2 != nullptr) || p.act == 3));
     const bool want_cs = EPI == 2 || (EPI == 3 && p.colsum != nullptr);
     // one column group of JW 32-wide tiles (JW = 2: 128-byte staging rows, 8 rows per store; JW = 1: 64-byte rows, 16 per store)
@@ -1038,9 +1045,12 @@ __global__ __launch_bounds__(512) void gemm_pers_kernel(GemmParams p) {
         }
       // bias-gradient column sums are taken from the read-back (row-wise) copy of the bf16 output: a lane keeps 8 running sums
       // for its 8-column chunk over all row slices; one 3-step lane tree at the end
-      float cs[8];
+      float cs[8], sq[2] = {0.f, 0.f};                 // statistics flavours: cs[0..1] / sq[0..1] = the chunk's two channel quads
 #pragma unroll
       for (int e = 0; e < 8; e++) cs[e] = 0.f;
+      // statistics: this wave's rows belong to ONE image (gn_img_rows is a multiple of 256); a row counts when its padded-grid
+      // position is an interior pixel.  floor((pix + 0.5) / rp) in fp32 is exact for pix < 2^22.
+      const int st_img = want_st ? mw / p.gn_img_rows : 0, st_base = st_img * p.gn_img_rows;
       // aux (saved pre-activation / saved GELU') of the NEXT row slice is requested before this slice is processed
       const bool want_aux = (act == 2 || act == 4 || act == 5);
       uint2 ax[2][JW][4];
@@ -1104,6 +1114,15 @@ __global__ __launch_bounds__(512) void gemm_pers_kernel(GemmParams p) {
 #pragma unroll
               for (int e = 0; e < 8; e++) cs[e] += f[e];
             }
+            if (pass == 1 && want_st && mm < p.M) {
+              const int pix = mm - st_base, py = (int)(((float)pix + 0.5f) * p.gn_inv_rp), px = pix - py * p.gn_rp;
+              const unsigned msk = (py >= 1 && py <= p.gn_h && px >= 1 && px <= p.gn_w) ? 0xffffffffu : 0u;
+              const unsigned w0 = v4.x & msk, w1 = v4.y & msk, w2 = v4.z & msk, w3 = v4.w & msk;   // the stored (rounded) values, packed
+              cs[0] = dot2_acc(w1, OPERAND_ONE_X2, dot2_acc(w0, OPERAND_ONE_X2, cs[0]));
+              cs[1] = dot2_acc(w3, OPERAND_ONE_X2, dot2_acc(w2, OPERAND_ONE_X2, cs[1]));
+              sq[0] = dot2_acc(w1, w1, dot2_acc(w0, w0, sq[0]));
+              sq[1] = dot2_acc(w3, w3, dot2_acc(w2, w2, sq[1]));
+            }
           }
           __builtin_amdgcn_s_waitcnt(0xc07f);          // reads returned before the slice is overwritten
         }
@@ -1116,6 +1135,18 @@ __global__ __launch_bounds__(512) void gemm_pers_kernel(GemmParams p) {
           v += __shfl_xor(v, 8); v += __shfl_xor(v, 16); v += __shfl_xor(v, 32);
           const int n = nw + j0 * 32 + (lane % LPR) * 8 + e;
           if (lane < LPR && n < p.N) atomicAdd(p.colsum + (size_t)((mw >> 7) % PXA_COLSUM_SLOTS) * p.colsum_stride + n, v);
+        }
+      }
+      if (want_st) {
+        float* dst = p.gn_part + ((size_t)((mw >> 7) % PXA_COLSUM_SLOTS) * p.gn_B + st_img) * (p.N / 4) * 2;
+#pragma unroll
+        for (int h = 0; h < 2; h++) {                  // lanes with the same chunk hold partial sums of the same two quads
+          float v = cs[h], u = sq[h];
+          if (LPR <= 4) { v += __shfl_xor(v, 4); u += __shfl_xor(u, 4); }
+          v += __shfl_xor(v, 8); v += __shfl_xor(v, 16); v += __shfl_xor(v, 32);
+          u += __shfl_xor(u, 8); u += __shfl_xor(u, 16); u += __shfl_xor(u, 32);
+          const int n = nw + j0 * 32 + (lane % LPR) * 8 + 4 * h;
+          if (lane < LPR && n < p.N) { atomicAdd(dst + (n >> 2) * 2, v); atomicAdd(dst + (n >> 2) * 2 + 1, u); }
         }
       }
     };
@@ -1137,7 +1168,8 @@ __global__ __launch_bounds__(512) void gemm_pers_kernel(GemmParams p) {
 #endif
     {   // stores this wave has just issued, if every one of them was a full (unpredicated) 16-byte row segment
       const bool interior = mw + tm_eff * 32 <= p.M && nw + 64 <= p.N;
-      prev_stores = (interior && !want_cs && p.out) ? tm_eff * 4 * (dual ? 2 : 1) : 0;
+      // (the statistics flavours issue 4 more vector-memory instructions behind the stores: their atomics)
+      prev_stores = (interior && !want_cs && p.out) ? tm_eff * 4 * (dual ? 2 : 1) + (want_st ? 4 : 0) : 0;
     }
     nk = nk_pf;
     if (!more) break;
@@ -1242,9 +1274,14 @@ int launch(GemmParams p, int split, hipStream_t s) {
     if constexpr (LAYOUT == 0) {
       static const bool no_pers_seg = getenv("PXA_GEMM_NO_PERSISTENT") != nullptr;
       if (p.out && !p.outf && (p.act == 0 || p.act == 5) && p.M >= 1024 && p.N >= 128 && p.N % 128 == 0 && p.k_seg % 32 == 0 && !no_pers_seg) {
+        if (p.gn_part) {                                 // + GroupNorm statistics of the output
+          if (p.act == 5) return pers_halfcol(p.N) ? launch_pers<0, 6, 2, true>(p, 1, s) : launch_pers<0, 6, 0, true>(p, 1, s);
+          return pers_halfcol(p.N) ? launch_pers<0, 5, 2, true>(p, 1, s) : launch_pers<0, 5, 0, true>(p, 1, s);
+        }
         if (p.act == 5) return pers_halfcol(p.N) ? launch_pers<0, 4, 2, true>(p, 1, s) : launch_pers<0, 4, 0, true>(p, 1, s);   // conv + residual
         return pers_halfcol(p.N) ? launch_pers<0, 0, 2, true>(p, 1, s) : launch_pers<0, 0, 0, true>(p, 1, s);
       }
+      if (p.gn_part) { pxa_set_error("pxa_gemm: gn_part needs the persistent implicit-convolution path (bf16 output, M >= 1024, N a multiple of 128)"); return -1; }
       if (p.out && !p.outf && p.act == 0) return launch_glds_e<0, 128, 128, 2, 2, 1, true>(p, 1, s);
       return launch_glds_e<0, 128, 128, 2, 2, 0, true>(p, 1, s);
     }
@@ -1341,6 +1378,15 @@ extern "C" int pxa_gemm(const pxa_gemm_args* a, hipStream_t stream) {
   split = (a->K + kps - 1) / kps;
   p.slab = nullptr;
   p.colsum = a->colsum; p.colsum_stride = a->colsum_stride;
+  p.gn_part = a->gn_part; p.gn_img_rows = a->gn_img_rows; p.gn_rp = a->gn_row_pitch; p.gn_h = a->gn_h; p.gn_w = a->gn_w;
+  p.gn_B = 0; p.gn_inv_rp = 0.f;
+  if (a->gn_part) {
+    PXA_CHECK(a->k_seg && a->out_bf16 && !a->out_f32 && (a->act == 0 || a->act == 5), "pxa_gemm: gn_part needs an implicit convolution (k_seg) with a bf16 output and act 0 or 5");
+    PXA_CHECK(a->gn_img_rows > 0 && a->gn_img_rows % 256 == 0 && a->M % a->gn_img_rows == 0, "pxa_gemm: gn_img_rows=%d must be a multiple of 256 dividing M=%d", a->gn_img_rows, a->M);
+    PXA_CHECK(a->gn_row_pitch == a->gn_w + 2 && a->gn_h > 0 && a->gn_w > 0 && (long)(a->gn_h + 2) * a->gn_row_pitch <= a->gn_img_rows && a->gn_img_rows < (1 << 22),
+              "pxa_gemm: bad padded-grid geometry for gn_part (h=%d w=%d row_pitch=%d img_rows=%d)", a->gn_h, a->gn_w, a->gn_row_pitch, a->gn_img_rows);
+    p.gn_B = a->M / a->gn_img_rows; p.gn_inv_rp = 1.0f / (float)a->gn_row_pitch;
+  }
   if (p.accumulate && p.outf) {
     if (split == 1) p.accumulate = 2;
     else if (a->splitk_ws && a->splitk_ws_elems >= (long)split * a->M * a->N) { p.accumulate = 3; p.slab = a->splitk_ws; }

@@ -61,6 +61,23 @@ __global__ void gn_finalize_kernel(const double* __restrict__ ws, float* __restr
   rstd[i] = (float)(1.0 / sqrt(var + (double)eps));
 }
 
+// statistics that a convolution's epilogue already produced (pxa_gemm_args.gn_part): part[slot][b][C/4][2] (sum, sum of squares per quad of
+// adjacent channels) -> mean / rstd per (b, group)
+__global__ void gn_finalize_part_kernel(const float* __restrict__ part, float* __restrict__ mean, float* __restrict__ rstd, int B, int C, int cpg,
+                                        double count, float eps) {
+  const int G = C / cpg, i = blockIdx.x * blockDim.x + threadIdx.x;      // i = b * G + g
+  if (i >= B * G) return;
+  const int b = i / G, g = i - b * G;
+  double s = 0.0, q = 0.0;
+  for (int slot = 0; slot < PXA_COLSUM_SLOTS; slot++) {
+    const float2* row = reinterpret_cast<const float2*>(part) + ((size_t)slot * B + b) * (C / 4) + g * (cpg / 4);
+    for (int c = 0; c < cpg / 4; c++) { s += (double)row[c].x; q += (double)row[c].y; }
+  }
+  const double m = s / count, var = fmax(q / count - m * m, 0.0);
+  mean[i] = (float)m;
+  rstd[i] = (float)(1.0 / sqrt(var + (double)eps));
+}
+
 // the value a consumer sees: optional GroupNorm (affine), optional SiLU
 struct Norm {
   const float* mean; const float* rstd; const float* gamma; const float* beta; int cpg, G, silu;
@@ -85,14 +102,27 @@ struct Norm {
 };
 
 // ---- y[b, yo, xo] = act(norm(x[b, yo / up, xo / up])): writes the interior of y (the zero border of a padded grid is the caller's)
+// A thread handles one 16-byte chunk column of GA_ROWS consecutive output rows: the loads are issued before any arithmetic, so a
+// wave keeps GA_ROWS KiB in flight (one chunk per thread left this kernel latency-bound at ~2.4 TB/s).
+constexpr int GA_ROWS = 4;
 __global__ __launch_bounds__(256) void gn_apply_kernel(Grid x, Norm nm, int up, Grid y) {
-  const int CV = x.C / 8, i = blockIdx.x * 256 + threadIdx.x;   // grid: (chunks of one output row, output row, sample)
+  const int CV = x.C / 8, i = blockIdx.x * 256 + threadIdx.x;   // grid: (chunks of one output row, group of output rows, sample)
   if (i >= y.W * CV) return;
-  const int xo = i / CV, cv = i - xo * CV, yo = blockIdx.y, b = blockIdx.z;
-  float f[8];
-  unpack_bf16x8(*reinterpret_cast<const uint4*>(x.at(b, yo >> (up - 1), xo >> (up - 1)) + cv * 8), f);
-  nm.apply(f, b, cv * 8);
-  *reinterpret_cast<uint4*>(y.at(b, yo, xo) + cv * 8) = pack8(f);
+  const int xo = i / CV, cv = i - xo * CV, y0 = blockIdx.y * GA_ROWS, b = blockIdx.z;
+  uint4 v[GA_ROWS];
+#pragma unroll
+  for (int r = 0; r < GA_ROWS; r++) {
+    const int yo = min(y0 + r, y.H - 1);
+    v[r] = *reinterpret_cast<const uint4*>(x.at(b, yo >> (up - 1), xo >> (up - 1)) + cv * 8);
+  }
+#pragma unroll
+  for (int r = 0; r < GA_ROWS; r++) {
+    if (y0 + r >= y.H) break;
+    float f[8];
+    unpack_bf16x8(v[r], f);
+    nm.apply(f, b, cv * 8);
+    *reinterpret_cast<uint4*>(y.at(b, y0 + r, xo) + cv * 8) = pack8(f);
+  }
 }
 
 // ---- explicit patch matrix: col[(b, yo, xo)][tap * C + c] = act(norm(x[b, yo*stride + ky - pad, xo*stride + kx - pad])) or 0 outside
@@ -222,6 +252,15 @@ extern "C" int pxa_vae_gn_stats(const pxa_grid* x, int groups, float eps, double
   return 0;
 }
 
+extern "C" int pxa_vae_gn_finalize(const float* part, int B, int C, int groups, long pixels, float eps, float* mean, float* rstd, hipStream_t stream) {
+  PXA_CHECK(part && mean && rstd && B > 0 && pixels > 0, "pxa_vae_gn_finalize: bad arguments");
+  PXA_CHECK(groups > 0 && C % groups == 0 && (C / groups) % 4 == 0, "pxa_vae_gn_finalize: C=%d / groups=%d must be a multiple of 4", C, groups);
+  const int n = B * groups;
+  hipLaunchKernelGGL(gn_finalize_part_kernel, dim3((n + 63) / 64), dim3(64), 0, stream, part, mean, rstd, B, C, C / groups, (double)pixels * (C / groups), eps);
+  PXA_LAUNCH_CHECK();
+  return 0;
+}
+
 extern "C" int pxa_vae_gn_apply(const pxa_grid* x, const float* mean, const float* rstd, const float* gamma, const float* beta, int groups,
                                 int silu, int upsample, const pxa_grid* y, hipStream_t stream) {
   if (int rc = check_grid(x, "pxa_vae_gn_apply(x)")) return rc;
@@ -231,7 +270,7 @@ extern "C" int pxa_vae_gn_apply(const pxa_grid* x, const float* mean, const floa
   Norm nm;
   if (int rc = make_norm(nm, mean, rstd, gamma, beta, x->C, groups, silu, "pxa_vae_gn_apply")) return rc;
   PXA_CHECK(y->H <= 65535 && y->B <= 65535, "pxa_vae_gn_apply: grid too large");
-  hipLaunchKernelGGL(gn_apply_kernel, dim3((y->W * (y->C / 8) + 255) / 256, y->H, y->B), dim3(256), 0, stream, to_grid(x), nm, upsample, to_grid(y));
+  hipLaunchKernelGGL(gn_apply_kernel, dim3((y->W * (y->C / 8) + 255) / 256, (y->H + GA_ROWS - 1) / GA_ROWS, y->B), dim3(256), 0, stream, to_grid(x), nm, upsample, to_grid(y));
   PXA_LAUNCH_CHECK();
   return 0;
 }

@@ -13,7 +13,7 @@ OPERAND = os.environ.get("PXA_OPERAND_DTYPE", "bf16").lower()
 assert OPERAND in ("bf16", "f16"), f"PXA_OPERAND_DTYPE must be bf16 or f16, got {OPERAND!r}"
 OPERAND_DTYPE = torch.float16 if OPERAND == "f16" else torch.bfloat16
 LIB_PATH = os.environ.get("PXA_LIB_PATH") or os.path.join(_HERE, "libpixart_hip_f16.so" if OPERAND == "f16" else "libpixart_hip.so")   # env override: A/B kernel builds
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 c_void_p, c_int, c_long, c_float = C.c_void_p, C.c_int, C.c_long, C.c_float
 
@@ -25,7 +25,8 @@ class GemmArgs(C.Structure):
                 ("out_bf16", c_void_p), ("out2_bf16", c_void_p), ("ld_out", c_int),
                 ("out_f32", c_void_p), ("ld_f32", c_int), ("accumulate", c_int), ("split_k", c_int),
                 ("splitk_ws", c_void_p), ("splitk_ws_elems", c_long), ("colsum", c_void_p), ("colsum_stride", c_long),
-                ("k_seg", c_int), ("a_seg_stride", c_long), ("k_tap", c_int)]
+                ("k_seg", c_int), ("a_seg_stride", c_long), ("k_tap", c_int),
+                ("gn_part", c_void_p), ("gn_img_rows", c_int), ("gn_row_pitch", c_int), ("gn_h", c_int), ("gn_w", c_int)]
 
 
 class GridArg(C.Structure):
@@ -98,6 +99,7 @@ SIGNATURES = {
     "pxa_iddpm_loss_fwd": [_P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P],
     "pxa_iddpm_loss_bwd": [_P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P],
     "pxa_vae_gn_stats": [_G, _I, _F, _P, _P, _P, _P],
+    "pxa_vae_gn_finalize": [_P, _I, _I, _I, _L, _F, _P, _P, _P],
     "pxa_vae_gn_apply": [_G, _P, _P, _P, _P, _I, _I, _I, _G, _P],
     "pxa_vae_im2col3x3": [_G, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P, _P],
     "pxa_vae_add": [_G, _G, _G, _P],

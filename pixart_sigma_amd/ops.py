@@ -21,10 +21,12 @@ def _chk(t, dtype, name):
 
 
 def gemm(a, b, layout=NT, bias=None, act=ACT_NONE, aux=None, out=None, out2=None, out_f32=None, accumulate=False,
-         split_k=1, out_dtype=BF16, colsum=None, k_seg=0, a_seg_stride=0, k_tap=0):
+         split_k=1, out_dtype=BF16, colsum=None, k_seg=0, a_seg_stride=0, k_tap=0, gn_part=None, gn_geom=None):
     """C = op(A) op(B) (see include/pixart_hip.h).  a, b: 2-D bf16 (row stride arbitrary multiple of 8).
     Returns the bf16 output (or fp32 when out_dtype is float32 / out_f32 is given).
-    k_seg / a_seg_stride / k_tap: segmented-K A operand (the implicit 3x3 convolution of the VAE kernel set)."""
+    k_seg / a_seg_stride / k_tap: segmented-K A operand (the implicit 3x3 convolution of the VAE kernel set).
+    gn_part (PXA_COLSUM_SLOTS, B, N/4, 2) fp32 zeros + gn_geom = (img_rows, row_pitch, H, W): GroupNorm statistics of the output
+    accumulated by the epilogue (see pxa_gemm_args.gn_part)."""
     _chk(a, BF16, "A")
     _chk(b, BF16, "B")
     if layout == NT:
@@ -65,6 +67,11 @@ def gemm(a, b, layout=NT, bias=None, act=ACT_NONE, aux=None, out=None, out2=None
         g.out2_bf16 = ptr(out2)
     g.accumulate, g.split_k = int(accumulate), split_k
     g.k_seg, g.a_seg_stride, g.k_tap = k_seg, a_seg_stride, k_tap
+    if gn_part is not None:
+        _chk(gn_part, F32, "gn_part")
+        assert gn_part.is_contiguous() and gn_part.numel() == COLSUM_SLOTS * (M // gn_geom[0]) * (N // 4) * 2
+        g.gn_part = ptr(gn_part)
+        g.gn_img_rows, g.gn_row_pitch, g.gn_h, g.gn_w = gn_geom
     if colsum is not None:               # (PXA_COLSUM_SLOTS, stride) partial buffer view: row 0 of the slice to accumulate
         g.colsum, g.colsum_stride = ptr(colsum), colsum.stride(0)
     if accumulate and split_k != 1:       # split-K partial slabs: caller-owned workspace, cached per device (max 16 slabs)
@@ -309,6 +316,14 @@ def vae_gn_stats(x, groups, eps):
     mean = torch.empty(x.B * groups, dtype=F32, device=dev)
     rstd = torch.empty_like(mean)
     call("pxa_vae_gn_stats", x.arg(), groups, eps, ptr(ws), ptr(mean), ptr(rstd))
+    return mean, rstd
+
+
+def vae_gn_finalize(part, B, C, groups, pixels, eps):
+    """(mean, rstd) from the per-channel partial sums a convolution epilogue accumulated (gemm(..., gn_part=...))."""
+    mean = torch.empty(B * groups, dtype=F32, device=part.device)
+    rstd = torch.empty_like(mean)
+    call("pxa_vae_gn_finalize", ptr(part), B, C, groups, pixels, eps, ptr(mean), ptr(rstd))
     return mean, rstd
 
 

@@ -25,6 +25,12 @@ def _c8(n):
     return (n + 7) // 8 * 8
 
 
+def _img_rows(H, W):
+    """Pixel slots per image of a zero-bordered (H+2) x (W+2) grid, rounded up to the GEMM's 256-row tile: every output tile of an
+    implicit convolution then belongs to one image (the GroupNorm statistics of its epilogue need that) and M has no partial tile."""
+    return ((H + 2) * (W + 2) + 255) // 256 * 256
+
+
 class DiagonalGaussianDistribution:
     """diffusers.models.autoencoders.vae.DiagonalGaussianDistribution: moments (B, 2*latent, h, w) -> mean / logvar halves."""
 
@@ -237,37 +243,47 @@ class AutoencoderKL(nn.Module):
 
     # ------------------------------------------------------------------ layers on pixel grids
     def _padded(self, B, H, W, C, dev):
-        """Zero-bordered input of an implicit 3x3 convolution: [guard | B x (H+2) x (W+2) pixels | guard], guard = W+3 pixels.
-        Only the interior is ever written, so the border stays zero for the lifetime of the cache entry."""
+        """Zero-bordered input of an implicit 3x3 convolution: [guard | B x (_img_rows(H, W) >= (H+2) x (W+2)) pixels | guard], guard = W+3
+        pixels.  Only the interior is ever written, so the border (and each image's tail) stays zero for the lifetime of the cache entry."""
         key = (B, H, W, C, str(dev))
         buf = self._pad_cache.get(key)
         if buf is None:
-            buf = self._pad_cache[key] = torch.zeros((B * (H + 2) * (W + 2) + 2 * (W + 3)) * C, dtype=BF16, device=dev)
+            buf = self._pad_cache[key] = torch.zeros((B * _img_rows(H, W) + 2 * (W + 3)) * C, dtype=BF16, device=dev)
         return buf
 
     def _norm(self, x, gn):
-        mean, rstd = ops.vae_gn_stats(x, gn.num_groups, gn.eps)
+        part = getattr(x, "gn_part", None)
+        if part is not None:                                    # the producing convolution's epilogue already summed the output
+            mean, rstd = ops.vae_gn_finalize(part, x.B, x.C, gn.num_groups, x.H * x.W, gn.eps)
+        else:
+            mean, rstd = ops.vae_gn_stats(x, gn.num_groups, gn.eps)
         gamma, beta = self._packed[id(gn)]
         return (mean, rstd, gamma, beta, gn.num_groups)
 
-    def _conv3(self, x, conv, norm=None, silu=False, upsample=1, out_f32=False, residual=None):
+    def _conv3(self, x, conv, norm=None, silu=False, upsample=1, out_f32=False, residual=None, stats=False):
         """3x3 stride-1 pad-1 convolution of act(norm(x)) (optionally 2x upsampled first); `residual` (a grid) is added to the result -
-        inside the GEMM epilogue when it already has the output's padded-grid layout, by the add kernel otherwise."""
+        inside the GEMM epilogue when it already has the output's padded-grid layout, by the add kernel otherwise.  stats: a GroupNorm
+        reads the result next - its per-channel sums are taken in the GEMM epilogue (no separate pass over the output)."""
         w, b, _ = self._packed[id(conv)]
         B, H, W, C, dev = x.B, x.H * upsample, x.W * upsample, x.C, x.buf.device
         assert w.shape[1] == 9 * C
         if C % 64 == 0:                                         # implicit GEMM over the padded pixels
             buf = self._padded(B, H, W, C, dev)
-            ip, rp = (H + 2) * (W + 2), W + 2
+            ip, rp, Co = _img_rows(H, W), W + 2, w.shape[0]
             ops.vae_gn_apply(x, Grid(buf, B, H, W, C, rp, ip, origin=(W + 3) + rp + 1), norm, silu, upsample)
             a = buf.as_strided((B * ip, 9 * C), (C, 1))
-            fused = (residual is not None and not out_f32 and residual.C == w.shape[0] and residual.row_pitch == rp and residual.img_pitch == ip
+            fused = (residual is not None and not out_f32 and residual.C == Co and residual.row_pitch == rp and residual.img_pitch == ip
                      and residual.origin == W + 3 and (residual.B, residual.H, residual.W) == (B, H, W))
+            stats = (stats and not out_f32 and (fused or residual is None) and Co % 128 == 0 and B * ip >= 1024 and ip < (1 << 22)
+                     and os.environ.get("PXA_VAE_FUSED_GN_STATS", "1") != "0")
+            part = torch.zeros(ops.COLSUM_SLOTS, B, Co // 4, 2, dtype=F32, device=dev) if stats else None
             out = ops.gemm(a, w, ops.NT, bias=b, out_dtype=F32 if out_f32 else BF16, k_seg=3 * C, a_seg_stride=rp * C, k_tap=C,
-                           act=ops.ACT_ADD_AUX if fused else ops.ACT_NONE, aux=residual.rows() if fused else None)
+                           act=ops.ACT_ADD_AUX if fused else ops.ACT_NONE, aux=residual.rows() if fused else None,
+                           gn_part=part, gn_geom=(ip, rp, H, W) if stats else None)
             if out_f32:
-                return out.view(B, H + 2, W + 2, -1)[:, 1:-1, 1:-1]
-            y = Grid(out, B, H, W, w.shape[0], rp, ip, origin=W + 3)
+                return out.view(B, ip, -1)[:, :(H + 2) * (W + 2)].view(B, H + 2, W + 2, -1)[:, 1:-1, 1:-1]
+            y = Grid(out, B, H, W, Co, rp, ip, origin=W + 3)
+            y.gn_part = part
             return y if fused or residual is None else ops.vae_add(y, residual, y)
         assert upsample == 1 and not out_f32 and residual is None
         col = ops.vae_im2col3x3(x, 1, 1, H, W, norm, silu)      # stem convolutions: C = 8 (3 / 4 real channels)
@@ -286,10 +302,10 @@ class AutoencoderKL(nn.Module):
         out = ops.gemm(x.rows(), w, ops.NT, bias=b, out_dtype=F32 if out_f32 else BF16)
         return out if out_f32 else x.like_rows(out, w.shape[0])
 
-    def _resnet(self, x, r):
-        h = self._conv3(x, r.conv1, self._norm(x, r.norm1), silu=True)
+    def _resnet(self, x, r, out_stats=True):
+        h = self._conv3(x, r.conv1, self._norm(x, r.norm1), silu=True, stats=True)
         sc = x if r.conv_shortcut is None else self._conv1(x, r.conv_shortcut)
-        return self._conv3(h, r.conv2, self._norm(h, r.norm2), silu=True, residual=sc)
+        return self._conv3(h, r.conv2, self._norm(h, r.norm2), silu=True, residual=sc, stats=out_stats)
 
     def _attention(self, x, at):
         B, HW, C, dev = x.B, x.H * x.W, x.C, x.buf.device
@@ -321,8 +337,8 @@ class AutoencoderKL(nn.Module):
         assert x.shape[1] == self.config.in_channels and x.shape[2] % (1 << n_down) == 0 and x.shape[3] % (1 << n_down) == 0
         h = self._conv3(self._to_grid(x), enc.conv_in)
         for blk in enc.down_blocks:
-            for r in blk.resnets:
-                h = self._resnet(h, r)
+            for i, r in enumerate(blk.resnets):                  # a resampling convolution (no norm) reads the block's last output
+                h = self._resnet(h, r, out_stats=not (hasattr(blk, "downsamplers") and i == len(blk.resnets) - 1))
             if hasattr(blk, "downsamplers"):
                 h = self._conv3_s2(h, blk.downsamplers[0].conv)
         h = self._mid(h, enc.mid_block)
@@ -330,7 +346,7 @@ class AutoencoderKL(nn.Module):
         lc2 = 2 * self.config.latent_channels
         m = self._conv1(h, self.quant_conv, out_f32=True)        # fp32 moments over every pixel slot of h's (padded-grid) layout
         assert h.row_pitch == h.W + 2 and h.origin == h.W + 3
-        m = m.view(h.B, h.H + 2, h.W + 2, -1)[:, 1:-1, 1:-1, :lc2].permute(0, 3, 1, 2).contiguous().to(x.dtype)
+        m = m.view(h.B, h.img_pitch, -1)[:, :(h.H + 2) * (h.W + 2)].view(h.B, h.H + 2, h.W + 2, -1)[:, 1:-1, 1:-1, :lc2].permute(0, 3, 1, 2).contiguous().to(x.dtype)
         dist = DiagonalGaussianDistribution(m)
         return SimpleNamespace(latent_dist=dist) if return_dict else (dist,)
 
@@ -343,10 +359,10 @@ class AutoencoderKL(nn.Module):
         h = self._conv3(h, dec.conv_in)
         h = self._mid(h, dec.mid_block)
         for blk in dec.up_blocks:
-            for r in blk.resnets:
-                h = self._resnet(h, r)
+            for i, r in enumerate(blk.resnets):
+                h = self._resnet(h, r, out_stats=not (hasattr(blk, "upsamplers") and i == len(blk.resnets) - 1))
             if hasattr(blk, "upsamplers"):
-                h = self._conv3(h, blk.upsamplers[0].conv, upsample=2)
+                h = self._conv3(h, blk.upsamplers[0].conv, upsample=2, stats=True)
         img = self._conv3(h, dec.conv_out, self._norm(h, dec.conv_norm_out), silu=True, out_f32=True)
         img = img[..., : self.config.out_channels].permute(0, 3, 1, 2).contiguous().to(z.dtype)
         return SimpleNamespace(sample=img) if return_dict else (img,)

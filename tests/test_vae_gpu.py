@@ -90,6 +90,39 @@ def test_implicit_conv3x3_is_conv2d(ops, B, C, Co, H, W, interleave):
     outf = ops.gemm(a, wk, ops.NT, bias=bias, out_dtype=torch.float32, **seg)                                # fp32 output flavour
     assert rel_l2(outf.view(B, H + 2, W + 2, Co)[:, 1:-1, 1:-1].permute(0, 3, 1, 2), ref) < 2e-5
 
+@pytest.mark.parametrize("B,C,Co,H,W,groups", [(2, 64, 128, 30, 30, 32), (3, 128, 384, 20, 31, 32), (2, 256, 256, 24, 40, 32), (1, 128, 512, 64, 64, 32)])
+@pytest.mark.parametrize("residual", [False, True])
+def test_conv_epilogue_groupnorm_statistics(ops, B, C, Co, H, W, groups, residual):
+    """pxa_gemm_args.gn_part: the implicit convolution's epilogue adds the sum / sum of squares (per quad of adjacent channels) of its bf16-rounded output over
+    the INTERIOR pixels of each image (image pitch rounded to the 256-row tile; border and tail rows hold garbage and must not count);
+    pxa_vae_gn_finalize turns them into the (mean, rstd) torch.nn.GroupNorm computes on that output.  Also the conv result itself in the
+    rounded-pitch layout, with and without the fused residual."""
+    g, x = to_grid(ops, rnd(B, C, H, W, seed=1))
+    w = rnd(Co, C, 3, 3, scale=(9 * C) ** -0.5, seed=2).to(ops.BF16)
+    bias = rnd(Co, seed=3) + 0.5                                                                              # non-zero mean: the variance must survive E[x^2] - E[x]^2
+    rp, ip = W + 2, ((H + 2) * (W + 2) + 255) // 256 * 256
+    buf = torch.zeros((B * ip + 2 * (W + 3)) * C, dtype=ops.BF16, device="cuda")
+    ops.vae_gn_apply(g, ops.Grid(buf, B, H, W, C, rp, ip, origin=(W + 3) + rp + 1))
+    wk = w.permute(0, 2, 3, 1).reshape(Co, 3, 3, C // 64, 64).permute(0, 3, 1, 2, 4).reshape(Co, 9 * C).contiguous()
+    a = buf.as_strided((B * ip, 9 * C), (C, 1))
+    res = (rnd(B * ip, Co, seed=4) * 3.0).to(ops.BF16) if residual else None                                  # garbage-free only in the interior
+    part = torch.zeros(ops.COLSUM_SLOTS, B, Co // 4, 2, device="cuda")
+    out = ops.gemm(a, wk, ops.NT, bias=bias, k_seg=3 * C, a_seg_stride=rp * C, k_tap=C, act=ops.ACT_ADD_AUX if residual else ops.ACT_NONE, aux=res,
+                   gn_part=part, gn_geom=(ip, rp, H, W))
+    y = from_grid(ops.Grid(out, B, H, W, Co, rp, ip, origin=W + 3))                                           # the bf16 output, interior, as fp32
+    ref = F.conv2d(x, w.float(), bias, padding=1)
+    if residual:
+        ref = ref + from_grid(ops.Grid(res, B, H, W, Co, rp, ip, origin=W + 3))
+    assert rel_l2(y, ref) < BF16_TOL
+    sums, yq = part.sum(0), y.view(B, Co // 4, 4, H, W)                                                       # (B, Co/4, 2): per quad of channels
+    assert rel_l2(sums[..., 0], yq.sum((2, 3, 4))) < 1e-5 and rel_l2(sums[..., 1], (yq * yq).sum((2, 3, 4))) < 1e-5
+    mean, rstd = ops.vae_gn_finalize(part, B, Co, groups, H * W, 1e-6)
+    yg = y.view(B, groups, -1)
+    assert rel_l2(mean, yg.mean(-1).flatten()) < 2e-5
+    r = rel_l2(rstd, (yg.var(-1, unbiased=False) + 1e-6).rsqrt().flatten())
+    print(f"conv-epilogue GroupNorm statistics B{B} C{C}->{Co} {H}x{W} residual={residual}: rstd rel-L2 {r:.2e}")
+    assert r < 2e-5
+
 
 @pytest.mark.parametrize("stride", [1, 2])
 def test_im2col_conv(ops, stride):
