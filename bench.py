@@ -285,13 +285,14 @@ def main():
         flops_step = 3 * fwd_flops_per_sample(N) * B          # per GPU, fwd + bwd, no recompute, no optimizer
         out = {
             "metric": "denoising steps/sec (fwd+bwd) PixArt-Sigma-XL/2 1024px bs16 @1/2/4/8 GPU",
-            "value": 1.0 / sec_per_step, "unit": "steps/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            # whole-job aggregate: batch-16 denoising steps completed per second by ALL ranks (every rank runs one per iteration)
+            "value": world / sec_per_step, "unit": "steps/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": sec_per_step * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": a.dtype, "data": "synthetic",
             "config": {"workload": f"PixArt-Sigma-XL/2 {a.image_size}px training step (fwd+bwd+clip+{'CAME' if a.optimizer == 'came' else 'AdamW'}), batch {B}/GPU, L=300 text tokens, "
                                    f"DP={world} RCCL all-reduce", "model": "PixArtMS_XL_2", "global_batch": B * world, "seq_len": N,
                        "parallelism": f"dp{world}", "grad_checkpoint": bool(a.grad_checkpoint), "optimizer": a.optimizer},
-            "images_per_s": B * world / sec_per_step, "final_loss": loss_v, "process_group": "nccl" if use_pg else None,
+            "steps_per_s_per_gpu": 1.0 / sec_per_step, "images_per_s": B * world / sec_per_step, "final_loss": loss_v, "process_group": "nccl" if use_pg else None,
             **({"loss_scale": scaler.value, "steps_skipped": scaler.steps_skipped} if scaler is not None else {}),
             "step_tflops_per_gpu": flops_step / sec_per_step / 1e12,
         }

@@ -36,7 +36,10 @@ def test_loss_scaler_matches_unscaled_step_skips_on_overflow_and_grows():
         mb._store.grad.copy_(gr * sc.value)
         oa.step()
         ob.step()
-    assert torch.allclose(mb._store.master, ma._store.master, rtol=1e-6, atol=1e-9)
+    # The two optimizers see the same gradients up to the fp32 atomic-add order of the global-norm reduction (4096 block partials:
+    # ~1e-6 relative on the norm, run to run) -> the clip coefficient -> at most lr * 1e-5 per step on a weight: atol = 3 steps of that.
+    ATOL = 3 * 1e-3 * 1e-5
+    assert torch.allclose(mb._store.master, ma._store.master, rtol=1e-6, atol=ATOL)
     assert torch.allclose(ob.last_norm, oa.last_norm, rtol=1e-5)                  # the reported norm is the unscaled one
     assert sc.value == 8192.0 and sc.steps_applied == 2 and sc.steps_skipped == 0     # two clean steps -> grown once
     # overflow
@@ -51,7 +54,10 @@ def test_loss_scaler_matches_unscaled_step_skips_on_overflow_and_grows():
     mb._store.grad.copy_(grads[2] * sc.value)
     oa.step()
     ob.step()
-    assert not sc.found_inf and torch.allclose(mb._store.master, ma._store.master, rtol=1e-6, atol=1e-9)
+    assert not sc.found_inf and sc.steps_applied == 3
+    d = (mb._store.master - ma._store.master).abs()
+    tol = ATOL + 1e-6 * ma._store.master.abs()
+    assert bool((d <= tol).all()), f"max |diff| {float(d.max()):.3e}, worst excess over tolerance {float((d - tol).max()):.3e}, elements over {int((d > tol).sum())} of {d.numel()}"
 
 
 def test_came_skips_on_overflow():
