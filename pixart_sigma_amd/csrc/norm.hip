@@ -76,6 +76,9 @@ __global__ __launch_bounds__(256) void ln_mod_fwd_kernel(
 }
 
 constexpr int BWD_ROWS = 16;  // rows per half-wave in the reducing backward kernels
+#ifndef LNB_VARIANT
+#define LNB_VARIANT 1          // 1 = the row's dx_in loads are issued with its other loads (dx_out may alias dx_in, so a load placed behind the
+#endif                         //     previous chunk's store cannot be hoisted: 0 = that order, 312 us; 1: 250 us; 3 = all dx_in loads after the reduction: 407 us)
 
 template <int NV>
 __global__ __launch_bounds__(256) void ln_mod_bwd_kernel(
@@ -117,6 +120,15 @@ __global__ __launch_bounds__(256) void ln_mod_bwd_kernel(
     const size_t base = (size_t)row * D;
     const float mu = mean[row], rs = rstd[row];
     float4 g[NV], xh[NV];
+#if LNB_VARIANT == 1 || LNB_VARIANT == 3
+    float4 di[NV];
+#endif
+#if LNB_VARIANT == 1
+    if (dx_in) {
+#pragma unroll
+      for (int j = 0; j < NV; j++) di[j] = *reinterpret_cast<const float4*>(dx_in + base + (hl + 32 * j) * 4);
+    }
+#endif
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int j = 0; j < NV; j++) {
@@ -134,14 +146,24 @@ __global__ __launch_bounds__(256) void ln_mod_bwd_kernel(
       s2 += (g[j].x * xh[j].x + g[j].y * xh[j].y) + (g[j].z * xh[j].z + g[j].w * xh[j].w);
     }
     const float c1 = half_wave_sum(s1) / D, c2 = half_wave_sum(s2) / D;
+#if LNB_VARIANT == 3
+    if (dx_in) {
+#pragma unroll
+      for (int j = 0; j < NV; j++) di[j] = *reinterpret_cast<const float4*>(dx_in + base + (hl + 32 * j) * 4);
+    }
+#endif
 #pragma unroll
     for (int j = 0; j < NV; j++) {
       const int c = (hl + 32 * j) * 4;
       float4 o = make_float4(rs * (g[j].x - c1 - xh[j].x * c2), rs * (g[j].y - c1 - xh[j].y * c2),
                              rs * (g[j].z - c1 - xh[j].z * c2), rs * (g[j].w - c1 - xh[j].w * c2));
       if (dx_in) {
+#if LNB_VARIANT == 1 || LNB_VARIANT == 3
+        o.x += di[j].x; o.y += di[j].y; o.z += di[j].z; o.w += di[j].w;
+#else
         const float4 di = *reinterpret_cast<const float4*>(dx_in + base + c);
         o.x += di.x; o.y += di.y; o.z += di.z; o.w += di.w;
+#endif
       }
       *reinterpret_cast<float4*>(dx_out + base + c) = o;
       if (dx_bf16) *reinterpret_cast<uint2*>(dx_bf16 + base + c) = pack_bf16x4(o.x, o.y, o.z, o.w);
@@ -199,23 +221,32 @@ __global__ __launch_bounds__(256) void gate_bwd_kernel(
     const int b = row / rows_per_batch;
     if (b != cur_b) { flush(cur_b); cur_b = b; }
     const size_t base = (size_t)row * D;
+    // every load of the row is issued before its first store: dx_out may alias dx (in place), so a load behind a store could not be
+    // hoisted over it and the row became nine serialised load -> store round trips (the same fix took ln_mod_bwd from 3.4 to 4.2 TB/s)
+    float4 gv[NV];
+    uint2 av[NV], uv[NV];
 #pragma unroll
     for (int j = 0; j < NV; j++) {
       const int c = (hl + 32 * j) * 4;
-      float4 g = *reinterpret_cast<const float4*>(dx + base + c);
+      gv[j] = *reinterpret_cast<const float4*>(dx + base + c);
+      if (add) av[j] = *reinterpret_cast<const uint2*>(add + base + c);
+      if (gate) uv[j] = *reinterpret_cast<const uint2*>(u + base + c);
+    }
+#pragma unroll
+    for (int j = 0; j < NV; j++) {
+      const int c = (hl + 32 * j) * 4;
+      float4 g = gv[j];
       if (add) {
-        const uint2 aa = *reinterpret_cast<const uint2*>(add + base + c);
         float a0, a1, a2, a3;
-        unpack_bf16x2(aa.x, a0, a1); unpack_bf16x2(aa.y, a2, a3);
+        unpack_bf16x2(av[j].x, a0, a1); unpack_bf16x2(av[j].y, a2, a3);
         g.x += a0; g.y += a1; g.z += a2; g.w += a3;
       }
       if (dx_out) *reinterpret_cast<float4*>(dx_out + base + c) = g;
       float4 o = g;
       if (gate) {
         const float4 gt = *reinterpret_cast<const float4*>(gate + (size_t)b * mod_stride + c);
-        const uint2 uu = *reinterpret_cast<const uint2*>(u + base + c);
         float u0, u1, u2, u3;
-        unpack_bf16x2(uu.x, u0, u1); unpack_bf16x2(uu.y, u2, u3);
+        unpack_bf16x2(uv[j].x, u0, u1); unpack_bf16x2(uv[j].y, u2, u3);
         ag[j].x += g.x * u0; ag[j].y += g.y * u1; ag[j].z += g.z * u2; ag[j].w += g.w * u3;
         o = make_float4(g.x * gt.x, g.y * gt.y, g.z * gt.z, g.w * gt.w);
       }
