@@ -868,8 +868,9 @@ __global__ __launch_bounds__(512) void gemm_pers_kernel(GemmParams p) {
     // vmcnt retires in issue order - are still in flight: interior tiles of the plain / dual-output bf16 epilogues issue exactly
     // `prev_stores` of them per wave (4 per 32-row slice and output), so the main loop starts while 128 KiB of stores drain instead of
     // behind them (K = 1152 tiles: the store drain was most of a 16 % epilogue cost).  Anything else waits for everything.
-    if (GEMM_STORE_OVERLAP && LAYOUT != 2 && (EPI == 0 || EPI == 1 || EPI == 4 || EPI == 5 || EPI == 6)) {
+    if (GEMM_STORE_OVERLAP && LAYOUT != 2 && EPI != 3) {
       if (prev_stores == 32) wait_vmcnt<32>();
+      else if (prev_stores == 24) wait_vmcnt<24>();
       else if (prev_stores == 20) wait_vmcnt<20>();
       else if (prev_stores == 16) wait_vmcnt<16>();
       else if (prev_stores == 12) wait_vmcnt<12>();
@@ -1168,8 +1169,8 @@ __global__ __launch_bounds__(512) void gemm_pers_kernel(GemmParams p) {
 #endif
     {   // stores this wave has just issued, if every one of them was a full (unpredicated) 16-byte row segment
       const bool interior = mw + tm_eff * 32 <= p.M && nw + 64 <= p.N;
-      // (the statistics flavours issue 4 more vector-memory instructions behind the stores: their atomics)
-      prev_stores = (interior && !want_cs && p.out) ? tm_eff * 4 * (dual ? 2 : 1) + (want_st ? 4 : 0) : 0;
+      // (the statistics / column-sum flavours issue 4 / 8 more vector-memory instructions behind the stores: their atomics)
+      prev_stores = (interior && p.out) ? tm_eff * 4 * (dual ? 2 : 1) + (want_st ? 4 : 0) + (want_cs ? 8 : 0) : 0;
     }
     nk = nk_pf;
     if (!more) break;
