@@ -707,10 +707,10 @@ __global__ __launch_bounds__(512) void gemm_pers_kernel(GemmParams p) {
   // work items: output tile (or paired half-width tile) x k-slice (split-K only for the fp32 weight-gradient layout), XCD-aware order
   const int mt = (p.M + 255) / 256, ntf = p.N / 256, remn = p.N - ntf * 256;
   constexpr bool PAIR = (RM == 1), HALF = (RM == 2);
-  const bool remcol = RM != 0 && remn > 0 && remn <= 128 && (HALF || mt % 2 == 0);
+  const bool remcol = RM != 0 && remn > 0 && remn <= 128;   // PAIR with an odd m-tile count: the last pair's second half lies beyond M (loads clamp, stores are guarded)
   const int ntp = remcol ? ntf : (p.N + 255) / 256;    // n-tile columns handled as (possibly padded) full tiles
   const int rem_pg = remcol ? (PAIR ? 4 : 8) : 0;      // remainder items per group of 8 m-tiles
-  const int per_group = 8 * ntp + rem_pg, tiles = mt * ntp + (remcol ? (PAIR ? mt / 2 : mt) : 0), T = tiles * p.split;
+  const int per_group = 8 * ntp + rem_pg, tiles = mt * ntp + (remcol ? (PAIR ? (mt + 1) / 2 : mt) : 0), T = tiles * p.split;
   auto units_of = [&](int z) { return (min(p.K, (z + 1) * p.k_per_split) - z * p.k_per_split) / BKT; };   // >= 2: k ranges are multiples of 64
 
   // current / prefetched item: row origins of the (two) A row blocks, column origin, paired flag, k-slice
@@ -1181,13 +1181,13 @@ __global__ __launch_bounds__(512) void gemm_pers_kernel(GemmParams p) {
 
 static std::atomic<unsigned> g_launch_seq{0};          // cursor-slot round robin, shared by every instantiation of the persistent kernel
 // work items of the persistent kernel per k-slice (must match the kernel's own count)
-static inline bool pers_pairing(int M, int N) { return N % 256 > 0 && N % 256 <= 128 && ((M + 255) / 256) % 2 == 0; }
+static inline bool pers_pairing(int M, int N) { (void)M; return N % 256 > 0 && N % 256 <= 128; }
 static inline bool pers_halfcol(int N) { return N % 256 > 0 && N % 256 <= 128; }
 static inline int pers_tiles(int M, int N, int rm) {
   const int mt = (M + 255) / 256, ntf = N / 256;
   if (rm == 2 && pers_halfcol(N)) return mt * ntf + mt;
   const bool pairing = rm == 1 && pers_pairing(M, N);
-  return mt * (pairing ? ntf : (N + 255) / 256) + (pairing ? mt / 2 : 0);
+  return mt * (pairing ? ntf : (N + 255) / 256) + (pairing ? (mt + 1) / 2 : 0);
 }
 template <int LAYOUT, int EPI, int RM = 0, bool SEG = false>
 int launch_pers(GemmParams p, int split, hipStream_t s) {
@@ -1357,10 +1357,12 @@ extern "C" int pxa_gemm(const pxa_gemm_args* a, hipStream_t stream) {
   if (a->split_k == 0 && a->out_f32 && a->accumulate && !a->out_bf16 && a->act == 0 && !a->bias && a->K % BK == 0) {
     // Split-K weight-gradient GEMMs (K = tokens, 65536): a handful of long-running workgroups, so wave quantisation against the
     // 256 CUs decides the time.  Pick (tile, split) minimising  rounds x k-tiles x tile cost  + atomic epilogue traffic.
-    // Candidates: 128 x 128 tiles, two workgroups per CU (512 slots, ~800 TF/s when full) and the persistent 256 x 256 kernel
-    // (256 slots, ~1000 TF/s when full).  time = rounds x k-range x tile FLOPs / per-slot rate  +  slab write + read + reduce.
+    // Candidates: 128 x 128 tiles, two workgroups per CU (512 slots, ~760 TF/s when full) and the persistent 256 x 256 kernel
+    // (256 slots, ~1050 TF/s when full since the 16-MFMA phases; with the round-1 constants 800 / 1000 the 1152 x 1152 gradients still went
+    // to the 128 kernel: 232-245 us against 212 for 25 padded 256 tiles x 10 k-slices).
+    // time = rounds x k-range x tile FLOPs / per-slot rate  +  slab write + read + reduce.
     struct Cfg { int tile, bm, bn, slots; double rate; };
-    const Cfg cfgs[2] = {{128, 128, 128, 512, 800e12}, {256, 256, 256, 256, 1000e12}};
+    const Cfg cfgs[2] = {{128, 128, 128, 512, 760e12}, {256, 256, 256, 256, 1050e12}};
     double best = 1e30;
     for (const Cfg& c : cfgs) {
       if (c.tile == 256 && (a->M < 256 || a->N < 256)) continue;
