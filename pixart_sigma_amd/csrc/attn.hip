@@ -307,6 +307,48 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* __restric
   delta[((long)b * H + h) * Nq + q] = acc;
 }
 
+// Same for token-contiguous O / dO ([B][Nq][H][72], what the engine passes): the kernel above reads adjacent 144-byte rows from adjacent
+// lanes (every 16-byte load of a wave touches 64 different cache lines) and scatters its 4-byte results Nq floats apart.  Here a block
+// takes 16 tokens = 2,304 16-byte chunks, reads them fully coalesced (9 per thread), parks the per-chunk partial dot products in LDS and
+// lets thread (h, q) add the 9 partials of its head: 64-byte runs of delta per head.
+constexpr int DELTA_TOK = 16;
+__global__ __launch_bounds__(256) void attn_delta_rows_kernel(const bf16_t* __restrict__ O, const bf16_t* __restrict__ dO, float* __restrict__ delta,
+                                                              int H, int Nq, long tokens) {
+  __shared__ float part[DELTA_TOK * 16 * NCH + 16];
+  const long tok0 = (long)blockIdx.x * DELTA_TOK;
+  const int cpt = H * NCH;                                 // chunks per token (144)
+  const long nchunks = min((long)DELTA_TOK, tokens - tok0) * cpt;
+  const uint4* po = reinterpret_cast<const uint4*>(O) + tok0 * cpt;
+  const uint4* pd = reinterpret_cast<const uint4*>(dO) + tok0 * cpt;
+  uint4 a[NCH], d[NCH];
+#pragma unroll
+  for (int i = 0; i < NCH; i++) {
+    const int c = threadIdx.x + 256 * i;
+    if (c < nchunks) { a[i] = po[c]; d[i] = pd[c]; }
+  }
+#pragma unroll
+  for (int i = 0; i < NCH; i++) {
+    const int c = threadIdx.x + 256 * i;
+    if (c < nchunks) {
+      float fa[8], fd[8], acc = 0.f;
+      unpack_bf16x8(a[i], fa); unpack_bf16x8(d[i], fd);
+#pragma unroll
+      for (int e = 0; e < 8; e++) acc += fa[e] * fd[e];
+      part[c] = acc;
+    }
+  }
+  __syncthreads();
+  const int ql = threadIdx.x % DELTA_TOK, h = threadIdx.x / DELTA_TOK;   // H <= 16
+  const long tok = tok0 + ql;
+  if (h < H && tok < tokens) {
+    float acc = 0.f;
+#pragma unroll
+    for (int i = 0; i < NCH; i++) acc += part[ql * cpt + h * NCH + i];
+    const long b = tok / Nq, q = tok - b * Nq;
+    delta[(b * H + h) * Nq + q] = acc;
+  }
+}
+
 // Forward with TWO query sub-tiles per wave (256 queries per workgroup).  A K or V^T fragment read from LDS now feeds two MFMAs,
 // and a K/V tile pair fetched by LDS-DMA serves twice as many queries: the single-sub-tile kernel above moves 12.9 GB from L2 into
 // LDS per self-attention launch (8.6 TB/s - the same ballpark as the GEMM's DMA-only ceiling) and issues 1.9 LDS instructions per
@@ -691,8 +733,13 @@ extern "C" int pxa_attn_bwd(const pxa_attn_args* a, hipStream_t stream) {
   for (long s : {p.dq_ts, p.dk_ts, p.dv_ts, (long)p.dq_hs, (long)p.dk_hs, (long)p.dv_hs, p.dq_bs, p.dk_bs, p.dv_bs})
     PXA_CHECK(s % 4 == 0, "pxa_attn_bwd: gradient strides must be multiples of 4 elements");
   const long total = (long)p.B * p.Nq * p.H;
-  hipLaunchKernelGGL(attn_delta_kernel, dim3((total + 255) / 256), dim3(256), 0, stream, p.O, p.dO, a->delta,
-                     p.o_bs, p.o_ts, p.o_hs, p.o_bs, p.o_ts, p.o_hs, p.B, p.H, p.Nq);
+  if (p.o_hs == DH && p.o_ts == (long)p.H * DH && p.o_bs == (long)p.Nq * p.o_ts && p.H <= 16 && ((uintptr_t)p.O % 16) == 0 && ((uintptr_t)p.dO % 16) == 0) {
+    const long tokens = (long)p.B * p.Nq;                  // token-contiguous rows: the coalesced form
+    hipLaunchKernelGGL(attn_delta_rows_kernel, dim3((tokens + DELTA_TOK - 1) / DELTA_TOK), dim3(256), 0, stream, p.O, p.dO, a->delta, p.H, p.Nq, tokens);
+  } else {
+    hipLaunchKernelGGL(attn_delta_kernel, dim3((total + 255) / 256), dim3(256), 0, stream, p.O, p.dO, a->delta,
+                       p.o_bs, p.o_ts, p.o_hs, p.o_bs, p.o_ts, p.o_hs, p.B, p.H, p.Nq);
+  }
   PXA_LAUNCH_CHECK();
   if (p.dQ) {
     hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3((p.Nq + 127) / 128, p.H, p.B), dim3(256), 0, stream, p);
