@@ -156,8 +156,14 @@ class FusedAdamW:
     def last_norm(self):
         return self.coef[1]
 
+    def _check_store(self):
+        if self.model._store is not self.store:
+            raise RuntimeError("the model rebuilt its flat parameter store after this optimizer was created (model moved to another device, or a "
+                               "parameter's storage was replaced): the optimizer would update orphaned buffers - build the optimizer after the move")
+
     def step(self):
         from . import ops
+        self._check_store()
         self.store.attach_grads()            # adopt gradients autograd may have allocated outside the flat buffer
         inv_world = self.reducer.finish()
         self.t += 1
@@ -273,6 +279,7 @@ class FusedCAME(FusedAdamW):
     def step(self):
         from . import ops
         from .lib import CameArgs, call, ptr
+        self._check_store()
         self.store.attach_grads()
         inv_world = self.reducer.finish()
         self.t += 1

@@ -332,6 +332,9 @@ class PixArtMS(nn.Module):
         return self
 
     def _prepare(self, device):
+        device = torch.device(device)
+        if device.type == "cuda" and device.index is None:     # "cuda" and "cuda:<current>" are the same place: without this a store built by
+            device = torch.device("cuda", torch.cuda.current_device())   # prepare("cuda") was rebuilt (hooks and optimizer state orphaned) by the first forward
         named = self._ordered_named_params()
         if self._store is None or self._store.device != device or not self._store.owns_all(named):
             if any(p.dtype != F32 for _, p in named):
