@@ -28,7 +28,7 @@ sys.path.insert(0, ROOT)
 
 D, H, DFF, DEPTH, LTXT = 1152, 16, 4608, 28, 300
 MFMA_PEAK = 2.5e15   # dense bf16, MI355X (MI355X_MICROARCH.md)
-PMC_FILES = ["profiles/r02_pmc_attention.json", "profiles/r01_pmc_attention.json"]   # newest first (tools/pmc_query.py --json)
+PMC_FILES = ["profiles/r02b_pmc_attention.json", "profiles/r02_pmc_attention.json", "profiles/r01_pmc_attention.json"]   # newest first (tools/pmc_query.py --json)
 
 
 def pmc_traffic(kernel_substr, grid):
@@ -42,7 +42,7 @@ def pmc_traffic(kernel_substr, grid):
         with open(path) as f:
             rows = json.load(f)["kernels"]
         for r in rows:
-            if kernel_substr in r["kernel"] and r.get("grid") == grid and "FETCH_SIZE" in r["counters"] and "WRITE_SIZE" in r["counters"]:
+            if kernel_substr in r["kernel"] and r.get("grid") in grid and "FETCH_SIZE" in r["counters"] and "WRITE_SIZE" in r["counters"]:
                 return 2 * r["counters"]["FETCH_SIZE"] * 1e3 + r["counters"]["WRITE_SIZE"] * 1e3, f"{rel}: 2 x FETCH_SIZE (gfx950 correction) + WRITE_SIZE, separate --pmc passes, bytes per launch"
     return None, "no PMC file for this kernel / grid under profiles/"
 
@@ -302,7 +302,7 @@ def main():
             ks = kernel_rooflines(B, N)
             # dominant kernel of the step by total time (profiles/: attn_bwd_dkv_kernel, 56 launches, ~17 % of the step)
             dom = ks["attn_bwd_dkv_kernel"]
-            traffic, tsrc = pmc_traffic("attn_bwd_dkv_kernel", N // 128)     # x-dimension of the launch grid: 32 key blocks = the self-attention launch
+            traffic, tsrc = pmc_traffic("attn_bwd_dkv_kernel", ((N // 128) * H * B, N // 128))   # workgroups of the self-attention launch: flat grid (since r02b), x extent of the old 3-D grid
             roof = {"bound": "mfma", "kernel": "attn_bwd_dkv_kernel (self-attention, B16 H16 N4096 d72)", "achieved": dom["tflops"], "peak": MFMA_PEAK / 1e12,
                     "unit": "TFLOP/s", "frac": dom["frac"], "traffic": traffic, "traffic_source": tsrc,
                     "flops_per_launch": dom["flops"], "ms_per_launch": dom["seconds"] * 1e3,

@@ -52,7 +52,29 @@ struct AttnParams {
   int B, H, Nq, Nk;
   const int* kv_start; const int* kv_len;  // optional per-batch varlen (rows into the packed K/V)
   float scale, scale_log2;
+  int nx;              // blocks per (batch, head) of the launch: the grid is the flat nx * H * B, see block_coords()
 };
+
+// Block -> (row block, head, batch).  Every block of one (batch, head) streams the same rows (K / V in the forward and dQ kernels,
+// Q / dO / lse / delta in the dK/dV kernel).  Workgroup i of a launch runs on XCD i % 8 (observed dispatch rule, used for speed
+// only) and the eight L2s do not share: in plain x-fastest order the nx blocks of a head are dealt round-robin to all eight XCDs and
+// each of them fetches the head's rows from HBM for itself - measured on the dK/dV kernel at B16 H16 N4096: 2.72 GB fetched per launch
+// for 0.60 GB of operands (profiles/r02_pmc_attention.txt).  Here XCD x takes the contiguous range [xs(x), xs(x) + xc(x)) of that order,
+// i.e. whole heads: the 32 CUs of an XCD work on the same one or two heads at a time and the rows come from HBM once.
+#ifndef ATTN_XCD_HEADS
+#define ATTN_XCD_HEADS 1   // 0 = plain order (A/B builds, tools/build_variant.py)
+#endif
+__device__ __forceinline__ void block_coords(const AttnParams& p, int& bx, int& h, int& b) {
+  int v = blockIdx.x;
+#if ATTN_XCD_HEADS
+  const int T = gridDim.x, xq = T >> 3, xr = T & 7, xcd = v & 7;
+  v = xcd * xq + min(xcd, xr) + (v >> 3);
+#endif
+  bx = v % p.nx;
+  const int hb = v / p.nx;
+  h = hb % p.H;
+  b = hb / p.H;
+}
 
 __device__ __forceinline__ void kv_range(const AttnParams& p, int b, long& kbase, long& vbase, long& dkbase, long& dvbase, int& len) {
   if (p.kv_start) {
@@ -179,8 +201,9 @@ template <bool B> struct BoolC { static constexpr bool value = B; };
 __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
   __shared__ __attribute__((aligned(16))) char smem[4 * TILE_B];   // 2 stages x {K, V}
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), hi = lane >> 5;
-  const int b = blockIdx.z, h = blockIdx.y;
-  const int q = blockIdx.x * 128 + wave * 32 + (lane & 31);
+  int bx, h, b;
+  block_coords(p, bx, h, b);
+  const int q = bx * 128 + wave * 32 + (lane & 31);
   const bool qvalid = q < p.Nq;
   long kbase, vbase, d0_, d1_; int kvlen;
   kv_range(p, b, kbase, vbase, d0_, d1_, kvlen);
@@ -357,7 +380,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd2_kernel(AttnParams p) {
   constexpr int QS = 2;
   __shared__ __attribute__((aligned(16))) char smem[4 * TILE_B];   // 2 stages x {K, V}
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), hi = lane >> 5;
-  const int b = blockIdx.z, h = blockIdx.y;
+  int bx, h, b;
+  block_coords(p, bx, h, b);
   long kbase, vbase, d0_, d1_; int kvlen;
   kv_range(p, b, kbase, vbase, d0_, d1_, kvlen);
   const bf16_t* Kp = p.K + kbase + (long)h * p.k_hs;
@@ -369,7 +393,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd2_kernel(AttnParams p) {
   bf16x8 qf[QS][KSTEPS];
 #pragma unroll
   for (int s = 0; s < QS; s++) {
-    q[s] = blockIdx.x * 256 + wave * 64 + s * 32 + (lane & 31);
+    q[s] = bx * 256 + wave * 64 + s * 32 + (lane & 31);
     qvalid[s] = q[s] < p.Nq;
     load_row_frags(qf[s], p.Q + (long)b * p.q_bs + (long)q[s] * p.q_ts + (long)h * p.q_hs, qvalid[s], hi);
   }
@@ -493,8 +517,9 @@ __global__ __launch_bounds__(256, 2) void attn_fwd2_kernel(AttnParams p) {
 __global__ __launch_bounds__(256, ATTN_BWD_WAVES) void attn_bwd_dq_kernel(AttnParams p) {
   __shared__ __attribute__((aligned(16))) char smem[4 * TILE_B];   // 2 stages x {K, V}
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), hi = lane >> 5;
-  const int b = blockIdx.z, h = blockIdx.y;
-  const int q = blockIdx.x * 128 + wave * 32 + (lane & 31);
+  int bx, h, b;
+  block_coords(p, bx, h, b);
+  const int q = bx * 128 + wave * 32 + (lane & 31);
   const bool qvalid = q < p.Nq;
   long kbase, vbase, d0_, d1_; int kvlen;
   kv_range(p, b, kbase, vbase, d0_, d1_, kvlen);
@@ -577,12 +602,16 @@ __global__ __launch_bounds__(256, ATTN_BWD_WAVES) void attn_bwd_dkv_kernel(AttnP
   __shared__ __attribute__((aligned(16))) char smem[4 * TILE_B + 4 * BKV * 4];   // 2 stages x {Q, dO} + 2 stages x {lse, delta}
   float* ldsL = reinterpret_cast<float*>(smem + 4 * TILE_B);                      // [2][2][64]
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), hi = lane >> 5;
-  const int b = blockIdx.z, h = blockIdx.y;
+  int bx, h, b;
+  block_coords(p, bx, h, b);
   long kbase, vbase, dkbase, dvbase; int kvlen;
   kv_range(p, b, kbase, vbase, dkbase, dvbase, kvlen);
-  if ((int)(blockIdx.x * 128) >= kvlen) return;  // whole block beyond this sample's keys (uniform across the block)
-  const int kv = blockIdx.x * 128 + wave * 32 + (lane & 31);
+  if (bx * 128 >= kvlen) return;  // whole block beyond this sample's keys (uniform across the block)
+  const int kv = bx * 128 + wave * 32 + (lane & 31);
   const bool kvvalid = kv < kvlen;
+  // A wave whose 32 keys all lie beyond the sample's length (text keys: 300 = 128 + 128 + 32 + 12) still serves the block's LDS-DMA and
+  // barriers but issues no MFMA / softmax work: the matrix pipe of its SIMD is left to the co-resident workgroup's wave.
+  const bool wave_active = bx * 128 + wave * 32 < kvlen;
 
   bf16x8 kf[KSTEPS], vf[KSTEPS];
   load_row_frags(kf, p.K + kbase + (long)kv * p.k_ts + (long)h * p.k_hs, kvvalid, hi);
@@ -631,6 +660,7 @@ __global__ __launch_bounds__(256, ATTN_BWD_WAVES) void attn_bwd_dkv_kernel(AttnP
     if (tid < BKV) { sL[tid] = rl; sL[BKV + tid] = rdl; }   // buffer (t&1) was last read two iterations ago
     __syncthreads();
     if (!(ATTN_ABL & 16) && t + 1 < T) issue(t + 1);
+    if (!wave_active) continue;
 #pragma unroll
     for (int sub = 0; sub < 2; sub++) {
       f32x16 s, dp;
@@ -719,8 +749,11 @@ extern "C" int pxa_attn_fwd(const pxa_attn_args* a, hipStream_t stream) {
   if (int rc = fill(p, a)) return rc;
   PXA_CHECK(p.Q && p.K && p.V && p.O, "pxa_attn_fwd: null tensor");
   static const bool one_sub = getenv("PXA_ATTN_FWD1") != nullptr;   // A/B: the one-sub-tile kernel
-  if (!one_sub && p.Nq >= 256) hipLaunchKernelGGL(attn_fwd2_kernel, dim3((p.Nq + 255) / 256, p.H, p.B), dim3(256), 0, stream, p);
-  else hipLaunchKernelGGL(attn_fwd_kernel, dim3((p.Nq + 127) / 128, p.H, p.B), dim3(256), 0, stream, p);
+  const bool two = !one_sub && p.Nq >= 256;
+  p.nx = two ? (p.Nq + 255) / 256 : (p.Nq + 127) / 128;
+  PXA_CHECK((long)p.nx * p.H * p.B < (1L << 31), "pxa_attn_fwd: grid too large");
+  if (two) hipLaunchKernelGGL(attn_fwd2_kernel, dim3(p.nx * p.H * p.B), dim3(256), 0, stream, p);
+  else hipLaunchKernelGGL(attn_fwd_kernel, dim3(p.nx * p.H * p.B), dim3(256), 0, stream, p);
   PXA_LAUNCH_CHECK();
   return 0;
 }
@@ -742,12 +775,16 @@ extern "C" int pxa_attn_bwd(const pxa_attn_args* a, hipStream_t stream) {
   }
   PXA_LAUNCH_CHECK();
   if (p.dQ) {
-    hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3((p.Nq + 127) / 128, p.H, p.B), dim3(256), 0, stream, p);
+    p.nx = (p.Nq + 127) / 128;
+    PXA_CHECK((long)p.nx * p.H * p.B < (1L << 31), "pxa_attn_bwd: grid too large");
+    hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3(p.nx * p.H * p.B), dim3(256), 0, stream, p);
     PXA_LAUNCH_CHECK();
   }
   if (p.dK) {
     const int max_k = a->max_kv_len > 0 ? a->max_kv_len : p.Nk;
-    hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3((max_k + 127) / 128, p.H, p.B), dim3(256), 0, stream, p);
+    p.nx = (max_k + 127) / 128;
+    PXA_CHECK((long)p.nx * p.H * p.B < (1L << 31), "pxa_attn_bwd: grid too large");
+    if (p.nx > 0) hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3(p.nx * p.H * p.B), dim3(256), 0, stream, p);
     PXA_LAUNCH_CHECK();
   }
   return 0;

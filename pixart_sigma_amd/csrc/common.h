@@ -94,6 +94,18 @@ __device__ __forceinline__ f32x16 mfma32(bf16x8 a, bf16x8 b, f32x16 c) {
 #endif
 }
 
+// v_mfma_f32_16x16x32 (probe/probe.hip): A[i = l&15][k = 8*(l>>4) + j], B[k = 8*(l>>4) + j][n = l&15], j = 0..7; C: col = l&15, row = 4*(l>>4) + g,
+// g = 0..3.  Same FLOP rate on paper as the 32x32x16 form, but per FLOP it moves half the accumulator words through the register file:
+// on N(0,1) operands the chip's power limit lets an MFMA-only loop of this shape run 12 % faster (1.95 vs 1.75 PFLOP/s, probe/mfma_power.hip,
+// profiles/r02b_mfma_power.txt); with zero operands it is 2 % slower (17 vs 16 issue cycles per 16 cycles of work).
+__device__ __forceinline__ f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) {
+#ifdef PXA_OPERAND_F16
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+#else
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+#endif
+}
+
 // GELU(approximate="tanh") and its derivative (reference: nn.GELU(approximate="tanh"), PixArtMS.py:66), written through the
 // identity 0.5 (1 + tanh u) = sigmoid(2u) = 1 / (1 + 2^w),  w = -2 log2(e) k0 x (1 + k1 x^2):
 //   gelu(x)  = x s                                   7 VALU ops, 2 of them transcendental (v_exp_f32, v_rcp_f32)

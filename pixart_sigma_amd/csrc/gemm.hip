@@ -592,7 +592,12 @@ __device__ __forceinline__ void wait_vm_upto(int n) {      // n (wave-uniform) i
 }
 #define PXA_SB() __builtin_amdgcn_sched_barrier(0)
 #ifndef GEMM_ABL
-#define GEMM_ABL 0          // ablation bits (tools/build_variant.py; wrong results on purpose): 1 = every k-unit re-fetches the item's FIRST unit (cache-hot DMA), 2 = no bf16 epilogue
+#define GEMM_ABL 0          // ablation bits (tools/build_variant.py; wrong results on purpose): 1 = every k-unit re-fetches the item's FIRST unit (cache-hot DMA), 2 = no bf16 epilogue,
+#endif                      // 4 = the main loop's FLOPs issued as v_mfma_f32_16x16x32 on the quarters of each accumulator tile (what the other MFMA shape would buy)
+#if GEMM_ABL & 4
+__device__ __forceinline__ void mfma_abl16(f32x4 (&q)[4], bf16x8 b0, bf16x8 a0, bf16x8 b1, bf16x8 a1) {
+  q[0] = mfma16(b0, a0, q[0]); q[1] = mfma16(b1, a1, q[1]); q[2] = mfma16(b0, a1, q[2]); q[3] = mfma16(b1, a0, q[3]);
+}
 #endif
 #ifndef GEMM_STORE_OVERLAP
 #define GEMM_STORE_OVERLAP 1   // next item's main loop starts over the draining epilogue stores (counted vmcnt); 0 = wait for them (A/B)
@@ -856,6 +861,15 @@ __global__ __launch_bounds__(512) void gemm_pers_kernel(GemmParams p) {
       for (int j = 0; j < TN; j++)
 #pragma unroll
         for (int g = 0; g < 16; g++) acc[i][j][g] = 0.f;
+#if GEMM_ABL & 4
+    f32x4 a4[TM][TN][4];
+#pragma unroll
+    for (int i = 0; i < TM; i++)
+#pragma unroll
+      for (int j = 0; j < TN; j++)
+#pragma unroll
+        for (int q = 0; q < 4; q++) a4[i][j][q] = f32x4{0.f, 0.f, 0.f, 0.f};
+#endif
     // this item's fragment geometry (the prefetch of the next item will overwrite vt / m0a / ...)
     const bool vtc = PAIR && vt, hfc = HALF && vt;
     const int a_rb = hfc ? (wave >> 1) * 64 : (vtc ? (wn >> 1) * 256 : 0) + wm * 128, b_rb = (vtc || hfc) ? (wn & 1) * 64 : wn * 64;
@@ -910,12 +924,19 @@ __global__ __launch_bounds__(512) void gemm_pers_kernel(GemmParams p) {
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       PXA_SB(); __builtin_amdgcn_s_barrier(); PXA_SB();
       __builtin_amdgcn_s_setprio(1);
+#if GEMM_ABL & 4
+#pragma unroll
+      for (int i = 0; i < 2 * TH; i++)
+#pragma unroll
+        for (int j = 0; j < TN; j++) mfma_abl16(a4[i][j], bf[0][j], af[0][i], bf[1][j], af[1][i]);
+#else
 #pragma unroll
       for (int ks = 0; ks < 2; ks++)
 #pragma unroll
         for (int i = 0; i < 2 * TH; i++)
 #pragma unroll
           for (int j = 0; j < TN; j++) acc[i][j] = mfma32(bf[ks][j], af[ks][i], acc[i][j]);
+#endif
       __builtin_amdgcn_s_setprio(0);
       PXA_SB(); __builtin_amdgcn_s_barrier(); PXA_SB();
     };
@@ -946,12 +967,19 @@ __global__ __launch_bounds__(512) void gemm_pers_kernel(GemmParams p) {
         if (h == 0) rest_a(); else rest_b();
         PXA_SB(); __builtin_amdgcn_s_barrier(); PXA_SB();
         __builtin_amdgcn_s_setprio(1);
+#if GEMM_ABL & 4
+#pragma unroll
+        for (int i = 0; i < TH; i++)
+#pragma unroll
+          for (int j = 0; j < TN; j++) mfma_abl16(a4[h * TH + i][j], bf[0][j], af[0][i], bf[1][j], af[1][i]);
+#else
 #pragma unroll
         for (int ks = 0; ks < 2; ks++)
 #pragma unroll
           for (int i = 0; i < TH; i++)
 #pragma unroll
             for (int j = 0; j < TN; j++) acc[h * TH + i][j] = mfma32(bf[ks][j], af[ks][i], acc[h * TH + i][j]);
+#endif
         __builtin_amdgcn_s_setprio(0);
         PXA_SB(); __builtin_amdgcn_s_barrier(); PXA_SB();
       }
@@ -967,6 +995,14 @@ __global__ __launch_bounds__(512) void gemm_pers_kernel(GemmParams p) {
       unit(t++, IntC<0>{}, th_c);
     };
     if (HALF && hfc) run_units(IntC<1>{}); else run_units(IntC<2>{});
+#if GEMM_ABL & 4
+#pragma unroll
+    for (int i = 0; i < TM; i++)
+#pragma unroll
+      for (int j = 0; j < TN; j++)
+#pragma unroll
+        for (int g = 0; g < 16; g++) acc[i][j][g] = a4[i][j][g >> 2][g & 3];
+#endif
     PXA_TR(2);
     if (!late) __builtin_amdgcn_s_barrier();           // every wave has executed the same number of barriers; the ring is idle
     PXA_TR(3);
