@@ -197,6 +197,104 @@ __device__ __forceinline__ void zero3(f32x16 (&a)[3]) {
 }
 template <bool B> struct BoolC { static constexpr bool value = B; };
 
+// ------------------------------------------------------------------------------------------------ second products on 16x16x32 MFMAs
+// O^T = V^T P^T, dQ^T = K^T dS^T, dV^T = dO^T P, dK^T = Q^T dS: the products whose OUTPUT rows are the head dimension.  With 32-row tiles
+// 72 rows pad to 96 (3 tiles); with the 16-row shape to 80 (5 tiles): 10 v_mfma_f32_16x16x32 per 32 x 32 block of P instead of 6
+// v_mfma_f32_32x32x16 = 160 instead of 192 matrix-pipe cycles, and the 16-row shape is the one the power limit favours (common.h).
+// The first products stay on 32x32x16 (their REDUCTION runs over the head dimension: 80 = 5 x 16, where K = 32 steps would need 96).
+// Operand B.  A 32 x 32 block of P^T sits in the first product's accumulators: lane (col n = l & 31, hi = l >> 5) holds rows
+// (g & 3) + 8 (g >> 2) + 4 hi, g = 0..15.  The 16-row shape wants, per 16-lane row R = l >> 4 of the wave, 8 k-values of column l & 15.
+// With a = rows {0-3, 16-19} + 4 hi (g 0-3, 8-11) and b = rows {8-11, 24-27} + 4 hi (g 4-7, 12-15), both packed to 4 dwords, one
+// v_permlane16_swap per dword (odd 16-lane rows of the first operand <-> even rows of the second) leaves
+//   X = {a(R0), b(R0), a(R2), b(R2)}: columns 0-15,  lane row R holds rows k16(R) + {0-3} and k16(R) + 16 + {0-3}
+//   Y = {a(R1), b(R1), a(R3), b(R3)}: columns 16-31, same rows,                     k16(R) = 8 (R & 1) + 4 (R >> 1)
+// in the original lane rows R0..R3 - the two B operands of the block, 4 extra VALU instructions.
+// Operand A.  X^T[d = 16 t + (l & 15)][those 8 rows] of a row-major [row][d] LDS tile: two transpose reads (ds_read_b64_tr_b16: inside a
+// 16-lane group, lanes 4 i .. 4 i + 3 address row i of a [4][16] block and lane c receives column c), rows k16(R) + i and k16(R) + 16 + i.
+// The two 16-lane groups of a 32-lane LDS group read rows 8 apart: same bank base (8 x 192 B = 6 x 256 B), XOR swizzle differing in bit 1
+// -> the two halves of one 64-byte window, as in the 32-row fragment: conflict-free.
+// Result.  Lane (R, c) holds X^T[16 t + 4 R + g][column], g = 0..3, for columns c (from X) and 16 + c (from Y): 8 contiguous bytes of
+// two output rows per tile.
+struct Tr16Addr { int tb[2][2]; };   // [read e][tile parity]: the swizzle XOR acts on chunk bits 0-1 and a 16-wide tile starts at chunk 2 t
+__device__ __forceinline__ void tr16_addr(Tr16Addr& ta, int lane) {
+  const int gg = lane >> 4, tt = lane & 15, x = (tt & 3) >> 1;
+#pragma unroll
+  for (int e = 0; e < 2; e++) {
+    const int row = 8 * (gg & 1) + 4 * (gg >> 1) + (tt >> 2) + 16 * e, sw = (row >> 2) & 3;
+#pragma unroll
+    for (int par = 0; par < 2; par++) ta.tb[e][par] = row * ROWB + (((2 * par + x) ^ sw) << 4) + (tt & 1) * 8;
+  }
+}
+__device__ __forceinline__ bf16x8 trfrag16(const char* lds, const Tr16Addr& ta, int t, int sub) {
+  const int off = sub * 32 * ROWB + (t >> 1) * 64;
+  return concat_tr(lds_tr_read(lds + ta.tb[0][t & 1] + off), lds_tr_read(lds + ta.tb[1][t & 1] + off));
+}
+__device__ __forceinline__ void pack_xy(const f32x16& v, bf16x8& x, bf16x8& y) {
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  bf16x8 a, b;
+#pragma unroll
+  for (int j = 0; j < 4; j++) { a[j] = (bf16_t)v[j]; a[4 + j] = (bf16_t)v[8 + j]; b[j] = (bf16_t)v[4 + j]; b[4 + j] = (bf16_t)v[12 + j]; }
+  const u32x4 ua = __builtin_bit_cast(u32x4, a), ub = __builtin_bit_cast(u32x4, b);
+  u32x4 ux, uy;
+#pragma unroll
+  for (int w = 0; w < 4; w++) {
+    const auto r = __builtin_amdgcn_permlane16_swap(ua[w], ub[w], false, false);
+    ux[w] = r[0]; uy[w] = r[1];
+  }
+  x = __builtin_bit_cast(bf16x8, ux);
+  y = __builtin_bit_cast(bf16x8, uy);
+}
+#ifndef ATTN_PV16
+#define ATTN_PV16 1    // forward and dQ kernels: 0 = second products on three 32-row tiles (the round-1 kernels; A/B builds, tools/build_variant.py)
+#endif
+#ifndef ATTN_DKV16
+#define ATTN_DKV16 0   // dK/dV kernel: 0 = 32-row tiles, 1 = both second products on the 16-row shape, 2 = the same with the dV / dK MFMAs of a d tile
+#endif                 // interleaved in source order, 3 = dV on the 16-row shape and dK on 32-row tiles
+constexpr int NT16 = 5;              // ceil(72 / 16) output tiles
+struct Acc16 { f32x4 v[NT16][2]; };  // [d tile][column half]: lane (R, c) <-> d = 16 t + 4 R + g, output row c / 16 + c of the wave's 32
+__device__ __forceinline__ void zero16(Acc16& a) {
+#pragma unroll
+  for (int t = 0; t < NT16; t++)
+#pragma unroll
+    for (int h = 0; h < 2; h++) a.v[t][h] = f32x4{0.f, 0.f, 0.f, 0.f};
+}
+__device__ __forceinline__ void mma16(Acc16& acc, const char* lds, const Tr16Addr& ta, int sub, const bf16x8& x, const bf16x8& y) {
+#pragma unroll
+  for (int t = 0; t < NT16; t++) {
+    const bf16x8 af = trfrag16(lds, ta, t, sub);
+    acc.v[t][0] = mfma16(af, x, acc.v[t][0]);
+    acc.v[t][1] = mfma16(af, y, acc.v[t][1]);
+  }
+}
+// rows X[row0 + c][0..71] and X[row0 + 16 + c][0..71] (token stride ts); mul0 / mul1 scale the two rows, ok0 / ok1 guard them
+__device__ __forceinline__ void store_rows16(bf16_t* __restrict__ base, long ts, const Acc16& acc, float mul0, float mul1, bool ok0, bool ok1, int lane) {
+  const int R = lane >> 4, c = lane & 15;
+  bf16_t* r0 = base + (long)c * ts;
+  bf16_t* r1 = base + (long)(16 + c) * ts;
+#pragma unroll
+  for (int t = 0; t < NT16; t++) {
+    const int d0 = 16 * t + 4 * R;
+    if (16 * t + 12 < DH || d0 < DH) {                   // compile-time for t < 4, lane rows 0 / 1 of the last tile
+      if (ok0) *reinterpret_cast<uint2*>(r0 + d0) = pack_bf16x4(acc.v[t][0][0] * mul0, acc.v[t][0][1] * mul0, acc.v[t][0][2] * mul0, acc.v[t][0][3] * mul0);
+      if (ok1) *reinterpret_cast<uint2*>(r1 + d0) = pack_bf16x4(acc.v[t][1][0] * mul1, acc.v[t][1][1] * mul1, acc.v[t][1][2] * mul1, acc.v[t][1][3] * mul1);
+    }
+  }
+}
+// bias gradient of the Linear that produced this operand (see colsum_rows): colsum[d] += sum over the wave's 32 rows
+__device__ __forceinline__ void colsum_rows16(float* __restrict__ dst, const Acc16& acc, float mul, bool ok0, bool ok1, int lane) {
+  const int R = lane >> 4, c = lane & 15;
+#pragma unroll
+  for (int t = 0; t < NT16; t++)
+#pragma unroll
+    for (int g = 0; g < 4; g++) {
+      float v = (ok0 ? acc.v[t][0][g] : 0.f) + (ok1 ? acc.v[t][1][g] : 0.f);
+      v += __shfl_xor(v, 8); v += __shfl_xor(v, 4); v += __shfl_xor(v, 2); v += __shfl_xor(v, 1);
+      const int d = 16 * t + 4 * R + g;
+      if (c == 0 && d < DH) atomicAdd(dst + d, v * mul);
+    }
+}
+
+
 // ------------------------------------------------------------------------------------------------ forward
 __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
   __shared__ __attribute__((aligned(16))) char smem[4 * TILE_B];   // 2 stages x {K, V}
@@ -222,8 +320,15 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
     init_pads(smem + st * 2 * TILE_B, false, tid);            // K
     init_pads(smem + st * 2 * TILE_B + TILE_B, true, tid);    // V: column 72 = 1 -> O^T row 72 accumulates sum_kv P = l
   }
+#if ATTN_PV16
+  Acc16 o;
+  zero16(o);
+  Tr16Addr ta;
+  tr16_addr(ta, lane);
+#else
   f32x16 o[3];
   zero3(o);
+#endif
   float m = -INFINITY;
   const float c = p.scale_log2;
 
@@ -258,22 +363,38 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
       const float mn = fmaxf(m, mt);
       const float alpha = __builtin_amdgcn_exp2f((m - mn) * c);
       m = mn;
+#if ATTN_PV16
+      const float ao = __shfl_xor(alpha, 16);           // the accumulators of lane (R, c) belong to queries c and 16 + c, alpha to query l & 31
+      const float a0 = (lane & 16) ? ao : alpha, a1 = (lane & 16) ? alpha : ao;
+#pragma unroll
+      for (int t = 0; t < NT16; t++) { o.v[t][0] *= a0; o.v[t][1] *= a1; }   // includes the row-sum row (d = 72)
+#else
 #pragma unroll
       for (int dt = 0; dt < 3; dt++)
 #pragma unroll
         for (int g = 0; g < 16; g++) o[dt][g] *= alpha;   // includes the row-sum row (d = 72)
+#endif
     }
     const float mc = m * c;
 #pragma unroll
     for (int sub = 0; sub < 2; sub++)
 #pragma unroll
       for (int g = 0; g < 16; g++) s[sub][g] = __builtin_amdgcn_exp2f(s[sub][g] * c - mc);
+#if ATTN_PV16
+#pragma unroll
+    for (int sub = 0; sub < 2; sub++) {
+      bf16x8 px, py;
+      pack_xy(s[sub], px, py);
+      mma16(o, sV, ta, sub, px, py);
+    }
+#else
 #pragma unroll
     for (int u = 0; u < 4; u++) {
       const bf16x8 pb = pack8(s[u >> 1], 8 * (u & 1));
 #pragma unroll
       for (int dt = 0; dt < 3; dt++) o[dt] = mfma32(trfrag(sV, fa, dt, u), pb, o[dt]);
     }
+#endif
   };
 
   const int Tfull = kvlen / BKV, rem = kvlen - Tfull * BKV, T = Tfull + (rem ? 1 : 0);
@@ -299,6 +420,16 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
     const char* st = smem + (Tfull & 1) * 2 * TILE_B;
     tile(BoolC<true>{}, st, st + TILE_B, Tfull * BKV);
   }
+#if ATTN_PV16
+  // row 72 of O^T (tile 4, lane row 2, g = 0: lanes 32 + c) = sum over keys of the bf16 P actually multiplied into O
+  const float la = __shfl(o.v[4][0][0], 32 + (lane & 15)), lb = __shfl(o.v[4][1][0], 32 + (lane & 15));
+  const float l = (lane & 16) ? lb : la;               // of query l & 31
+  const float inv = l > 0.f ? 1.f / l : 0.f, invo = __shfl_xor(inv, 16);
+  const int q0w = bx * 128 + wave * 32;
+  store_rows16(p.O + (long)b * p.o_bs + (long)q0w * p.o_ts + (long)h * p.o_hs, p.o_ts, o, (lane & 16) ? invo : inv, (lane & 16) ? inv : invo,
+               q0w + (lane & 15) < p.Nq, q0w + 16 + (lane & 15) < p.Nq, lane);
+  if (qvalid && hi == 0 && p.LSE) p.LSE[((long)b * p.H + h) * p.Nq + q] = m * c + log2f(l);
+#else
   // row 72 of O^T (dt = 2, g = 4, lanes with hi = 0) = sum over keys of the bf16 P actually multiplied into O
   const float l = __shfl(o[2][4], lane & 31);
   if (qvalid) {
@@ -306,6 +437,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
     store_rows(p.O + (long)b * p.o_bs + (long)q * p.o_ts + (long)h * p.o_hs, o, inv, hi);
     if (hi == 0 && p.LSE) p.LSE[((long)b * p.H + h) * p.Nq + q] = m * c + log2f(l);
   }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------ delta = rowsum(dO * O)
@@ -405,10 +537,23 @@ __global__ __launch_bounds__(256, 2) void attn_fwd2_kernel(AttnParams p) {
     init_pads(smem + st * 2 * TILE_B, false, tid);            // K
     init_pads(smem + st * 2 * TILE_B + TILE_B, true, tid);    // V: column 72 = 1 -> O^T row 72 accumulates sum_kv P = l
   }
+#if ATTN_PV16
+  Acc16 o[QS];
+  Tr16Addr ta;
+  tr16_addr(ta, lane);
+#else
   f32x16 o[QS][3];
+#endif
   float m[QS];
 #pragma unroll
-  for (int s = 0; s < QS; s++) { zero3(o[s]); m[s] = -INFINITY; }
+  for (int s = 0; s < QS; s++) {
+#if ATTN_PV16
+    zero16(o[s]);
+#else
+    zero3(o[s]);
+#endif
+    m[s] = -INFINITY;
+  }
   const float c = p.scale_log2;
 
   auto tile = [&](auto tailc, const char* sK, const char* sV, int kv0) {
@@ -448,10 +593,17 @@ __global__ __launch_bounds__(256, 2) void attn_fwd2_kernel(AttnParams p) {
         const float mn = fmaxf(m[s], mt);
         const float alpha = __builtin_amdgcn_exp2f((m[s] - mn) * c);
         m[s] = mn;
+#if ATTN_PV16
+        const float ao = __shfl_xor(alpha, 16);
+        const float a0 = (lane & 16) ? ao : alpha, a1 = (lane & 16) ? alpha : ao;
+#pragma unroll
+        for (int t = 0; t < NT16; t++) { o[s].v[t][0] *= a0; o[s].v[t][1] *= a1; }
+#else
 #pragma unroll
         for (int dt = 0; dt < 3; dt++)
 #pragma unroll
           for (int g = 0; g < 16; g++) o[s][dt][g] *= alpha;
+#endif
       }
       const float mc = m[s] * c;
 #pragma unroll
@@ -459,6 +611,23 @@ __global__ __launch_bounds__(256, 2) void attn_fwd2_kernel(AttnParams p) {
 #pragma unroll
         for (int g = 0; g < 16; g++) sc[s][sub][g] = __builtin_amdgcn_exp2f(sc[s][sub][g] * c - mc);
     }
+#if ATTN_PV16
+#pragma unroll
+    for (int sub = 0; sub < 2; sub++) {
+      bf16x8 px[QS], py[QS];
+#pragma unroll
+      for (int s = 0; s < QS; s++) pack_xy(sc[s][sub], px[s], py[s]);
+#pragma unroll
+      for (int t = 0; t < NT16; t++) {
+        const bf16x8 vf = trfrag16(sV, ta, t, sub);          // one transposed fragment, four MFMAs
+#pragma unroll
+        for (int s = 0; s < QS; s++) {
+          o[s].v[t][0] = mfma16(vf, px[s], o[s].v[t][0]);
+          o[s].v[t][1] = mfma16(vf, py[s], o[s].v[t][1]);
+        }
+      }
+    }
+#else
 #pragma unroll
     for (int u = 0; u < 4; u++) {
       bf16x8 pb[QS];
@@ -471,6 +640,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd2_kernel(AttnParams p) {
         for (int s = 0; s < QS; s++) o[s][dt] = mfma32(vf, pb[s], o[s][dt]);
       }
     }
+#endif
   };
 
   const int Tfull = kvlen / BKV, rem = kvlen - Tfull * BKV, T = Tfull + (rem ? 1 : 0);
@@ -498,12 +668,22 @@ __global__ __launch_bounds__(256, 2) void attn_fwd2_kernel(AttnParams p) {
   }
 #pragma unroll
   for (int s = 0; s < QS; s++) {
+#if ATTN_PV16
+    const float la = __shfl(o[s].v[4][0][0], 32 + (lane & 15)), lb = __shfl(o[s].v[4][1][0], 32 + (lane & 15));
+    const float l = (lane & 16) ? lb : la;             // row 72 of O^T = sum over keys of the bf16 P actually multiplied into O, of query l & 31
+    const float inv = l > 0.f ? 1.f / l : 0.f, invo = __shfl_xor(inv, 16);
+    const int q0w = bx * 256 + wave * 64 + s * 32;
+    store_rows16(p.O + (long)b * p.o_bs + (long)q0w * p.o_ts + (long)h * p.o_hs, p.o_ts, o[s], (lane & 16) ? invo : inv, (lane & 16) ? inv : invo,
+                 q0w + (lane & 15) < p.Nq, q0w + 16 + (lane & 15) < p.Nq, lane);
+    if (qvalid[s] && hi == 0 && p.LSE) p.LSE[((long)b * p.H + h) * p.Nq + q[s]] = m[s] * c + log2f(l);
+#else
     const float l = __shfl(o[s][2][4], lane & 31);     // row 72 of O^T = sum over keys of the bf16 P actually multiplied into O
     if (qvalid[s]) {
       const float inv = l > 0.f ? 1.f / l : 0.f;
       store_rows(p.O + (long)b * p.o_bs + (long)q[s] * p.o_ts + (long)h * p.o_hs, o[s], inv, hi);
       if (hi == 0 && p.LSE) p.LSE[((long)b * p.H + h) * p.Nq + q[s]] = m[s] * c + log2f(l);
     }
+#endif
   }
 }
 
@@ -539,8 +719,15 @@ __global__ __launch_bounds__(256, ATTN_BWD_WAVES) void attn_bwd_dq_kernel(AttnPa
   frag_addr(fa, lane);
 
   for (int st = 0; st < 4; st++) init_pads(smem + st * TILE_B, false, tid);
+#if ATTN_PV16
+  Acc16 dq;
+  zero16(dq);
+  Tr16Addr ta;
+  tr16_addr(ta, lane);
+#else
   f32x16 dq[3];
   zero3(dq);
+#endif
   const float c = p.scale_log2;
   auto tile = [&](auto tailc, const char* sK, const char* sV, int kv0) {
     constexpr bool TAIL = decltype(tailc)::value;
@@ -563,12 +750,21 @@ __global__ __launch_bounds__(256, ATTN_BWD_WAVES) void attn_bwd_dq_kernel(AttnPa
         if (TAIL && kv0 + sub * 32 + (g & 3) + 8 * (g >> 2) + 4 * hi >= kvlen) pr = 0.f;
         s[sub][g] = pr * (dp[sub][g] - delta);  // dS^T (without the softmax scale, applied at the end)
       }
+#if ATTN_PV16
+#pragma unroll
+    for (int sub = 0; sub < 2; sub++) {
+      bf16x8 dx, dy;
+      pack_xy(s[sub], dx, dy);
+      mma16(dq, sK, ta, sub, dx, dy);
+    }
+#else
 #pragma unroll
     for (int u = 0; u < 4; u++) {
       const bf16x8 db = pack8(s[u >> 1], 8 * (u & 1));
 #pragma unroll
       for (int dt = 0; dt < 3; dt++) dq[dt] = mfma32(trfrag(sK, fa, dt, u), db, dq[dt]);
     }
+#endif
   };
   const int Tfull = kvlen / BKV, rem = kvlen - Tfull * BKV, T = Tfull + (rem ? 1 : 0);
   auto issue = [&](int t) {                // DMA of tile t into stage t&1
@@ -593,8 +789,15 @@ __global__ __launch_bounds__(256, ATTN_BWD_WAVES) void attn_bwd_dq_kernel(AttnPa
     const char* st = smem + (Tfull & 1) * 2 * TILE_B;
     tile(BoolC<true>{}, st, st + TILE_B, Tfull * BKV);
   }
+#if ATTN_PV16
+  const int q0w = bx * 128 + wave * 32;
+  const bool ok0 = q0w + (lane & 15) < p.Nq, ok1 = q0w + 16 + (lane & 15) < p.Nq;
+  store_rows16(p.dQ + (long)b * p.dq_bs + (long)q0w * p.dq_ts + (long)h * p.dq_hs, p.dq_ts, dq, p.scale, p.scale, ok0, ok1, lane);
+  if (p.dq_colsum) colsum_rows16(p.dq_colsum + (b % PXA_COLSUM_SLOTS) * p.colsum_stride + h * DH, dq, p.scale, ok0, ok1, lane);
+#else
   if (qvalid) store_rows(p.dQ + (long)b * p.dq_bs + (long)q * p.dq_ts + (long)h * p.dq_hs, dq, p.scale, hi);
   if (p.dq_colsum) colsum_rows(p.dq_colsum + (b % PXA_COLSUM_SLOTS) * p.colsum_stride + h * DH, dq, p.scale, qvalid, hi, lane);
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------ backward: dK, dV
@@ -627,9 +830,13 @@ __global__ __launch_bounds__(256, ATTN_BWD_WAVES) void attn_bwd_dkv_kernel(AttnP
   frag_addr(fa, lane);
 
   for (int st = 0; st < 4; st++) init_pads(smem + st * TILE_B, false, tid);
+  constexpr bool DV16 = ATTN_DKV16 != 0, DK16 = ATTN_DKV16 == 1 || ATTN_DKV16 == 2;
+  Acc16 dk16, dv16;                    // the set a build does not use is never touched and costs no registers
   f32x16 dk[3], dv[3];
-  zero3(dk);
-  zero3(dv);
+  if (DV16) zero16(dv16); else zero3(dv);
+  if (DK16) zero16(dk16); else zero3(dk);
+  Tr16Addr ta;
+  tr16_addr(ta, lane);
   const float c = p.scale_log2;
   const int T = (p.Nq + BKV - 1) / BKV;
   float rl = INFINITY, rdl = 0.f;
@@ -692,6 +899,29 @@ __global__ __launch_bounds__(256, ATTN_BWD_WAVES) void attn_bwd_dkv_kernel(AttnP
           dp[qd * 4 + e] = pr * (dp[qd * 4 + e] - Dv[e]);
         }
       }
+      if (DV16 && DK16) {
+        bf16x8 px, py, dx, dy;
+        pack_xy(s, px, py);
+        pack_xy(dp, dx, dy);
+        if (ATTN_DKV16 == 2) {
+#pragma unroll
+          for (int t = 0; t < NT16; t++) {
+            const bf16x8 ad = trfrag16(sD, ta, t, sub), aq = trfrag16(sQ, ta, t, sub);
+            dv16.v[t][0] = mfma16(ad, px, dv16.v[t][0]);
+            dk16.v[t][0] = mfma16(aq, dx, dk16.v[t][0]);
+            dv16.v[t][1] = mfma16(ad, py, dv16.v[t][1]);
+            dk16.v[t][1] = mfma16(aq, dy, dk16.v[t][1]);
+          }
+        } else {
+          mma16(dv16, sD, ta, sub, px, py);    // dV^T[d][kv] += dO^T[d][q] P[q][kv]
+          mma16(dk16, sQ, ta, sub, dx, dy);    // dK^T[d][kv] += Q^T[d][q] dS[q][kv]
+        }
+      } else {
+      if (DV16) {
+        bf16x8 px, py;
+        pack_xy(s, px, py);
+        mma16(dv16, sD, ta, sub, px, py);
+      }
 #pragma unroll
       for (int uu = 0; uu < 2; uu++) {
         const bf16x8 pb = pack8(s, 8 * uu), db = pack8(dp, 8 * uu);
@@ -704,19 +934,32 @@ __global__ __launch_bounds__(256, ATTN_BWD_WAVES) void attn_bwd_dkv_kernel(AttnP
             dv[dt][u] += (float)dot[0] * (float)pb[dt];
             dk[dt][u] += (float)qt[0] * (float)db[dt];
           } else {
-            dv[dt] = mfma32(dot, pb, dv[dt]);
+            if (!DV16) dv[dt] = mfma32(dot, pb, dv[dt]);
             dk[dt] = mfma32(qt, db, dk[dt]);
           }
         }
       }
+      }
     }
   }
-  if (kvvalid) {
-    store_rows(p.dK + dkbase + (long)kv * p.dk_ts + (long)h * p.dk_hs, dk, p.scale, hi);
-    store_rows(p.dV + dvbase + (long)kv * p.dv_ts + (long)h * p.dv_hs, dv, 1.f, hi);
+  const int kv0w = bx * 128 + wave * 32;
+  const bool ok0 = kv0w + (lane & 15) < kvlen, ok1 = kv0w + 16 + (lane & 15) < kvlen;
+  float* const cs_k = p.dk_colsum ? p.dk_colsum + (b % PXA_COLSUM_SLOTS) * p.colsum_stride + h * DH : nullptr;
+  float* const cs_v = p.dv_colsum ? p.dv_colsum + (b % PXA_COLSUM_SLOTS) * p.colsum_stride + h * DH : nullptr;
+  if (DK16) {
+    store_rows16(p.dK + dkbase + (long)kv0w * p.dk_ts + (long)h * p.dk_hs, p.dk_ts, dk16, p.scale, p.scale, ok0, ok1, lane);
+    if (cs_k) colsum_rows16(cs_k, dk16, p.scale, ok0, ok1, lane);
+  } else {
+    if (kvvalid) store_rows(p.dK + dkbase + (long)kv * p.dk_ts + (long)h * p.dk_hs, dk, p.scale, hi);
+    if (cs_k) colsum_rows(cs_k, dk, p.scale, kvvalid, hi, lane);
   }
-  if (p.dk_colsum) colsum_rows(p.dk_colsum + (b % PXA_COLSUM_SLOTS) * p.colsum_stride + h * DH, dk, p.scale, kvvalid, hi, lane);
-  if (p.dv_colsum) colsum_rows(p.dv_colsum + (b % PXA_COLSUM_SLOTS) * p.colsum_stride + h * DH, dv, 1.f, kvvalid, hi, lane);
+  if (DV16) {
+    store_rows16(p.dV + dvbase + (long)kv0w * p.dv_ts + (long)h * p.dv_hs, p.dv_ts, dv16, 1.f, 1.f, ok0, ok1, lane);
+    if (cs_v) colsum_rows16(cs_v, dv16, 1.f, ok0, ok1, lane);
+  } else {
+    if (kvvalid) store_rows(p.dV + dvbase + (long)kv * p.dv_ts + (long)h * p.dv_hs, dv, 1.f, hi);
+    if (cs_v) colsum_rows(cs_v, dv, 1.f, kvvalid, hi, lane);
+  }
 }
 
 int fill(AttnParams& p, const pxa_attn_args* a) {
