@@ -602,6 +602,9 @@ __device__ __forceinline__ void mfma_abl16(f32x4 (&q)[4], bf16x8 b0, bf16x8 a0, 
 #ifndef GEMM_STORE_OVERLAP
 #define GEMM_STORE_OVERLAP 1   // next item's main loop starts over the draining epilogue stores (counted vmcnt); 0 = wait for them (A/B)
 #endif
+#ifndef GEMM_NT16
+#define GEMM_NT16 1         // NT instances with the plain / GELU epilogues: main loop on v_mfma_f32_16x16x32 (0 = 32x32x16 everywhere; A/B builds)
+#endif
 #ifndef GEMM_PHASE16
 #define GEMM_PHASE16 -1     // matrix phases per k-unit: -1 = per layout (below), 0 = two 8-MFMA phases everywhere, 1 = one 16-MFMA phase everywhere
 #endif
@@ -634,11 +637,18 @@ __device__ __forceinline__ void mfma_abl16(f32x4 (&q)[4], bf16x8 b0, bf16x8 a0, 
 // column that wastes half its MFMAs: the remainder columns of TWO consecutive m-tiles form one "paired" item - 512 rows x 128
 // columns, the same 65,536 outputs, the same 128 x 64 per wave (waves wn = 0,1 take the first m-tile, wn = 2,3 the second) - whose
 // k-unit is 32 A pieces + 8 B pieces (40 KiB, hence the 40 KiB ring slots).
-template <bool KC>
+// Bank swizzle of the k-contiguous images (64-byte rows, 4 chunks): chunk' = chunk ^ swz(row), applied to the DMA's per-lane SOURCE address
+// and mirrored by the fragment reads.  ds_read_b128 is served in the 16-lane groups {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31} (+32):
+//   32-row fragments (lane = row & 31, chunk 2 ks + hi): swz = (row >> 2) & 3;
+//   16-row fragments (lane = row & 15, chunk lane >> 4): a group holds rows r, r + 12 with one chunk and r + 4, r + 8 with the next, so the
+//   four rows of a residue class mod 4 need the XOR pattern (0, 0, 3, 3): swz = 3 ((row >> 3) & 1).  Both conflict-free (checked per group).
+template <bool M16>
+__device__ __forceinline__ int kc_swz(int row) { return M16 ? ((row >> 3) & 1) * 3 : (row >> 2) & 3; }
+template <bool KC, bool M16 = false>
 __device__ __forceinline__ const bf16_t* piece_ptr_rt(const bf16_t* __restrict__ X, int ld, int r0a, int r0b, int R, int q, int rows_log2) {
   // q: 16-byte chunk index in the LDS image of one operand of a k-unit; image rows/columns [0, 256) come from r0a, [256, 512) from r0b
   if constexpr (KC) {
-    const int row = q >> 2, c = (q & 3) ^ ((row >> 2) & 3);
+    const int row = q >> 2, c = (q & 3) ^ kc_swz<M16>(row);
     const int gr = (row < 256 ? r0a : r0b - 256) + row;
     return X + (size_t)min(gr, R - 1) * ld + c * 8;
   } else {
@@ -661,6 +671,13 @@ __device__ __forceinline__ bf16x8 frag_rt(const char* lds, int rbase, int ks, in
     const char* p1 = lds + ((kr + 4) << (rows_log2 + 1)) + ((blk ^ ((kr + 4) & 3)) << 6) + inblk;
     return concat_tr(lds_tr_read(p0), lds_tr_read(p1));
   }
+}
+
+// Operand of v_mfma_f32_16x16x32 from a k-contiguous image: rows rbase .. rbase + 15, the k-unit's whole depth of 32 (lane l: row l & 15,
+// k = 8 (l >> 4) .. + 7).
+__device__ __forceinline__ bf16x8 frag16_kc(const char* lds, int rbase, int lane) {
+  const int row = rbase + (lane & 15);
+  return *reinterpret_cast<const bf16x8*>(lds + row * 64 + (((lane >> 4) ^ kc_swz<true>(row)) << 4));
 }
 
 // EPI (bf16 epilogue flavour, compiled separately so that none carries the others' registers - the epilogue runs with all
@@ -702,6 +719,13 @@ __global__ __launch_bounds__(512) void gemm_pers_kernel(GemmParams p) {
   // LDS transpose (NN: B, TN: both): those read phases are twice as long in instructions and did not fit under the partner's 8 MFMAs.
   // Measured at M = 65,536 (profiles/r02_gemm_phase16.txt): TN +18-20 %, NN +3-6 %, NT +-0 (keeps the finer interleave).
   constexpr bool PH16 = GEMM_PHASE16 < 0 ? (LAYOUT != 0) : (GEMM_PHASE16 != 0);
+  // MFMA shape.  Under the chip's power limit an MFMA stream of 16x16x32 instructions on N(0,1) operands runs 12 % faster than the same FLOPs as
+  // 32x32x16 (half the accumulator words through the register file per FLOP; probe/mfma_power.hip), and this kernel with its main-loop FLOPs
+  // re-issued in that shape (-DGEMM_ABL=4) measured NT +8-14 %, NN +2-8 %, TN +2-5 % (profiles/r02c_gemm_mfma16_ablation.txt).  The NT instances
+  // whose epilogue is the plain or the GELU one - both operands k-contiguous: fragments stay single ds_read_b128, 12 per k-unit as before - run
+  // it for real: wave tile 128 x 64 = 8 x 4 tiles of 16 x 16, the n side still the MFMA's A operand, so a lane owns 4 consecutive columns of one
+  // output row (lane (R, c): row 16 im + c, columns 16 jn + 4 R + g).
+  constexpr bool M16 = GEMM_NT16 && LAYOUT == 0 && !SEG && (EPI == 0 || EPI == 1) && !PH16 && !(GEMM_ABL & 4);
   constexpr int UNIT = 40960;                          // ring slot: A image at 0 (16 KiB; 32 KiB paired), B image behind it (16 KiB; 8 KiB paired)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), wm = wave >> 2, wn = wave & 3, hi = lane >> 5;
@@ -838,8 +862,8 @@ __global__ __launch_bounds__(512) void gemm_pers_kernel(GemmParams p) {
       const bool is_a = vq ? (i < 4) : (i < 2);                      // full: A A B B -, paired: A A A A B, half: A A B - -
       const int pid = is_a ? id : (vq ? id - 32 : id - 16);
       if (vq || (hq ? i < 3 : i < 4)) {
-        if (is_a) pp[i] = piece_ptr_rt<A_KC>(p.A, p.lda, m0a, m0b, p.M, pid * 64 + lane, rla) + (A_KC ? k0 : k0 * p.lda);
-        else pp[i] = piece_ptr_rt<B_KC>(p.B, p.ldb, n0, n0, p.N, pid * 64 + lane, rlb) + (B_KC ? k0 : k0 * p.ldb);
+        if (is_a) pp[i] = piece_ptr_rt<A_KC, M16>(p.A, p.lda, m0a, m0b, p.M, pid * 64 + lane, rla) + (A_KC ? k0 : k0 * p.lda);
+        else pp[i] = piece_ptr_rt<B_KC, M16>(p.B, p.ldb, n0, n0, p.N, pid * 64 + lane, rlb) + (B_KC ? k0 : k0 * p.ldb);
       }
       st[i] = is_a ? stepA : stepB;
       dof[i] = (is_a ? 0 : (vq ? 32768 : 16384)) + pid * 1024;
@@ -854,13 +878,18 @@ __global__ __launch_bounds__(512) void gemm_pers_kernel(GemmParams p) {
   int prev_stores = 0;                                 // epilogue store instructions of the previous item still allowed in flight (0: none)
 
   while (true) {
-    f32x16 acc[TM][TN];
+    f32x16 acc[TM][TN];                                // 32 x 32 tiles; M16 instances use acc4 instead (the unused set costs nothing)
+    f32x4 acc4[2 * TM][2 * TN];                        // 16 x 16 tiles: [m tile][n tile] of the wave's 128 x 64
 #pragma unroll
     for (int i = 0; i < TM; i++)
 #pragma unroll
       for (int j = 0; j < TN; j++)
 #pragma unroll
         for (int g = 0; g < 16; g++) acc[i][j][g] = 0.f;
+#pragma unroll
+    for (int i = 0; i < 2 * TM; i++)
+#pragma unroll
+      for (int j = 0; j < 2 * TN; j++) acc4[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 #if GEMM_ABL & 4
     f32x4 a4[TM][TN][4];
 #pragma unroll
@@ -952,6 +981,28 @@ __global__ __launch_bounds__(512) void gemm_pers_kernel(GemmParams p) {
         else if (REM == 2) { if (vtc) wait_vmcnt<5>(); else if (TH == 1) wait_vmcnt<3>(); else wait_vmcnt<4>(); }
         else if (REM == 1) wait_vmcnt<0>();
       };
+      if constexpr (M16) {
+        // the same two phases on 16 x 16 tiles: 4 n fragments (kept for phase b) + 2 TH m fragments per phase, each the unit's whole depth
+        bf16x8 bq[2 * TN];
+#pragma unroll
+        for (int j = 0; j < 2 * TN; j++) bq[j] = frag16_kc(sB, b_rb + j * 16, lane);
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+          bf16x8 aq[2 * TH];
+#pragma unroll
+          for (int i = 0; i < 2 * TH; i++) aq[i] = frag16_kc(sA, a_rb + (h * 2 * TH + i) * 16, lane);
+          if (h == 0) rest_a(); else rest_b();
+          PXA_SB(); __builtin_amdgcn_s_barrier(); PXA_SB();
+          __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+          for (int i = 0; i < 2 * TH; i++)
+#pragma unroll
+            for (int j = 0; j < 2 * TN; j++) acc4[h * 2 * TH + i][j] = mfma16(bq[j], aq[i], acc4[h * 2 * TH + i][j]);
+          __builtin_amdgcn_s_setprio(0);
+          PXA_SB(); __builtin_amdgcn_s_barrier(); PXA_SB();
+        }
+        return;
+      }
       // phases split the wave's rows: a = upper half x all columns (B fragments stay in registers for b = lower half)
       bf16x8 af[2][TH], bf[2][TN];
 #pragma unroll
@@ -1068,6 +1119,51 @@ __global__ __launch_bounds__(512) void gemm_pers_kernel(GemmParams p) {
     const bool want_cs = EPI == 2 || (EPI == 3 && p.colsum != nullptr);
     // one column group of JW 32-wide tiles (JW = 2: 128-byte staging rows, 8 rows per store; JW = 1: 64-byte rows, 16 per store)
     auto emit = [&](int j0, auto jw_c) {
+      if constexpr (M16) {
+        // 16 x 16 accumulator tiles (plain / GELU flavours only): lane (R, c) holds row 16 mt + c, columns 16 jn + 4 R + g.  The same staging
+        // slice and the same read-back as below: a 32-row slice is two m tiles, a lane's 4 values are 8 bytes of chunk 2 jn + (R >> 1).
+        const int R4 = lane >> 4, c16 = lane & 15;
+#pragma unroll
+        for (int jn = 0; jn < 2 * TN; jn++) {
+          const int n = nw + jn * 16 + 4 * R4;
+          const float4 b4 = (p.bias && n < p.N) ? *reinterpret_cast<const float4*>(p.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+          for (int mt = 0; mt < 2 * TM; mt++) { acc4[mt][jn][0] += b4.x; acc4[mt][jn][1] += b4.y; acc4[mt][jn][2] += b4.z; acc4[mt][jn][3] += b4.w; }
+        }
+#pragma unroll
+        for (int i = 0; i < TM; i++) {
+          if (i >= tm_eff) break;                      // half items: two 32-row slices per wave
+#pragma unroll
+          for (int pass = 0; pass < 2; pass++) {       // pass 0: GELU' as the second output (GELU flavour only); pass 1: final values
+            if (pass == 0 && !dual) continue;
+#pragma unroll
+            for (int mh = 0; mh < 2; mh++)
+#pragma unroll
+              for (int jn = 0; jn < 2 * TN; jn++) {
+                f32x4& a = acc4[2 * i + mh][jn];
+                float v[4] = {a[0], a[1], a[2], a[3]};
+                if (pass == 0 && act == 3) {
+                  float g[4];
+#pragma unroll
+                  for (int e = 0; e < 4; e++) { a[e] = gelu_tanh_both(v[e], g[e]); v[e] = g[e]; }
+                }
+                const int row = 16 * mh + c16, ch = 2 * jn + (R4 >> 1);
+                *reinterpret_cast<uint2*>(stg + row * 128 + ((ch ^ (row & 7)) << 4) + (R4 & 1) * 8) = pack_bf16x4(v[0], v[1], v[2], v[3]);
+              }
+            __builtin_amdgcn_s_waitcnt(0xc07f);        // lgkmcnt(0): the slice is private to this wave
+            bf16_t* dst = pass == 0 ? p.out2 : p.out;
+#pragma unroll
+            for (int t4 = 0; t4 < 4; t4++) {           // 8 rows x 128 B per store instruction
+              const int row = t4 * 8 + (lane >> 3), ch = lane & 7;
+              const uint4 v4 = *reinterpret_cast<const uint4*>(stg + row * 128 + ((ch ^ (row & 7)) << 4));
+              const int mm = mw + i * 32 + row, nn = nw + ch * 8;
+              if (mm < p.M && nn < p.N) *reinterpret_cast<uint4*>(dst + (size_t)mm * p.ldo + nn) = v4;
+            }
+            __builtin_amdgcn_s_waitcnt(0xc07f);        // reads returned before the slice is overwritten
+          }
+        }
+        return;
+      }
       constexpr int JW = decltype(jw_c)::value, RB = JW * 64;
       constexpr int LPR = JW * 4, RPI = 64 / LPR, NST = 4 / (3 - JW);   // read-back: JW = 2: 4 x (8 rows x 128 B); JW = 1: 2 x (16 rows x 64 B)
       // bias goes into the accumulators first, unconditionally (zero when absent), so nothing extra stays live across the row loop

@@ -12,7 +12,7 @@ for name, m in meta.items():
     if pat and not pat.search(name):
         continue
     i = s.find("\n" + name + ":")
-    j = s.find("s_endpgm", i)
+    j = s.find(".Lfunc_end", i)
     c = Counter(re.findall(r"^\s+([a-z_0-9]+)", s[i:j], re.M))
     keys = [k for k in c if "mfma" in k or k.startswith(("scratch_", "ds_read", "ds_write", "global_load_lds", "v_permlane", "v_accvgpr", "v_exp", "s_barrier"))]
     print(name[:110])
