@@ -602,8 +602,10 @@ __device__ __forceinline__ void mfma_abl16(f32x4 (&q)[4], bf16x8 b0, bf16x8 a0, 
 #ifndef GEMM_STORE_OVERLAP
 #define GEMM_STORE_OVERLAP 1   // next item's main loop starts over the draining epilogue stores (counted vmcnt); 0 = wait for them (A/B)
 #endif
-#ifndef GEMM_NT16
-#define GEMM_NT16 1         // NT instances with the plain / GELU epilogues: main loop on v_mfma_f32_16x16x32 (0 = 32x32x16 everywhere; A/B builds)
+#ifndef GEMM_M16
+#define GEMM_M16 3          // bit per layout (1 NT, 2 NN, 4 TN): main loop on v_mfma_f32_16x16x32; a cleared bit keeps that layout on 32x32x16.  TN measured
+                            // 2-4 % SLOWER in the 16-row shape (its read phase - 24 transpose reads + ~39 address VALU per k-unit - no longer fits into the issue
+                            // slots 32 back-to-back 16-cycle MFMAs of the partner wave leave: 3 per MFMA instead of 7), so it stays on 32x32x16
 #endif
 #ifndef GEMM_PHASE16
 #define GEMM_PHASE16 -1     // matrix phases per k-unit: -1 = per layout (below), 0 = two 8-MFMA phases everywhere, 1 = one 16-MFMA phase everywhere
@@ -652,7 +654,11 @@ __device__ __forceinline__ const bf16_t* piece_ptr_rt(const bf16_t* __restrict__
     const int gr = (row < 256 ? r0a : r0b - 256) + row;
     return X + (size_t)min(gr, R - 1) * ld + c * 8;
   } else {
-    const int sh = rows_log2 - 3, kr = q >> sh, cl = q & ((1 << sh) - 1), c = ((((cl >> 2) ^ (kr & 3)) << 2) | (cl & 3));
+    // k-strided image [32 k][rows]: 64-byte block' = block ^ (k & 3) puts the 4 k-rows of a transpose read on the 4 bank quarters.  16-row
+    // fragments read the same 32 bytes of rows k and k + 8 from the two halves of a 32-lane LDS group: their images also swap the 32-byte
+    // halves of a block where k has bit 3 set.
+    const int sh = rows_log2 - 3, kr = q >> sh, cl = q & ((1 << sh) - 1);
+    const int c = ((((cl >> 2) ^ (kr & 3)) << 2) | ((cl & 3) ^ (M16 ? ((kr >> 3) & 1) << 1 : 0)));
     const int col = c * 8;
     int gc = (col < 256 ? r0a : r0b - 256) + col;
     gc = gc < R ? gc : 0;
@@ -678,6 +684,21 @@ __device__ __forceinline__ bf16x8 frag_rt(const char* lds, int rbase, int ks, in
 __device__ __forceinline__ bf16x8 frag16_kc(const char* lds, int rbase, int lane) {
   const int row = rbase + (lane & 15);
   return *reinterpret_cast<const bf16x8*>(lds + row * 64 + (((lane >> 4) ^ kc_swz<true>(row)) << 4));
+}
+// The same operand from a k-strided image [32 k][2^rows_log2]: rows (of the operand) rbase .. rbase + 15 are 16 columns of the image; lane group
+// G = l >> 4 takes k = 8 G .. 8 G + 7 - the order the k-contiguous partner's chunk G has - as two transpose reads of [4 k][16] blocks.
+template <bool KC>
+__device__ __forceinline__ bf16x8 frag16(const char* lds, int rbase, int lane, int rows_log2) {
+  if constexpr (KC) {
+    return frag16_kc(lds, rbase, lane);
+  } else {
+    const int gg = lane >> 4, tt = lane & 15;
+    const int kr = 8 * gg + (tt >> 2), col = rbase + (tt & 3) * 4;
+    const int blk = col >> 5, inblk = ((col & 31) * 2) ^ ((gg & 1) << 5);       // (kr >> 3) & 1 == gg & 1, also for kr + 4
+    const char* p0 = lds + (kr << (rows_log2 + 1)) + ((blk ^ (kr & 3)) << 6) + inblk;
+    const char* p1 = lds + ((kr + 4) << (rows_log2 + 1)) + ((blk ^ ((kr + 4) & 3)) << 6) + inblk;
+    return concat_tr(lds_tr_read(p0), lds_tr_read(p1));
+  }
 }
 
 // EPI (bf16 epilogue flavour, compiled separately so that none carries the others' registers - the epilogue runs with all
@@ -721,11 +742,11 @@ __global__ __launch_bounds__(512) void gemm_pers_kernel(GemmParams p) {
   constexpr bool PH16 = GEMM_PHASE16 < 0 ? (LAYOUT != 0) : (GEMM_PHASE16 != 0);
   // MFMA shape.  Under the chip's power limit an MFMA stream of 16x16x32 instructions on N(0,1) operands runs 12 % faster than the same FLOPs as
   // 32x32x16 (half the accumulator words through the register file per FLOP; probe/mfma_power.hip), and this kernel with its main-loop FLOPs
-  // re-issued in that shape (-DGEMM_ABL=4) measured NT +8-14 %, NN +2-8 %, TN +2-5 % (profiles/r02c_gemm_mfma16_ablation.txt).  The NT instances
-  // whose epilogue is the plain or the GELU one - both operands k-contiguous: fragments stay single ds_read_b128, 12 per k-unit as before - run
-  // it for real: wave tile 128 x 64 = 8 x 4 tiles of 16 x 16, the n side still the MFMA's A operand, so a lane owns 4 consecutive columns of one
-  // output row (lane (R, c): row 16 im + c, columns 16 jn + 4 R + g).
-  constexpr bool M16 = GEMM_NT16 && LAYOUT == 0 && !SEG && (EPI == 0 || EPI == 1) && !PH16 && !(GEMM_ABL & 4);
+  // re-issued in that shape (-DGEMM_ABL=4) measured NT +8-14 %, NN +2-8 %, TN +2-5 % (profiles/r02c_gemm_mfma16_ablation.txt); run for real:
+  // NT +8-11 %, NN +2-7 %, the VAE's implicit convolutions -10 % decode time, TN -2-4 % (profiles/r02d_gemm_nt16_ab.txt, r02e_gemm_m16_ab.txt).  Wave tile 128 x 64 = 8 x 4 tiles of 16 x 16, the n side still the MFMA's A operand, so a lane
+  // owns 4 consecutive columns of one output row (lane (R, c): row 16 im + c, columns 16 jn + 4 R + g).  Fragment counts per k-unit are those of
+  // the 32-row form: 12 ds_read_b128 (k-contiguous operands) or transpose-read pairs (k-strided), each now the unit's whole depth of 32.
+  constexpr bool M16 = ((GEMM_M16 >> LAYOUT) & 1) && !(GEMM_ABL & 4);
   constexpr int UNIT = 40960;                          // ring slot: A image at 0 (16 KiB; 32 KiB paired), B image behind it (16 KiB; 8 KiB paired)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), wm = wave >> 2, wn = wave & 3, hi = lane >> 5;
@@ -937,6 +958,27 @@ __global__ __launch_bounds__(512) void gemm_pers_kernel(GemmParams p) {
       constexpr int REM = decltype(rem_c)::value, TH = decltype(th_c)::value;   // 2 * TH row tiles (4; 2 for half items)
       const char* sA = smem + (t & 3) * UNIT;
       const char* sB = sA + boff;
+      if constexpr (M16) {
+        bf16x8 bq[2 * TN], aq[4 * TH];
+#pragma unroll
+        for (int j = 0; j < 2 * TN; j++) bq[j] = frag16<B_KC>(sB, b_rb + j * 16, lane, rlb);
+#pragma unroll
+        for (int i = 0; i < 4 * TH; i++) aq[i] = frag16<A_KC>(sA, a_rb + i * 16, lane, rla);
+        if (REM >= 3) { issue_lo(); issue_hi(); }
+        if (REM >= 3) { if (vtc) wait_vmcnt<10>(); else if (TH == 1) wait_vmcnt<6>(); else wait_vmcnt<8>(); }
+        else if (REM == 2) { if (vtc) wait_vmcnt<5>(); else if (TH == 1) wait_vmcnt<3>(); else wait_vmcnt<4>(); }
+        else if (REM == 1) wait_vmcnt<0>();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        PXA_SB(); __builtin_amdgcn_s_barrier(); PXA_SB();
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int i = 0; i < 4 * TH; i++)
+#pragma unroll
+          for (int j = 0; j < 2 * TN; j++) acc4[i][j] = mfma16(bq[j], aq[i], acc4[i][j]);
+        __builtin_amdgcn_s_setprio(0);
+        PXA_SB(); __builtin_amdgcn_s_barrier(); PXA_SB();
+        return;
+      }
       bf16x8 af[2][2 * TH], bf[2][TN];
 #pragma unroll
       for (int ks = 0; ks < 2; ks++)
@@ -985,12 +1027,12 @@ __global__ __launch_bounds__(512) void gemm_pers_kernel(GemmParams p) {
         // the same two phases on 16 x 16 tiles: 4 n fragments (kept for phase b) + 2 TH m fragments per phase, each the unit's whole depth
         bf16x8 bq[2 * TN];
 #pragma unroll
-        for (int j = 0; j < 2 * TN; j++) bq[j] = frag16_kc(sB, b_rb + j * 16, lane);
+        for (int j = 0; j < 2 * TN; j++) bq[j] = frag16<B_KC>(sB, b_rb + j * 16, lane, rlb);
 #pragma unroll
         for (int h = 0; h < 2; h++) {
           bf16x8 aq[2 * TH];
 #pragma unroll
-          for (int i = 0; i < 2 * TH; i++) aq[i] = frag16_kc(sA, a_rb + (h * 2 * TH + i) * 16, lane);
+          for (int i = 0; i < 2 * TH; i++) aq[i] = frag16<A_KC>(sA, a_rb + (h * 2 * TH + i) * 16, lane, rla);
           if (h == 0) rest_a(); else rest_b();
           PXA_SB(); __builtin_amdgcn_s_barrier(); PXA_SB();
           __builtin_amdgcn_s_setprio(1);
@@ -1087,10 +1129,21 @@ __global__ __launch_bounds__(512) void gemm_pers_kernel(GemmParams p) {
       for (int i = 0; i < TM; i++)
 #pragma unroll
         for (int j = 0; j < TN; j++) {
+          if constexpr (M16) {                           // the 32 x 32 block as 2 x 2 tiles: lane (R, c) -> row 16 mh + c, floats 16 nh + 4 R ..
+#pragma unroll
+            for (int mh = 0; mh < 2; mh++)
+#pragma unroll
+              for (int nh = 0; nh < 2; nh++) {
+                const f32x4 a = acc4[2 * i + mh][2 * j + nh];
+                const int row = 16 * mh + (lane & 15);
+                *reinterpret_cast<float4*>(stg + row * 128 + (((4 * nh + (lane >> 4)) ^ (row & 7)) << 4)) = make_float4(a[0], a[1], a[2], a[3]);
+              }
+          } else {
 #pragma unroll
           for (int q = 0; q < 4; q++)
             *reinterpret_cast<float4*>(stg + srow * 128 + (((q * 2 + hi) ^ (srow & 7)) << 4)) =
                 make_float4(acc[i][j][q * 4], acc[i][j][q * 4 + 1], acc[i][j][q * 4 + 2], acc[i][j][q * 4 + 3]);
+          }
           __builtin_amdgcn_s_waitcnt(0xc07f);
 #pragma unroll
           for (int t4 = 0; t4 < 4; t4++) {
@@ -1119,10 +1172,14 @@ __global__ __launch_bounds__(512) void gemm_pers_kernel(GemmParams p) {
     const bool want_cs = EPI == 2 || (EPI == 3 && p.colsum != nullptr);
     // one column group of JW 32-wide tiles (JW = 2: 128-byte staging rows, 8 rows per store; JW = 1: 64-byte rows, 16 per store)
     auto emit = [&](int j0, auto jw_c) {
+      constexpr int JW = decltype(jw_c)::value, RB = JW * 64;
+      constexpr int LPR = JW * 4, RPI = 64 / LPR, NST = 4 / (3 - JW);   // read-back: JW = 2: 4 x (8 rows x 128 B); JW = 1: 2 x (16 rows x 64 B)
+      static_assert(!M16 || JW == 2, "16 x 16 accumulator tiles: the wave's 64 columns are one column group");
+      // M16: lane (R4, c16) holds row 16 mt + c16, columns 16 jn + 4 R4 + g of the wave tile; a 32-row slice is the two m tiles 2 i, 2 i + 1 and
+      // a lane's 4 values are 8 bytes of staging chunk 2 jn + (R4 >> 1).  Everything behind the staging slice is shared with the 32 x 32 form.
+      const int R4 = lane >> 4, c16 = lane & 15;
+      // bias goes into the accumulators first, unconditionally (zero when absent), so nothing extra stays live across the row loop
       if constexpr (M16) {
-        // 16 x 16 accumulator tiles (plain / GELU flavours only): lane (R, c) holds row 16 mt + c, columns 16 jn + 4 R + g.  The same staging
-        // slice and the same read-back as below: a 32-row slice is two m tiles, a lane's 4 values are 8 bytes of chunk 2 jn + (R >> 1).
-        const int R4 = lane >> 4, c16 = lane & 15;
 #pragma unroll
         for (int jn = 0; jn < 2 * TN; jn++) {
           const int n = nw + jn * 16 + 4 * R4;
@@ -1130,43 +1187,7 @@ __global__ __launch_bounds__(512) void gemm_pers_kernel(GemmParams p) {
 #pragma unroll
           for (int mt = 0; mt < 2 * TM; mt++) { acc4[mt][jn][0] += b4.x; acc4[mt][jn][1] += b4.y; acc4[mt][jn][2] += b4.z; acc4[mt][jn][3] += b4.w; }
         }
-#pragma unroll
-        for (int i = 0; i < TM; i++) {
-          if (i >= tm_eff) break;                      // half items: two 32-row slices per wave
-#pragma unroll
-          for (int pass = 0; pass < 2; pass++) {       // pass 0: GELU' as the second output (GELU flavour only); pass 1: final values
-            if (pass == 0 && !dual) continue;
-#pragma unroll
-            for (int mh = 0; mh < 2; mh++)
-#pragma unroll
-              for (int jn = 0; jn < 2 * TN; jn++) {
-                f32x4& a = acc4[2 * i + mh][jn];
-                float v[4] = {a[0], a[1], a[2], a[3]};
-                if (pass == 0 && act == 3) {
-                  float g[4];
-#pragma unroll
-                  for (int e = 0; e < 4; e++) { a[e] = gelu_tanh_both(v[e], g[e]); v[e] = g[e]; }
-                }
-                const int row = 16 * mh + c16, ch = 2 * jn + (R4 >> 1);
-                *reinterpret_cast<uint2*>(stg + row * 128 + ((ch ^ (row & 7)) << 4) + (R4 & 1) * 8) = pack_bf16x4(v[0], v[1], v[2], v[3]);
-              }
-            __builtin_amdgcn_s_waitcnt(0xc07f);        // lgkmcnt(0): the slice is private to this wave
-            bf16_t* dst = pass == 0 ? p.out2 : p.out;
-#pragma unroll
-            for (int t4 = 0; t4 < 4; t4++) {           // 8 rows x 128 B per store instruction
-              const int row = t4 * 8 + (lane >> 3), ch = lane & 7;
-              const uint4 v4 = *reinterpret_cast<const uint4*>(stg + row * 128 + ((ch ^ (row & 7)) << 4));
-              const int mm = mw + i * 32 + row, nn = nw + ch * 8;
-              if (mm < p.M && nn < p.N) *reinterpret_cast<uint4*>(dst + (size_t)mm * p.ldo + nn) = v4;
-            }
-            __builtin_amdgcn_s_waitcnt(0xc07f);        // reads returned before the slice is overwritten
-          }
-        }
-        return;
-      }
-      constexpr int JW = decltype(jw_c)::value, RB = JW * 64;
-      constexpr int LPR = JW * 4, RPI = 64 / LPR, NST = 4 / (3 - JW);   // read-back: JW = 2: 4 x (8 rows x 128 B); JW = 1: 2 x (16 rows x 64 B)
-      // bias goes into the accumulators first, unconditionally (zero when absent), so nothing extra stays live across the row loop
+      } else {
 #pragma unroll
       for (int jj = 0; jj < JW; jj++)
 #pragma unroll
@@ -1176,6 +1197,7 @@ __global__ __launch_bounds__(512) void gemm_pers_kernel(GemmParams p) {
 #pragma unroll
           for (int i = 0; i < TM; i++) { acc[i][j0 + jj][q * 4] += b4.x; acc[i][j0 + jj][q * 4 + 1] += b4.y; acc[i][j0 + jj][q * 4 + 2] += b4.z; acc[i][j0 + jj][q * 4 + 3] += b4.w; }
         }
+      }
       // bias-gradient column sums are taken from the read-back (row-wise) copy of the bf16 output: a lane keeps 8 running sums
       // for its 8-column chunk over all row slices; one 3-step lane tree at the end
       float cs[8], sq[2] = {0.f, 0.f};                 // statistics flavours: cs[0..1] / sq[0..1] = the chunk's two channel quads
@@ -1186,8 +1208,17 @@ __global__ __launch_bounds__(512) void gemm_pers_kernel(GemmParams p) {
       const int st_img = want_st ? mw / p.gn_img_rows : 0, st_base = st_img * p.gn_img_rows;
       // aux (saved pre-activation / saved GELU') of the NEXT row slice is requested before this slice is processed
       const bool want_aux = (act == 2 || act == 4 || act == 5);
-      uint2 ax[2][JW][4];
+      uint2 ax[2][JW][4];                              // M16: [slice parity][m tile of the slice][n tile]
       auto load_aux = [&](int i, uint2 (&dst)[JW][4]) {
+        if constexpr (M16) {
+#pragma unroll
+          for (int mh = 0; mh < 2; mh++)
+#pragma unroll
+            for (int jn = 0; jn < 4; jn++) {
+              const int m = mw + i * 32 + 16 * mh + c16, n = nw + jn * 16 + 4 * R4;
+              dst[mh][jn] = (m < p.M && n < p.N) ? *reinterpret_cast<const uint2*>(p.aux + (size_t)m * p.ldaux + n) : make_uint2(0u, 0u);
+            }
+        } else {
         const int m = mw + i * 32 + srow;
 #pragma unroll
         for (int jj = 0; jj < JW; jj++)
@@ -1196,6 +1227,27 @@ __global__ __launch_bounds__(512) void gemm_pers_kernel(GemmParams p) {
             const int n = nw + (j0 + jj) * 32 + 8 * q + 4 * hi;
             dst[jj][q] = (m < p.M && n < p.N) ? *reinterpret_cast<const uint2*>(p.aux + (size_t)m * p.ldaux + n) : make_uint2(0u, 0u);
           }
+        }
+      };
+      // one group of 4 values: activation / second output / aux by flavour; returns what is parked (and leaves GELU in the accumulator on pass 0)
+      auto finish4 = [&](int pass, float (&v)[4], auto&& put_back, const uint2& a2) {
+        if (pass == 0 && act == 3) {                   // second output = GELU'(pre-activation); the activation itself replaces
+          float g[4];                                  // the accumulator so that pass 1 only has to park it
+#pragma unroll
+          for (int e = 0; e < 4; e++) { put_back(e, gelu_tanh_both(v[e], g[e])); v[e] = g[e]; }
+        }
+        if (pass == 1) {
+          if (act == 1) {
+#pragma unroll
+            for (int e = 0; e < 4; e++) v[e] = gelu_tanh(v[e]);
+          } else if (act == 2 || act == 4 || act == 5) {
+            float a0, a1, a2f, a3;
+            unpack_bf16x2(a2.x, a0, a1); unpack_bf16x2(a2.y, a2f, a3);
+            if (act == 2) { a0 = gelu_tanh_grad(a0); a1 = gelu_tanh_grad(a1); a2f = gelu_tanh_grad(a2f); a3 = gelu_tanh_grad(a3); }
+            if (act == 5) { v[0] += a0; v[1] += a1; v[2] += a2f; v[3] += a3; }
+            else { v[0] *= a0; v[1] *= a1; v[2] *= a2f; v[3] *= a3; }
+          }
+        }
       };
       if (want_aux) load_aux(0, ax[0]);
 #pragma unroll
@@ -1205,33 +1257,30 @@ __global__ __launch_bounds__(512) void gemm_pers_kernel(GemmParams p) {
 #pragma unroll
         for (int pass = 0; pass < 2; pass++) {         // pass 0: second output (dual-output flavours only); pass 1: final values
           if (pass == 0 && !dual) continue;
+          if constexpr (M16) {
+#pragma unroll
+            for (int mh = 0; mh < 2; mh++)
+#pragma unroll
+              for (int jn = 0; jn < 4; jn++) {
+                f32x4& a = acc4[2 * i + mh][jn];
+                float v[4] = {a[0], a[1], a[2], a[3]};
+                finish4(pass, v, [&](int e, float x) { a[e] = x; }, ax[i & 1][mh][jn]);
+                const int row = 16 * mh + c16, ch = 2 * jn + (R4 >> 1);
+                *reinterpret_cast<uint2*>(stg + row * RB + ((ch ^ (row & 7)) << 4) + (R4 & 1) * 8) = pack_bf16x4(v[0], v[1], v[2], v[3]);
+              }
+          } else {
 #pragma unroll
           for (int jj = 0; jj < JW; jj++)
 #pragma unroll
             for (int q = 0; q < 4; q++) {
               const int j = j0 + jj;
               float v[4] = {acc[i][j][q * 4], acc[i][j][q * 4 + 1], acc[i][j][q * 4 + 2], acc[i][j][q * 4 + 3]};
-              if (pass == 0 && act == 3) {             // second output = GELU'(pre-activation); the activation itself replaces
-                float g[4];                            // the accumulator so that pass 1 only has to park it
-#pragma unroll
-                for (int e = 0; e < 4; e++) { acc[i][j][q * 4 + e] = gelu_tanh_both(v[e], g[e]); v[e] = g[e]; }
-              }
-              if (pass == 1) {
-                if (act == 1) {
-#pragma unroll
-                  for (int e = 0; e < 4; e++) v[e] = gelu_tanh(v[e]);
-                } else if (act == 2 || act == 4 || act == 5) {
-                  float a0, a1, a2, a3;
-                  unpack_bf16x2(ax[i & 1][jj][q].x, a0, a1); unpack_bf16x2(ax[i & 1][jj][q].y, a2, a3);
-                  if (act == 2) { a0 = gelu_tanh_grad(a0); a1 = gelu_tanh_grad(a1); a2 = gelu_tanh_grad(a2); a3 = gelu_tanh_grad(a3); }
-                  if (act == 5) { v[0] += a0; v[1] += a1; v[2] += a2; v[3] += a3; }
-                  else { v[0] *= a0; v[1] *= a1; v[2] *= a2; v[3] *= a3; }
-                }
-              }
+              finish4(pass, v, [&](int e, float x) { acc[i][j][q * 4 + e] = x; }, ax[i & 1][jj][q]);
               const int ch = jj * 4 + q;               // 16-byte chunk of the staging row
               const int sw = JW == 2 ? (srow & 7) : ((srow >> 1) & 3);
               *reinterpret_cast<uint2*>(stg + srow * RB + ((ch ^ sw) << 4) + hi * 8) = pack_bf16x4(v[0], v[1], v[2], v[3]);
             }
+          }
           __builtin_amdgcn_s_waitcnt(0xc07f);          // lgkmcnt(0): the slice is private to this wave
           bf16_t* dst = pass == 0 ? p.out2 : p.out;
 #pragma unroll
@@ -1293,7 +1342,7 @@ __global__ __launch_bounds__(512) void gemm_pers_kernel(GemmParams p) {
     } else {
 #pragma unroll
       for (int j0 = 0; j0 + 1 < TN; j0 += 2) emit(j0, IntC<2>{});
-      if (TN % 2) emit(TN - 1, IntC<1>{});
+      if constexpr (TN % 2 == 1) emit(TN - 1, IntC<1>{});
     }
     PXA_TR(5);
 #if GEMM_TRACE
