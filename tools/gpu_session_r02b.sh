@@ -1,5 +1,6 @@
 # One GPU-box session (run from the repo root through gpurun): MFMA shape probe, A/B of the XCD-aware attention block order, the GPU test
 # tier, the default bench line and the round profile bundle.  Everything lands under gpurun_out/; copy what is kept into profiles/.
+# Variant library of this session: python tools/build_variant.py noxcd pixart_sigma_amd/csrc/attn.hip -DATTN_XCD_HEADS=0
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
 o=gpurun_out

@@ -1,5 +1,7 @@
 # GPU-box session: v_permlane16_swap probe, parity of the 16x16x32 second products of the attention kernels, their A/B against the 32-row
 # build (-DATTN_PV16=0), the GEMM main loop with its FLOPs issued as 16x16x32 MFMAs (-DGEMM_ABL=4, wrong results on purpose), full GPU tier.
+# Variant libraries of this session (state of commit d2156f7's parent): build_variant.py pv32 csrc/attn.hip -DATTN_PV16=0 (then: every attention kernel);
+# build_variant.py gemm16 csrc/gemm.hip -DGEMM_ABL=4
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
 o=gpurun_out

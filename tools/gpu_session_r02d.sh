@@ -1,4 +1,6 @@
 # GPU-box session: NT GEMMs on 16x16x32 MFMAs (parity + A/B against -DGEMM_NT16=0), dK/dV kernel modes (-DATTN_DKV16=1..3), full GPU tier, bench.
+# Variant libraries of this session: build_variant.py nt32 csrc/gemm.hip -DGEMM_NT16=0 (the switch is GEMM_M16 since the next commit); build_variant.py dkv{1,2,3}
+# csrc/attn.hip -DATTN_DKV16={1,2,3}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
 o=gpurun_out

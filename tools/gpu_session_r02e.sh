@@ -1,4 +1,5 @@
 # GPU-box session: NN / TN GEMMs and the VAE's implicit convolutions on 16x16x32 MFMAs (GEMM_M16=7) against NT only (-DGEMM_M16=1): parity, A/B, VAE
+# Variant libraries of this session (product built with GEMM_M16=7): build_variant.py m16nt csrc/gemm.hip -DGEMM_M16=1; build_variant.py m16none csrc/gemm.hip -DGEMM_M16=0
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
 o=gpurun_out
