@@ -479,7 +479,7 @@ __global__ __launch_bounds__(256) void attn_delta_rows_kernel(const bf16_t* __re
 #pragma unroll
   for (int i = 0; i < NCH; i++) {
     const int c = threadIdx.x + 256 * i;
-    if (c < nchunks) { a[i] = po[c]; d[i] = pd[c]; }
+    if (c < nchunks) { a[i] = ld_u4(po + c); d[i] = ld_u4(pd + c); }
   }
 #pragma unroll
   for (int i = 0; i < NCH; i++) {

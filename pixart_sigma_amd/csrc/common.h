@@ -139,6 +139,35 @@ __device__ __forceinline__ float gelu_tanh_grad(float x) {
   return fmaf(s * one_minus_s, x * fmaf(x2, 6.0f * k0 * k1, 2.0f * k0), s);
 }
 
+// Streaming accesses: rows / flat buffers whose every byte is touched once per launch (the HBM-bound kernels of norm.hip, optim.hip, the
+// delta pre-pass).  Non-temporal loads and stores measured ln_mod_fwd 200 -> 167 us (4.5 -> 5.4 TB/s), ln_mod_bwd 247 -> 227, gate_bwd 234 -> 225,
+// the training step -2.8 ms (profiles/r02h_elem_nt.txt).  PXA_STREAM_NT (A/B builds): bit 0 = stores, bit 1 = loads.
+#ifndef PXA_STREAM_NT
+#define PXA_STREAM_NT 3
+#endif
+typedef unsigned nt_u4 __attribute__((ext_vector_type(4)));
+typedef unsigned nt_u2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void st_f4(float* p, const float4& v) {
+  if (PXA_STREAM_NT & 1) __builtin_nontemporal_store(f32x4{v.x, v.y, v.z, v.w}, reinterpret_cast<f32x4*>(p));
+  else *reinterpret_cast<float4*>(p) = v;
+}
+__device__ __forceinline__ void st_u2(void* p, const uint2& v) {
+  if (PXA_STREAM_NT & 1) __builtin_nontemporal_store(nt_u2{v.x, v.y}, reinterpret_cast<nt_u2*>(p));
+  else *reinterpret_cast<uint2*>(p) = v;
+}
+__device__ __forceinline__ float4 ld_f4(const float* p) {
+  if (PXA_STREAM_NT & 2) { const f32x4 t = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p)); return make_float4(t[0], t[1], t[2], t[3]); }
+  return *reinterpret_cast<const float4*>(p);
+}
+__device__ __forceinline__ uint2 ld_u2(const void* p) {
+  if (PXA_STREAM_NT & 2) { const nt_u2 t = __builtin_nontemporal_load(reinterpret_cast<const nt_u2*>(p)); return make_uint2(t[0], t[1]); }
+  return *reinterpret_cast<const uint2*>(p);
+}
+__device__ __forceinline__ uint4 ld_u4(const void* p) {
+  if (PXA_STREAM_NT & 2) { const nt_u4 t = __builtin_nontemporal_load(reinterpret_cast<const nt_u4*>(p)); return make_uint4(t[0], t[1], t[2], t[3]); }
+  return *reinterpret_cast<const uint4*>(p);
+}
+
 __device__ __forceinline__ float half_wave_sum(float v) {  // reduce inside each 32-lane half
   v += __shfl_xor(v, 16); v += __shfl_xor(v, 8); v += __shfl_xor(v, 4); v += __shfl_xor(v, 2); v += __shfl_xor(v, 1);
   return v;

@@ -607,6 +607,12 @@ __device__ __forceinline__ void mfma_abl16(f32x4 (&q)[4], bf16x8 b0, bf16x8 a0, 
                             // 2-4 % SLOWER in the 16-row shape (its read phase - 24 transpose reads + ~39 address VALU per k-unit - no longer fits into the issue
                             // slots 32 back-to-back 16-cycle MFMAs of the partner wave leave: 3 per MFMA instead of 7), so it stays on 32x32x16
 #endif
+#ifndef GEMM_NT_STORE
+#define GEMM_NT_STORE 0     // bf16 output rows of the persistent kernel as non-temporal stores (A/B builds)
+#endif
+#ifndef GEMM_M16_PRIO
+#define GEMM_M16_PRIO 1     // s_setprio 1 around the 16-row matrix phases (0: none; A/B builds)
+#endif
 #ifndef GEMM_PHASE16
 #define GEMM_PHASE16 -1     // matrix phases per k-unit: -1 = per layout (below), 0 = two 8-MFMA phases everywhere, 1 = one 16-MFMA phase everywhere
 #endif
@@ -970,12 +976,12 @@ __global__ __launch_bounds__(512) void gemm_pers_kernel(GemmParams p) {
         else if (REM == 1) wait_vmcnt<0>();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         PXA_SB(); __builtin_amdgcn_s_barrier(); PXA_SB();
-        __builtin_amdgcn_s_setprio(1);
+        if (GEMM_M16_PRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int i = 0; i < 4 * TH; i++)
 #pragma unroll
           for (int j = 0; j < 2 * TN; j++) acc4[i][j] = mfma16(bq[j], aq[i], acc4[i][j]);
-        __builtin_amdgcn_s_setprio(0);
+        if (GEMM_M16_PRIO) __builtin_amdgcn_s_setprio(0);
         PXA_SB(); __builtin_amdgcn_s_barrier(); PXA_SB();
         return;
       }
@@ -1035,12 +1041,12 @@ __global__ __launch_bounds__(512) void gemm_pers_kernel(GemmParams p) {
           for (int i = 0; i < 2 * TH; i++) aq[i] = frag16<A_KC>(sA, a_rb + (h * 2 * TH + i) * 16, lane, rla);
           if (h == 0) rest_a(); else rest_b();
           PXA_SB(); __builtin_amdgcn_s_barrier(); PXA_SB();
-          __builtin_amdgcn_s_setprio(1);
+          if (GEMM_M16_PRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
           for (int i = 0; i < 2 * TH; i++)
 #pragma unroll
             for (int j = 0; j < 2 * TN; j++) acc4[h * 2 * TH + i][j] = mfma16(bq[j], aq[i], acc4[h * 2 * TH + i][j]);
-          __builtin_amdgcn_s_setprio(0);
+          if (GEMM_M16_PRIO) __builtin_amdgcn_s_setprio(0);
           PXA_SB(); __builtin_amdgcn_s_barrier(); PXA_SB();
         }
         return;
@@ -1289,7 +1295,10 @@ __global__ __launch_bounds__(512) void gemm_pers_kernel(GemmParams p) {
             const int sw = JW == 2 ? (row & 7) : ((row >> 1) & 3);
             const uint4 v4 = *reinterpret_cast<const uint4*>(stg + row * RB + ((ch ^ sw) << 4));
             const int mm = mw + i * 32 + row, nn = nw + j0 * 32 + ch * 8;
-            if (mm < p.M && nn < p.N) *reinterpret_cast<uint4*>(dst + (size_t)mm * p.ldo + nn) = v4;
+            if (mm < p.M && nn < p.N) {
+              if (GEMM_NT_STORE) __builtin_nontemporal_store(nt_u4{v4.x, v4.y, v4.z, v4.w}, reinterpret_cast<nt_u4*>(dst + (size_t)mm * p.ldo + nn));
+              else *reinterpret_cast<uint4*>(dst + (size_t)mm * p.ldo + nn) = v4;
+            }
             if (pass == 1 && want_cs && mm < p.M) {
               float f[8];
               unpack_bf16x8(v4, f);

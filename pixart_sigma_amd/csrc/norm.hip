@@ -25,12 +25,12 @@ __global__ __launch_bounds__(256) void ln_mod_fwd_kernel(
   const size_t base = (size_t)row * D;
   float4 v[NV];
 #pragma unroll
-  for (int j = 0; j < NV; j++) v[j] = *reinterpret_cast<const float4*>(x + base + (hl + 32 * j) * 4);
+  for (int j = 0; j < NV; j++) v[j] = ld_f4(x + base + (hl + 32 * j) * 4);
   if (u) {
 #pragma unroll
     for (int j = 0; j < NV; j++) {
       const int c = (hl + 32 * j) * 4;
-      const uint2 uu = *reinterpret_cast<const uint2*>(u + base + c);
+      const uint2 uu = ld_u2(u + base + c);
       float u0, u1, u2, u3;
       unpack_bf16x2(uu.x, u0, u1); unpack_bf16x2(uu.y, u2, u3);
       if (gate) {
@@ -43,11 +43,11 @@ __global__ __launch_bounds__(256) void ln_mod_fwd_kernel(
   }
   if (x_out) {
 #pragma unroll
-    for (int j = 0; j < NV; j++) *reinterpret_cast<float4*>(x_out + base + (hl + 32 * j) * 4) = v[j];
+    for (int j = 0; j < NV; j++) st_f4(x_out + base + (hl + 32 * j) * 4, v[j]);
   }
   if (xb) {
 #pragma unroll
-    for (int j = 0; j < NV; j++) *reinterpret_cast<uint2*>(xb + base + (hl + 32 * j) * 4) = pack_bf16x4(v[j].x, v[j].y, v[j].z, v[j].w);
+    for (int j = 0; j < NV; j++) st_u2(xb + base + (hl + 32 * j) * 4, pack_bf16x4(v[j].x, v[j].y, v[j].z, v[j].w));
   }
   if (!xn) return;
   float s = 0.f;
@@ -71,7 +71,7 @@ __global__ __launch_bounds__(256) void ln_mod_fwd_kernel(
     float y1 = (v[j].y - mean) * rstd * (1.f + sc.y) + sh.y;
     float y2 = (v[j].z - mean) * rstd * (1.f + sc.z) + sh.z;
     float y3 = (v[j].w - mean) * rstd * (1.f + sc.w) + sh.w;
-    *reinterpret_cast<uint2*>(xn + base + c) = pack_bf16x4(y0, y1, y2, y3);
+    st_u2(xn + base + c, pack_bf16x4(y0, y1, y2, y3));
   }
 }
 
@@ -126,15 +126,15 @@ __global__ __launch_bounds__(256) void ln_mod_bwd_kernel(
 #if LNB_VARIANT == 1
     if (dx_in) {
 #pragma unroll
-      for (int j = 0; j < NV; j++) di[j] = *reinterpret_cast<const float4*>(dx_in + base + (hl + 32 * j) * 4);
+      for (int j = 0; j < NV; j++) di[j] = ld_f4(dx_in + base + (hl + 32 * j) * 4);
     }
 #endif
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int j = 0; j < NV; j++) {
       const int c = (hl + 32 * j) * 4;
-      const uint2 dd = *reinterpret_cast<const uint2*>(dy + base + c);
-      const float4 xv = *reinterpret_cast<const float4*>(x + base + c);
+      const uint2 dd = ld_u2(dy + base + c);
+      const float4 xv = ld_f4(x + base + c);
       const float4 sc = *reinterpret_cast<const float4*>(scale + (size_t)b * mod_stride + c);
       float d0, d1, d2, d3;
       unpack_bf16x2(dd.x, d0, d1); unpack_bf16x2(dd.y, d2, d3);
@@ -165,8 +165,8 @@ __global__ __launch_bounds__(256) void ln_mod_bwd_kernel(
         o.x += di.x; o.y += di.y; o.z += di.z; o.w += di.w;
 #endif
       }
-      *reinterpret_cast<float4*>(dx_out + base + c) = o;
-      if (dx_bf16) *reinterpret_cast<uint2*>(dx_bf16 + base + c) = pack_bf16x4(o.x, o.y, o.z, o.w);
+      st_f4(dx_out + base + c, o);
+      if (dx_bf16) st_u2(dx_bf16 + base + c, pack_bf16x4(o.x, o.y, o.z, o.w));
     }
   }
   if (r_beg < R) flush(cur_b);
@@ -228,9 +228,9 @@ __global__ __launch_bounds__(256) void gate_bwd_kernel(
 #pragma unroll
     for (int j = 0; j < NV; j++) {
       const int c = (hl + 32 * j) * 4;
-      gv[j] = *reinterpret_cast<const float4*>(dx + base + c);
-      if (add) av[j] = *reinterpret_cast<const uint2*>(add + base + c);
-      if (gate) uv[j] = *reinterpret_cast<const uint2*>(u + base + c);
+      gv[j] = ld_f4(dx + base + c);
+      if (add) av[j] = ld_u2(add + base + c);
+      if (gate) uv[j] = ld_u2(u + base + c);
     }
 #pragma unroll
     for (int j = 0; j < NV; j++) {
@@ -241,7 +241,7 @@ __global__ __launch_bounds__(256) void gate_bwd_kernel(
         unpack_bf16x2(av[j].x, a0, a1); unpack_bf16x2(av[j].y, a2, a3);
         g.x += a0; g.y += a1; g.z += a2; g.w += a3;
       }
-      if (dx_out) *reinterpret_cast<float4*>(dx_out + base + c) = g;
+      if (dx_out) st_f4(dx_out + base + c, g);
       float4 o = g;
       if (gate) {
         const float4 gt = *reinterpret_cast<const float4*>(gate + (size_t)b * mod_stride + c);
@@ -250,7 +250,7 @@ __global__ __launch_bounds__(256) void gate_bwd_kernel(
         ag[j].x += g.x * u0; ag[j].y += g.y * u1; ag[j].z += g.z * u2; ag[j].w += g.w * u3;
         o = make_float4(g.x * gt.x, g.y * gt.y, g.z * gt.z, g.w * gt.w);
       }
-      if (du) *reinterpret_cast<uint2*>(du + base + c) = pack_bf16x4(o.x, o.y, o.z, o.w);
+      if (du) st_u2(du + base + c, pack_bf16x4(o.x, o.y, o.z, o.w));
       ab[j].x += o.x; ab[j].y += o.y; ab[j].z += o.z; ab[j].w += o.w;
     }
   }

@@ -19,7 +19,7 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ x,
   float acc = 0.f;
   const long n4 = n / 4;
   for (long i = blockIdx.x * 256L + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
-    const float4 v = reinterpret_cast<const float4*>(x)[i];
+    const float4 v = reinterpret_cast<const float4*>(x)[i];      // plain load: the optimizer step re-reads the gradient right behind this pass
     acc += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
   }
   if (blockIdx.x == 0 && threadIdx.x == 0)
@@ -70,9 +70,9 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
   const float gs = gscale ? gscale[0] : 1.f;
   const long n4 = n / 4;
   for (long i = blockIdx.x * 256L + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
-    float4 pv = reinterpret_cast<float4*>(p)[i];
-    const float4 gv = reinterpret_cast<const float4*>(g)[i];
-    float4 mv = reinterpret_cast<float4*>(m)[i], vv = reinterpret_cast<float4*>(v)[i];
+    float4 pv = ld_f4(p + 4 * i);
+    const float4 gv = ld_f4(g + 4 * i);
+    float4 mv = ld_f4(m + 4 * i), vv = ld_f4(v + 4 * i);
     float pa[4] = {pv.x, pv.y, pv.z, pv.w}, ga[4] = {gv.x * gs, gv.y * gs, gv.z * gs, gv.w * gs};
     float ma[4] = {mv.x, mv.y, mv.z, mv.w}, va[4] = {vv.x, vv.y, vv.z, vv.w};
 #pragma unroll
@@ -83,10 +83,10 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
       const float denom = sqrtf(va[e]) / bc2_sqrt + eps;
       pa[e] -= (lr / bc1) * (ma[e] / denom);
     }
-    reinterpret_cast<float4*>(p)[i] = make_float4(pa[0], pa[1], pa[2], pa[3]);
-    reinterpret_cast<float4*>(m)[i] = make_float4(ma[0], ma[1], ma[2], ma[3]);
-    reinterpret_cast<float4*>(v)[i] = make_float4(va[0], va[1], va[2], va[3]);
-    if (pb) reinterpret_cast<uint2*>(pb)[i] = pack_bf16x4(pa[0], pa[1], pa[2], pa[3]);
+    st_f4(p + 4 * i, make_float4(pa[0], pa[1], pa[2], pa[3]));
+    st_f4(m + 4 * i, make_float4(ma[0], ma[1], ma[2], ma[3]));
+    st_f4(v + 4 * i, make_float4(va[0], va[1], va[2], va[3]));
+    if (pb) st_u2(pb + 4 * i, pack_bf16x4(pa[0], pa[1], pa[2], pa[3]));
   }
 }
 
