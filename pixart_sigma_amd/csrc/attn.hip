@@ -244,12 +244,10 @@ __device__ __forceinline__ void pack_xy(const f32x16& v, bf16x8& x, bf16x8& y) {
   x = __builtin_bit_cast(bf16x8, ux);
   y = __builtin_bit_cast(bf16x8, uy);
 }
-#ifndef ATTN_PV16
-#define ATTN_PV16 1    // forward and dQ kernels: 0 = second products on three 32-row tiles (the round-1 kernels; A/B builds, tools/build_variant.py)
-#endif
-#ifndef ATTN_DKV16
-#define ATTN_DKV16 0   // dK/dV kernel: 0 = 32-row tiles, 1 = both second products on the 16-row shape, 2 = the same with the dV / dK MFMAs of a d tile
-#endif                 // interleaved in source order, 3 = dV on the 16-row shape and dK on 32-row tiles
+// Used by the forward and dQ kernels (dQ -5.7 %, forward -1.5 % against the 32-row form, profiles/r02c_attn_pv16_ab.txt).  The dK/dV kernel - two
+// such products and two re-layouts per block, and the heaviest softmax beside them - measured 3-7 % SLOWER in every variant of it (both products, one
+// of them, MFMAs interleaved by hand: profiles/r02d_attn_dkv_modes.txt; the 16-cycle MFMAs leave the SIMD's other wave fewer issue slots) and keeps
+// its 32-row tiles.
 constexpr int NT16 = 5;              // ceil(72 / 16) output tiles
 struct Acc16 { f32x4 v[NT16][2]; };  // [d tile][column half]: lane (R, c) <-> d = 16 t + 4 R + g, output row c / 16 + c of the wave's 32
 __device__ __forceinline__ void zero16(Acc16& a) {
@@ -320,15 +318,10 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
     init_pads(smem + st * 2 * TILE_B, false, tid);            // K
     init_pads(smem + st * 2 * TILE_B + TILE_B, true, tid);    // V: column 72 = 1 -> O^T row 72 accumulates sum_kv P = l
   }
-#if ATTN_PV16
   Acc16 o;
   zero16(o);
   Tr16Addr ta;
   tr16_addr(ta, lane);
-#else
-  f32x16 o[3];
-  zero3(o);
-#endif
   float m = -INFINITY;
   const float c = p.scale_log2;
 
@@ -363,38 +356,22 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
       const float mn = fmaxf(m, mt);
       const float alpha = __builtin_amdgcn_exp2f((m - mn) * c);
       m = mn;
-#if ATTN_PV16
       const float ao = __shfl_xor(alpha, 16);           // the accumulators of lane (R, c) belong to queries c and 16 + c, alpha to query l & 31
       const float a0 = (lane & 16) ? ao : alpha, a1 = (lane & 16) ? alpha : ao;
 #pragma unroll
       for (int t = 0; t < NT16; t++) { o.v[t][0] *= a0; o.v[t][1] *= a1; }   // includes the row-sum row (d = 72)
-#else
-#pragma unroll
-      for (int dt = 0; dt < 3; dt++)
-#pragma unroll
-        for (int g = 0; g < 16; g++) o[dt][g] *= alpha;   // includes the row-sum row (d = 72)
-#endif
     }
     const float mc = m * c;
 #pragma unroll
     for (int sub = 0; sub < 2; sub++)
 #pragma unroll
       for (int g = 0; g < 16; g++) s[sub][g] = __builtin_amdgcn_exp2f(s[sub][g] * c - mc);
-#if ATTN_PV16
 #pragma unroll
     for (int sub = 0; sub < 2; sub++) {
       bf16x8 px, py;
       pack_xy(s[sub], px, py);
       mma16(o, sV, ta, sub, px, py);
     }
-#else
-#pragma unroll
-    for (int u = 0; u < 4; u++) {
-      const bf16x8 pb = pack8(s[u >> 1], 8 * (u & 1));
-#pragma unroll
-      for (int dt = 0; dt < 3; dt++) o[dt] = mfma32(trfrag(sV, fa, dt, u), pb, o[dt]);
-    }
-#endif
   };
 
   const int Tfull = kvlen / BKV, rem = kvlen - Tfull * BKV, T = Tfull + (rem ? 1 : 0);
@@ -420,7 +397,6 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
     const char* st = smem + (Tfull & 1) * 2 * TILE_B;
     tile(BoolC<true>{}, st, st + TILE_B, Tfull * BKV);
   }
-#if ATTN_PV16
   // row 72 of O^T (tile 4, lane row 2, g = 0: lanes 32 + c) = sum over keys of the bf16 P actually multiplied into O
   const float la = __shfl(o.v[4][0][0], 32 + (lane & 15)), lb = __shfl(o.v[4][1][0], 32 + (lane & 15));
   const float l = (lane & 16) ? lb : la;               // of query l & 31
@@ -429,15 +405,6 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
   store_rows16(p.O + (long)b * p.o_bs + (long)q0w * p.o_ts + (long)h * p.o_hs, p.o_ts, o, (lane & 16) ? invo : inv, (lane & 16) ? inv : invo,
                q0w + (lane & 15) < p.Nq, q0w + 16 + (lane & 15) < p.Nq, lane);
   if (qvalid && hi == 0 && p.LSE) p.LSE[((long)b * p.H + h) * p.Nq + q] = m * c + log2f(l);
-#else
-  // row 72 of O^T (dt = 2, g = 4, lanes with hi = 0) = sum over keys of the bf16 P actually multiplied into O
-  const float l = __shfl(o[2][4], lane & 31);
-  if (qvalid) {
-    const float inv = l > 0.f ? 1.f / l : 0.f;
-    store_rows(p.O + (long)b * p.o_bs + (long)q * p.o_ts + (long)h * p.o_hs, o, inv, hi);
-    if (hi == 0 && p.LSE) p.LSE[((long)b * p.H + h) * p.Nq + q] = m * c + log2f(l);
-  }
-#endif
 }
 
 // ------------------------------------------------------------------------------------------------ delta = rowsum(dO * O)
@@ -537,21 +504,13 @@ __global__ __launch_bounds__(256, 2) void attn_fwd2_kernel(AttnParams p) {
     init_pads(smem + st * 2 * TILE_B, false, tid);            // K
     init_pads(smem + st * 2 * TILE_B + TILE_B, true, tid);    // V: column 72 = 1 -> O^T row 72 accumulates sum_kv P = l
   }
-#if ATTN_PV16
   Acc16 o[QS];
   Tr16Addr ta;
   tr16_addr(ta, lane);
-#else
-  f32x16 o[QS][3];
-#endif
   float m[QS];
 #pragma unroll
   for (int s = 0; s < QS; s++) {
-#if ATTN_PV16
     zero16(o[s]);
-#else
-    zero3(o[s]);
-#endif
     m[s] = -INFINITY;
   }
   const float c = p.scale_log2;
@@ -593,17 +552,10 @@ __global__ __launch_bounds__(256, 2) void attn_fwd2_kernel(AttnParams p) {
         const float mn = fmaxf(m[s], mt);
         const float alpha = __builtin_amdgcn_exp2f((m[s] - mn) * c);
         m[s] = mn;
-#if ATTN_PV16
         const float ao = __shfl_xor(alpha, 16);
         const float a0 = (lane & 16) ? ao : alpha, a1 = (lane & 16) ? alpha : ao;
 #pragma unroll
         for (int t = 0; t < NT16; t++) { o[s].v[t][0] *= a0; o[s].v[t][1] *= a1; }
-#else
-#pragma unroll
-        for (int dt = 0; dt < 3; dt++)
-#pragma unroll
-          for (int g = 0; g < 16; g++) o[s][dt][g] *= alpha;
-#endif
       }
       const float mc = m[s] * c;
 #pragma unroll
@@ -611,7 +563,6 @@ __global__ __launch_bounds__(256, 2) void attn_fwd2_kernel(AttnParams p) {
 #pragma unroll
         for (int g = 0; g < 16; g++) sc[s][sub][g] = __builtin_amdgcn_exp2f(sc[s][sub][g] * c - mc);
     }
-#if ATTN_PV16
 #pragma unroll
     for (int sub = 0; sub < 2; sub++) {
       bf16x8 px[QS], py[QS];
@@ -627,20 +578,6 @@ __global__ __launch_bounds__(256, 2) void attn_fwd2_kernel(AttnParams p) {
         }
       }
     }
-#else
-#pragma unroll
-    for (int u = 0; u < 4; u++) {
-      bf16x8 pb[QS];
-#pragma unroll
-      for (int s = 0; s < QS; s++) pb[s] = pack8(sc[s][u >> 1], 8 * (u & 1));
-#pragma unroll
-      for (int dt = 0; dt < 3; dt++) {
-        const bf16x8 vf = trfrag(sV, fa, dt, u);             // one transposed fragment, two MFMAs
-#pragma unroll
-        for (int s = 0; s < QS; s++) o[s][dt] = mfma32(vf, pb[s], o[s][dt]);
-      }
-    }
-#endif
   };
 
   const int Tfull = kvlen / BKV, rem = kvlen - Tfull * BKV, T = Tfull + (rem ? 1 : 0);
@@ -668,7 +605,6 @@ __global__ __launch_bounds__(256, 2) void attn_fwd2_kernel(AttnParams p) {
   }
 #pragma unroll
   for (int s = 0; s < QS; s++) {
-#if ATTN_PV16
     const float la = __shfl(o[s].v[4][0][0], 32 + (lane & 15)), lb = __shfl(o[s].v[4][1][0], 32 + (lane & 15));
     const float l = (lane & 16) ? lb : la;             // row 72 of O^T = sum over keys of the bf16 P actually multiplied into O, of query l & 31
     const float inv = l > 0.f ? 1.f / l : 0.f, invo = __shfl_xor(inv, 16);
@@ -676,14 +612,6 @@ __global__ __launch_bounds__(256, 2) void attn_fwd2_kernel(AttnParams p) {
     store_rows16(p.O + (long)b * p.o_bs + (long)q0w * p.o_ts + (long)h * p.o_hs, p.o_ts, o[s], (lane & 16) ? invo : inv, (lane & 16) ? inv : invo,
                  q0w + (lane & 15) < p.Nq, q0w + 16 + (lane & 15) < p.Nq, lane);
     if (qvalid[s] && hi == 0 && p.LSE) p.LSE[((long)b * p.H + h) * p.Nq + q[s]] = m[s] * c + log2f(l);
-#else
-    const float l = __shfl(o[s][2][4], lane & 31);     // row 72 of O^T = sum over keys of the bf16 P actually multiplied into O
-    if (qvalid[s]) {
-      const float inv = l > 0.f ? 1.f / l : 0.f;
-      store_rows(p.O + (long)b * p.o_bs + (long)q[s] * p.o_ts + (long)h * p.o_hs, o[s], inv, hi);
-      if (hi == 0 && p.LSE) p.LSE[((long)b * p.H + h) * p.Nq + q[s]] = m[s] * c + log2f(l);
-    }
-#endif
   }
 }
 
@@ -719,15 +647,10 @@ __global__ __launch_bounds__(256, ATTN_BWD_WAVES) void attn_bwd_dq_kernel(AttnPa
   frag_addr(fa, lane);
 
   for (int st = 0; st < 4; st++) init_pads(smem + st * TILE_B, false, tid);
-#if ATTN_PV16
   Acc16 dq;
   zero16(dq);
   Tr16Addr ta;
   tr16_addr(ta, lane);
-#else
-  f32x16 dq[3];
-  zero3(dq);
-#endif
   const float c = p.scale_log2;
   auto tile = [&](auto tailc, const char* sK, const char* sV, int kv0) {
     constexpr bool TAIL = decltype(tailc)::value;
@@ -750,21 +673,12 @@ __global__ __launch_bounds__(256, ATTN_BWD_WAVES) void attn_bwd_dq_kernel(AttnPa
         if (TAIL && kv0 + sub * 32 + (g & 3) + 8 * (g >> 2) + 4 * hi >= kvlen) pr = 0.f;
         s[sub][g] = pr * (dp[sub][g] - delta);  // dS^T (without the softmax scale, applied at the end)
       }
-#if ATTN_PV16
 #pragma unroll
     for (int sub = 0; sub < 2; sub++) {
       bf16x8 dx, dy;
       pack_xy(s[sub], dx, dy);
       mma16(dq, sK, ta, sub, dx, dy);
     }
-#else
-#pragma unroll
-    for (int u = 0; u < 4; u++) {
-      const bf16x8 db = pack8(s[u >> 1], 8 * (u & 1));
-#pragma unroll
-      for (int dt = 0; dt < 3; dt++) dq[dt] = mfma32(trfrag(sK, fa, dt, u), db, dq[dt]);
-    }
-#endif
   };
   const int Tfull = kvlen / BKV, rem = kvlen - Tfull * BKV, T = Tfull + (rem ? 1 : 0);
   auto issue = [&](int t) {                // DMA of tile t into stage t&1
@@ -789,15 +703,10 @@ __global__ __launch_bounds__(256, ATTN_BWD_WAVES) void attn_bwd_dq_kernel(AttnPa
     const char* st = smem + (Tfull & 1) * 2 * TILE_B;
     tile(BoolC<true>{}, st, st + TILE_B, Tfull * BKV);
   }
-#if ATTN_PV16
   const int q0w = bx * 128 + wave * 32;
   const bool ok0 = q0w + (lane & 15) < p.Nq, ok1 = q0w + 16 + (lane & 15) < p.Nq;
   store_rows16(p.dQ + (long)b * p.dq_bs + (long)q0w * p.dq_ts + (long)h * p.dq_hs, p.dq_ts, dq, p.scale, p.scale, ok0, ok1, lane);
   if (p.dq_colsum) colsum_rows16(p.dq_colsum + (b % PXA_COLSUM_SLOTS) * p.colsum_stride + h * DH, dq, p.scale, ok0, ok1, lane);
-#else
-  if (qvalid) store_rows(p.dQ + (long)b * p.dq_bs + (long)q * p.dq_ts + (long)h * p.dq_hs, dq, p.scale, hi);
-  if (p.dq_colsum) colsum_rows(p.dq_colsum + (b % PXA_COLSUM_SLOTS) * p.colsum_stride + h * DH, dq, p.scale, qvalid, hi, lane);
-#endif
 }
 
 // ------------------------------------------------------------------------------------------------ backward: dK, dV
@@ -830,13 +739,9 @@ __global__ __launch_bounds__(256, ATTN_BWD_WAVES) void attn_bwd_dkv_kernel(AttnP
   frag_addr(fa, lane);
 
   for (int st = 0; st < 4; st++) init_pads(smem + st * TILE_B, false, tid);
-  constexpr bool DV16 = ATTN_DKV16 != 0, DK16 = ATTN_DKV16 == 1 || ATTN_DKV16 == 2;
-  Acc16 dk16, dv16;                    // the set a build does not use is never touched and costs no registers
   f32x16 dk[3], dv[3];
-  if (DV16) zero16(dv16); else zero3(dv);
-  if (DK16) zero16(dk16); else zero3(dk);
-  Tr16Addr ta;
-  tr16_addr(ta, lane);
+  zero3(dk);
+  zero3(dv);
   const float c = p.scale_log2;
   const int T = (p.Nq + BKV - 1) / BKV;
   float rl = INFINITY, rdl = 0.f;
@@ -899,29 +804,6 @@ __global__ __launch_bounds__(256, ATTN_BWD_WAVES) void attn_bwd_dkv_kernel(AttnP
           dp[qd * 4 + e] = pr * (dp[qd * 4 + e] - Dv[e]);
         }
       }
-      if (DV16 && DK16) {
-        bf16x8 px, py, dx, dy;
-        pack_xy(s, px, py);
-        pack_xy(dp, dx, dy);
-        if (ATTN_DKV16 == 2) {
-#pragma unroll
-          for (int t = 0; t < NT16; t++) {
-            const bf16x8 ad = trfrag16(sD, ta, t, sub), aq = trfrag16(sQ, ta, t, sub);
-            dv16.v[t][0] = mfma16(ad, px, dv16.v[t][0]);
-            dk16.v[t][0] = mfma16(aq, dx, dk16.v[t][0]);
-            dv16.v[t][1] = mfma16(ad, py, dv16.v[t][1]);
-            dk16.v[t][1] = mfma16(aq, dy, dk16.v[t][1]);
-          }
-        } else {
-          mma16(dv16, sD, ta, sub, px, py);    // dV^T[d][kv] += dO^T[d][q] P[q][kv]
-          mma16(dk16, sQ, ta, sub, dx, dy);    // dK^T[d][kv] += Q^T[d][q] dS[q][kv]
-        }
-      } else {
-      if (DV16) {
-        bf16x8 px, py;
-        pack_xy(s, px, py);
-        mma16(dv16, sD, ta, sub, px, py);
-      }
 #pragma unroll
       for (int uu = 0; uu < 2; uu++) {
         const bf16x8 pb = pack8(s, 8 * uu), db = pack8(dp, 8 * uu);
@@ -934,32 +816,19 @@ __global__ __launch_bounds__(256, ATTN_BWD_WAVES) void attn_bwd_dkv_kernel(AttnP
             dv[dt][u] += (float)dot[0] * (float)pb[dt];
             dk[dt][u] += (float)qt[0] * (float)db[dt];
           } else {
-            if (!DV16) dv[dt] = mfma32(dot, pb, dv[dt]);
+            dv[dt] = mfma32(dot, pb, dv[dt]);
             dk[dt] = mfma32(qt, db, dk[dt]);
           }
         }
       }
-      }
     }
   }
-  const int kv0w = bx * 128 + wave * 32;
-  const bool ok0 = kv0w + (lane & 15) < kvlen, ok1 = kv0w + 16 + (lane & 15) < kvlen;
-  float* const cs_k = p.dk_colsum ? p.dk_colsum + (b % PXA_COLSUM_SLOTS) * p.colsum_stride + h * DH : nullptr;
-  float* const cs_v = p.dv_colsum ? p.dv_colsum + (b % PXA_COLSUM_SLOTS) * p.colsum_stride + h * DH : nullptr;
-  if (DK16) {
-    store_rows16(p.dK + dkbase + (long)kv0w * p.dk_ts + (long)h * p.dk_hs, p.dk_ts, dk16, p.scale, p.scale, ok0, ok1, lane);
-    if (cs_k) colsum_rows16(cs_k, dk16, p.scale, ok0, ok1, lane);
-  } else {
-    if (kvvalid) store_rows(p.dK + dkbase + (long)kv * p.dk_ts + (long)h * p.dk_hs, dk, p.scale, hi);
-    if (cs_k) colsum_rows(cs_k, dk, p.scale, kvvalid, hi, lane);
+  if (kvvalid) {
+    store_rows(p.dK + dkbase + (long)kv * p.dk_ts + (long)h * p.dk_hs, dk, p.scale, hi);
+    store_rows(p.dV + dvbase + (long)kv * p.dv_ts + (long)h * p.dv_hs, dv, 1.f, hi);
   }
-  if (DV16) {
-    store_rows16(p.dV + dvbase + (long)kv0w * p.dv_ts + (long)h * p.dv_hs, p.dv_ts, dv16, 1.f, 1.f, ok0, ok1, lane);
-    if (cs_v) colsum_rows16(cs_v, dv16, 1.f, ok0, ok1, lane);
-  } else {
-    if (kvvalid) store_rows(p.dV + dvbase + (long)kv * p.dv_ts + (long)h * p.dv_hs, dv, 1.f, hi);
-    if (cs_v) colsum_rows(cs_v, dv, 1.f, kvvalid, hi, lane);
-  }
+  if (p.dk_colsum) colsum_rows(p.dk_colsum + (b % PXA_COLSUM_SLOTS) * p.colsum_stride + h * DH, dk, p.scale, kvvalid, hi, lane);
+  if (p.dv_colsum) colsum_rows(p.dv_colsum + (b % PXA_COLSUM_SLOTS) * p.colsum_stride + h * DH, dv, 1.f, kvvalid, hi, lane);
 }
 
 int fill(AttnParams& p, const pxa_attn_args* a) {
