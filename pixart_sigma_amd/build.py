@@ -20,6 +20,10 @@ LIB = os.path.join(HERE, "libpixart_hip.so")
 VARIANTS = {"bf16": ("libpixart_hip.so", []), "f16": ("libpixart_hip_f16.so", ["-DPXA_OPERAND_F16"])}
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
+# Per-source flags.  attn.hip: the SLP vectoriser packs adjacent scalar fp32 multiplies / adds of the softmax into v_pk_* instructions, which cost more
+# issue time beside MFMAs than the scalar forms they replace (MI355X_MICROARCH.md, price of fillers) and re-pair values against the bf16 packing:
+# without it forward -1.3 %, dK/dV -1.9 %, dQ (with delta folded into dP) -3.6 % (profiles/r02n_attn_fold_ab.txt).
+PER_FILE_FLAGS = {"attn.hip": ["-fno-slp-vectorize"]}
 
 
 def _hipcc():
@@ -34,7 +38,7 @@ def _digest(path, extra=()):
     for p in [path, os.path.join(CSRC, "common.h"), os.path.join(INCLUDE, "pixart_hip.h")]:
         with open(p, "rb") as f:
             h.update(f.read())
-    h.update(" ".join([*FLAGS, *extra]).encode())
+    h.update(" ".join([*FLAGS, *PER_FILE_FLAGS.get(os.path.basename(path), []), *extra]).encode())
     return h.hexdigest()[:16]
 
 
@@ -57,7 +61,7 @@ def build(force=False, verbose=False, variants=("bf16", "f16")):
 
     def compile_one(job):
         src, obj, extra = job
-        cmd = [hipcc, *FLAGS, *extra, "-I", INCLUDE, "-c", src, "-o", obj]
+        cmd = [hipcc, *FLAGS, *PER_FILE_FLAGS.get(os.path.basename(src), []), *extra, "-I", INCLUDE, "-c", src, "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
         r = subprocess.run(cmd, capture_output=True, text=True)

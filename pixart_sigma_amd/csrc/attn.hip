@@ -111,12 +111,33 @@ __device__ __forceinline__ void dma_tile(char* lds, const bf16_t* __restrict__ b
                                        (__attribute__((address_space(3))) void*)(lds + (i * 4 + wave) * 1024), 16, 0, 0);
   }
 }
-// one-time pad initialisation of a [64][12-chunk] tile: chunks 9..11 <- 0, optionally element (row, 72) <- 1.0
-__device__ __forceinline__ void init_pads(char* tile, bool ones_col72, int tid) {
+// delta folded into dP (dQ kernel).  dS = P (dP - delta) with dP = dO V^T reduced over the head dimension in 5 steps of 16 = 80 slots, of which 72..79 are
+// zero padding: the lane's dO row (registers) carries delta in slots 72 / 73 (split hi + lo in the operand type: exact to 2^-16 relative in bf16) and the V
+// tiles carry -1.0 there (written once with the pads), so the MFMA returns dP - delta and the 32 subtractions per tile leave the VALU; nothing is added to
+// the matrix work: dQ kernel 1.990 -> 1.916 ms (profiles/r02n_attn_fold_ab.txt).  The dK/dV kernel would have to write delta into the dO tile's pad chunk
+// every tile (its dO rows come by DMA): measured +5 % there, not used.
+// bf16 operands only: delta = rowsum(dO o O) of a loss-scaled fp16 backward can leave the fp16 range (dO itself is kept inside it by the scaler, a sum of
+// 72 products is not), so the fp16-operand build keeps the fp32 subtraction.
+#ifndef ATTN_FOLD_DELTA
+#ifdef PXA_OPERAND_F16
+#define ATTN_FOLD_DELTA 0
+#else
+#define ATTN_FOLD_DELTA 1   // 0 = subtract delta on the VALU (A/B builds)
+#endif
+#endif
+#define PXA_OPERAND_MINUS_ONE_X2 (((PXA_OPERAND_ONE_BITS | 0x8000u) << 16) | PXA_OPERAND_ONE_BITS | 0x8000u)
+__device__ __forceinline__ uint32_t split_hi_lo(float x) {      // {hi, lo} in the operand type with hi + lo ~= x
+  const bf16_t h = (bf16_t)x, l = (bf16_t)(x - (float)h);
+  bf16x2 v; v[0] = h; v[1] = l;
+  return __builtin_bit_cast(uint32_t, v);
+}
+// one-time pad initialisation of a [64][12-chunk] tile: chunks 9..11 <- 0; pad 1: element (row, 72) <- 1.0; pad 2: (row, 72) and (row, 73) <- -1.0
+__device__ __forceinline__ void init_pads(char* tile, int pad, int tid) {
   for (int i = tid; i < BKV * 3; i += 256) {
     const int r = i / 3, c = NCH + (i - r * 3);
     uint4 v = make_uint4(0, 0, 0, 0);
-    if (ones_col72 && c == NCH) v.x = PXA_OPERAND_ONE_BITS;   // 1.0 in the low half = column 72
+    if (pad == 1 && c == NCH) v.x = PXA_OPERAND_ONE_BITS;     // 1.0 in the low half = column 72
+    if (pad == 2 && c == NCH) v.x = PXA_OPERAND_MINUS_ONE_X2; // -1.0 in columns 72 and 73
     *reinterpret_cast<uint4*>(tile + soff(r, c)) = v;
   }
 }
@@ -315,8 +336,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
   frag_addr(fa, lane);
 
   for (int st = 0; st < 2; st++) {
-    init_pads(smem + st * 2 * TILE_B, false, tid);            // K
-    init_pads(smem + st * 2 * TILE_B + TILE_B, true, tid);    // V: column 72 = 1 -> O^T row 72 accumulates sum_kv P = l
+    init_pads(smem + st * 2 * TILE_B, 0, tid);                // K
+    init_pads(smem + st * 2 * TILE_B + TILE_B, 1, tid);       // V: column 72 = 1 -> O^T row 72 accumulates sum_kv P = l
   }
   Acc16 o;
   zero16(o);
@@ -501,8 +522,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd2_kernel(AttnParams p) {
   FragAddr fa;
   frag_addr(fa, lane);
   for (int st = 0; st < 2; st++) {
-    init_pads(smem + st * 2 * TILE_B, false, tid);            // K
-    init_pads(smem + st * 2 * TILE_B + TILE_B, true, tid);    // V: column 72 = 1 -> O^T row 72 accumulates sum_kv P = l
+    init_pads(smem + st * 2 * TILE_B, 0, tid);                // K
+    init_pads(smem + st * 2 * TILE_B + TILE_B, 1, tid);       // V: column 72 = 1 -> O^T row 72 accumulates sum_kv P = l
   }
   Acc16 o[QS];
   Tr16Addr ta;
@@ -641,12 +662,18 @@ __global__ __launch_bounds__(256, ATTN_BWD_WAVES) void attn_bwd_dq_kernel(AttnPa
   const long sidx = ((long)b * p.H + h) * p.Nq + q;
   const float lse = qvalid ? p.LSE[sidx] : 0.f;
   const float delta = qvalid ? p.Delta[sidx] : 0.f;
+  if (ATTN_FOLD_DELTA && hi == 1) {                             // slots 72 / 73 of this lane's dO row (k-step 4, upper half: d = 72 .. 79)
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    u32x4 w = __builtin_bit_cast(u32x4, dof[KSTEPS - 1]);
+    w[0] = split_hi_lo(delta);
+    dof[KSTEPS - 1] = __builtin_bit_cast(bf16x8, w);
+  }
   DmaPlan pl;
   dma_plan(pl, wave, lane);
   FragAddr fa;
   frag_addr(fa, lane);
 
-  for (int st = 0; st < 4; st++) init_pads(smem + st * TILE_B, false, tid);
+  for (int st = 0; st < 4; st++) init_pads(smem + st * TILE_B, (ATTN_FOLD_DELTA && (st & 1)) ? 2 : 0, tid);   // odd tiles = V: -1.0 in slots 72 / 73
   Acc16 dq;
   zero16(dq);
   Tr16Addr ta;
@@ -671,7 +698,7 @@ __global__ __launch_bounds__(256, ATTN_BWD_WAVES) void attn_bwd_dq_kernel(AttnPa
       for (int g = 0; g < 16; g++) {
         float pr = __builtin_amdgcn_exp2f(s[sub][g] * c - lse);
         if (TAIL && kv0 + sub * 32 + (g & 3) + 8 * (g >> 2) + 4 * hi >= kvlen) pr = 0.f;
-        s[sub][g] = pr * (dp[sub][g] - delta);  // dS^T (without the softmax scale, applied at the end)
+        s[sub][g] = ATTN_FOLD_DELTA ? pr * dp[sub][g] : pr * (dp[sub][g] - delta);  // dS^T (without the softmax scale, applied at the end)
       }
 #pragma unroll
     for (int sub = 0; sub < 2; sub++) {
@@ -738,7 +765,7 @@ __global__ __launch_bounds__(256, ATTN_BWD_WAVES) void attn_bwd_dkv_kernel(AttnP
   FragAddr fa;
   frag_addr(fa, lane);
 
-  for (int st = 0; st < 4; st++) init_pads(smem + st * TILE_B, false, tid);
+  for (int st = 0; st < 4; st++) init_pads(smem + st * TILE_B, 0, tid);
   f32x16 dk[3], dv[3];
   zero3(dk);
   zero3(dv);

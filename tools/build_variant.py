@@ -15,7 +15,7 @@ for s in sorted(f for f in os.listdir(B.CSRC) if f.endswith(".hip")):
     path = os.path.join(B.CSRC, s)
     if s == os.path.basename(src):
         obj = os.path.join(out_dir, f"{s[:-4]}.{name}.o")
-        subprocess.run([B._hipcc(), *B.FLAGS, *flags, "-I", B.INCLUDE, "-c", path, "-o", obj], check=True)
+        subprocess.run([B._hipcc(), *B.FLAGS, *B.PER_FILE_FLAGS.get(s, []), *flags, "-I", B.INCLUDE, "-c", path, "-o", obj], check=True)
     else:
         obj = os.path.join(B.OBJ, f"{s[:-4]}.bf16.{B._digest(path, [])}.o")
     objs.append(obj)
