@@ -20,6 +20,8 @@ import os
 import sys
 import time
 
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # RCCL across processes needs dmabuf IPC on this driver; must be set before the HIP runtime starts
+
 import torch
 import torch.distributed as dist
 
