@@ -17,6 +17,8 @@ import runpy
 import sys
 import time
 
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # RCCL across processes needs dmabuf IPC on this driver; set before the HIP runtime starts
+
 import numpy as np
 import torch
 import torch.distributed as dist
