@@ -129,3 +129,24 @@ def test_tr16_reads_are_bank_conflict_free():
                     a = tr16_addr(l)[e][t & 1] + (t >> 1) * 64
                     banks += [(a // 4) % 64, (a // 4 + 1) % 64]
                 assert sorted(banks) == list(range(64)), (t, e, grp)
+
+
+def block_coords(blk, T, nx, H):    # attn.hip block_coords(): flat workgroup index -> (row block, head, batch)
+    xq, xr, xcd = T >> 3, T & 7, blk & 7
+    v = xcd * xq + min(xcd, xr) + (blk >> 3)
+    return v % nx, (v // nx) % H, v // nx // H
+
+
+def test_block_order_is_a_bijection_and_keeps_heads_on_one_xcd():
+    for nx, H, B in [(32, 16, 16), (16, 16, 16), (3, 16, 16), (2, 3, 2), (1, 3, 2), (1, 2, 1), (64, 16, 4), (5, 7, 3)]:
+        T = nx * H * B
+        seen = {}
+        for blk in range(T):
+            c = block_coords(blk, T, nx, H)
+            assert c not in seen and c[0] < nx and c[1] < H and c[2] < B
+            seen[c] = blk & 7                       # the XCD the block runs on (workgroup i -> XCD i % 8)
+        assert len(seen) == T
+        if T % 8 == 0 and (T // 8) % nx == 0:       # whole heads per XCD: every block of a (batch, head) on the same XCD
+            for h in range(H):
+                for b in range(B):
+                    assert len({seen[(x, h, b)] for x in range(nx)}) == 1
