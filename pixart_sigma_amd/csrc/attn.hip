@@ -7,11 +7,14 @@
 // Structure ("swapped QK^T"): a wave owns 32 query columns. S^T = K Q^T is computed with
 // v_mfma_f32_32x32x16_bf16 (A = K rows from LDS, B = Q^T held in registers), so every lane holds scores of ONE
 // query -> softmax max/sum are in-lane plus a single lane^32 exchange, and P^T in accumulator layout is
-// directly the B operand of O^T = V^T P^T (the reduction index kv is permuted identically on both operands).
+// the B operand of the second product O^T = V^T P^T: directly in the 32-row form (the reduction index kv is permuted
+// identically on both operands; dK/dV kernel), after 4 v_permlane16_swap per 32 x 32 block in the 16-row form
+// (v_mfma_f32_16x16x32: forward and dQ kernels, see "second products on 16x16x32 MFMAs" below).
 // V^T fragments come from a row-major [kv][d] LDS tile through ds_read_b64_tr_b16.
-// head_dim 72 is zero-padded to 80 for the QK^T reduction (5 k-steps) and to 96 for the O^T rows (3 tiles).
+// head_dim 72 is zero-padded to 80 for the QK^T reduction (5 k-steps of 16) and, as OUTPUT rows, to 80 (5 tiles of 16;
+// forward, dQ) or 96 (3 tiles of 32; dK/dV).
 // Backward = delta pre-pass + dQ kernel (q-stationary) + dK/dV kernel (kv-stationary), both recomputing P
-// from the saved log2-sum-exp.
+// from the saved log2-sum-exp.  Grids are flat and keep the blocks of a head on one XCD (block_coords).
 #include "common.h"
 #include "../../include/pixart_hip.h"
 
