@@ -240,13 +240,11 @@ template <bool B> struct BoolC { static constexpr bool value = B; };
 // Result.  Lane (R, c) holds X^T[16 t + 4 R + g][column], g = 0..3, for columns c (from X) and 16 + c (from Y): 8 contiguous bytes of
 // two output rows per tile.
 struct Tr16Addr { int tb[2][2]; };   // [read e][tile parity]: the swizzle XOR acts on chunk bits 0-1 and a 16-wide tile starts at chunk 2 t
-// alt: lane rows 2 / 3 exchange their row quads (rows 12-15 / 4-7 instead of 4-7 / 12-15): the k order of attn_bwd_dkv16_kernel, see there
-__device__ __forceinline__ void tr16_addr(Tr16Addr& ta, int lane, bool alt = false) {
+__device__ __forceinline__ void tr16_addr(Tr16Addr& ta, int lane) {
   const int gg = lane >> 4, tt = lane & 15, x = (tt & 3) >> 1;
-  const int quad = (2 * (gg & 1) + (gg >> 1)) ^ (alt ? 2 * (gg >> 1) : 0);
 #pragma unroll
   for (int e = 0; e < 2; e++) {
-    const int row = 4 * quad + (tt >> 2) + 16 * e, sw = (row >> 2) & 3;
+    const int row = 8 * (gg & 1) + 4 * (gg >> 1) + (tt >> 2) + 16 * e, sw = (row >> 2) & 3;
 #pragma unroll
     for (int par = 0; par < 2; par++) ta.tb[e][par] = row * ROWB + (((2 * par + x) ^ sw) << 4) + (tt & 1) * 8;
   }
@@ -863,152 +861,6 @@ __global__ __launch_bounds__(256, ATTN_BWD_WAVES) void attn_bwd_dkv_kernel(AttnP
   if (p.dv_colsum) colsum_rows(p.dv_colsum + (b % PXA_COLSUM_SLOTS) * p.colsum_stride + h * DH, dv, 1.f, kvvalid, hi, lane);
 }
 
-// ------------------------------------------------------------------------------------------------ backward: dK, dV, every product on 16 x 16 x 32 (experimental)
-// Not the product kernel: selected with PXA_ATTN_DKV16=1, unmeasured at the end of round 2 (the GPU budget was spent).  Idea: with the FIRST products in
-// 16-row tiles too, S and dP leave the MFMA as [16 q][16 kv] tiles whose lane (R, c) holds rows 4 R + g of column c - with two q tiles that is exactly
-// chunk R of the second product's K = 32 reduction, so P and dS feed it without any lane exchange, and all 88 MFMAs per 64-query tile are in the shape the
-// power limit favours (common.h).  Cost: the head-dimension reduction pads to 96 instead of 80 (48 instead of 40 half-size MFMAs for S and dP), paid back
-// by the second products (40 instead of 48); 72 LDS reads per tile instead of 84.  Risk: 16-cycle MFMAs leave the SIMD's other
-// wave fewer issue slots for its softmax.  The MFMA's row index i = 4 R + g of a q tile is mapped to tile row 4 quad(R) + g with quad = (0, 2, 3, 1): lane row
-// R then owns four consecutive tile rows (one [4][16] block of the second product's transpose reads, tr16_addr(alt)), the two halves of a transpose-read
-// group are 8 rows apart, and the first products' ds_read_b128 groups hit 16 distinct slots under the tile's XOR swizzle (the order (0, 2, 1, 3) of the
-// forward / dQ kernels would 2-way conflict there) - index chain and bank sets emulated in tests/test_attn_pv16_layout.py.
-constexpr int KS32 = 3;              // ceil(72 / 32) reduction steps of the first products
-__device__ __forceinline__ int quad16(int R) { return (2 * (R & 1) + (R >> 1)) ^ (2 * (R >> 1)); }   // (0, 2, 3, 1)
-__device__ __forceinline__ int row16_addr(int lane) {      // per-lane byte offset of tile row 4 quad(i >> 2) + (i & 3), i = l & 15, chunk (l >> 4) ^ swizzle
-  const int i = lane & 15, q4 = lane >> 4;
-  const int rq = 4 * quad16(i >> 2) + (i & 3);
-  return rq * ROWB + ((q4 ^ ((rq >> 2) & 3)) << 4);
-}
-__device__ __forceinline__ bf16x8 rowfrag16(const char* lds, int rb, int sub, int qt, int ks) {   // rows 32 sub + 16 qt + qmap(.), d = 32 ks + 8 (l >> 4) ..
-  return *reinterpret_cast<const bf16x8*>(lds + rb + (sub * 32 + qt * 16) * ROWB + ks * 64);
-}
-__device__ __forceinline__ void load_row_frags16(bf16x8 (&f)[KS32], const bf16_t* __restrict__ rowptr, bool valid, int q4) {
-#pragma unroll
-  for (int ks = 0; ks < KS32; ks++) {
-    const int d0 = ks * 32 + 8 * q4;
-    uint4 v = make_uint4(0, 0, 0, 0);
-    if (valid && d0 < DH) v = *reinterpret_cast<const uint4*>(rowptr + d0);
-    f[ks] = __builtin_bit_cast(bf16x8, v);
-  }
-}
-__device__ __forceinline__ bf16x8 pack44(const f32x4& a, const f32x4& b) {
-  bf16x8 r;
-#pragma unroll
-  for (int j = 0; j < 4; j++) { r[j] = (bf16_t)a[j]; r[4 + j] = (bf16_t)b[j]; }
-  return r;
-}
-__global__ __launch_bounds__(256, ATTN_BWD_WAVES) void attn_bwd_dkv16_kernel(AttnParams p) {
-  __shared__ __attribute__((aligned(16))) char smem[4 * TILE_B + 4 * BKV * 4];   // 2 stages x {Q, dO} + 2 stages x {lse, delta}
-  float* ldsL = reinterpret_cast<float*>(smem + 4 * TILE_B);                      // [2][2][64]
-  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), R4 = lane >> 4, c16 = lane & 15;
-  int bx, h, b;
-  block_coords(p, bx, h, b);
-  long kbase, vbase, dkbase, dvbase; int kvlen;
-  kv_range(p, b, kbase, vbase, dkbase, dvbase, kvlen);
-  if (bx * 128 >= kvlen) return;
-  const int kv0w = bx * 128 + wave * 32;
-  const bool wave_active = kv0w < kvlen;
-  const bool ok0 = kv0w + c16 < kvlen, ok1 = kv0w + 16 + c16 < kvlen;
-
-  bf16x8 kf[2][KS32], vf[2][KS32];     // B operands: this lane's key 16 kt + c16, d = 32 ks + 8 R4 ..
-#pragma unroll
-  for (int kt = 0; kt < 2; kt++) {
-    const long kvr = kv0w + 16 * kt + c16;
-    load_row_frags16(kf[kt], p.K + kbase + kvr * p.k_ts + (long)h * p.k_hs, kt ? ok1 : ok0, R4);
-    load_row_frags16(vf[kt], p.V + vbase + kvr * p.v_ts + (long)h * p.v_hs, kt ? ok1 : ok0, R4);
-  }
-  const bf16_t* Qp = p.Q + (long)b * p.q_bs + (long)h * p.q_hs;
-  const bf16_t* Dp = p.dO + (long)b * p.o_bs + (long)h * p.o_hs;
-  const float* Lp = p.LSE + ((long)b * p.H + h) * p.Nq;
-  const float* Dl = p.Delta + ((long)b * p.H + h) * p.Nq;
-  const int qts = (int)p.q_ts, ots = (int)p.o_ts;
-  DmaPlan pl;
-  dma_plan(pl, wave, lane);
-  Tr16Addr ta;
-  tr16_addr(ta, lane, true);
-  const int rb = row16_addr(lane);
-  const int qoff = 4 * quad16(R4);                      // first of this lane's 4 rows of a q tile
-
-  for (int st = 0; st < 4; st++) init_pads(smem + st * TILE_B, 0, tid);
-  Acc16 dk, dv;
-  zero16(dk);
-  zero16(dv);
-  const float c = p.scale_log2;
-  const int T = (p.Nq + BKV - 1) / BKV;
-  float rl = INFINITY, rdl = 0.f;
-  auto fetch_stats = [&](int q0) {
-    if (tid < BKV) {
-      const bool ok = q0 + tid < p.Nq;
-      rl = ok ? Lp[q0 + tid] : INFINITY;    // +inf -> P = exp2(-inf) = 0 for rows beyond Nq
-      rdl = ok ? Dl[q0 + tid] : 0.f;
-    }
-  };
-  const int Tfull = p.Nq / BKV;
-  auto issue = [&](int t) {
-    char* nx = smem + (t & 1) * 2 * TILE_B;
-    if (t < Tfull) {
-      dma_tile<true>(nx, Qp, qts, t * BKV, p.Nq, pl, wave);
-      dma_tile<true>(nx + TILE_B, Dp, ots, t * BKV, p.Nq, pl, wave);
-    } else {
-      dma_tile<false>(nx, Qp, qts, t * BKV, p.Nq, pl, wave);
-      dma_tile<false>(nx + TILE_B, Dp, ots, t * BKV, p.Nq, pl, wave);
-    }
-    fetch_stats(t * BKV);
-  };
-  issue(0);
-  for (int t = 0; t < T; t++) {
-    const char* sQ = smem + (t & 1) * 2 * TILE_B;
-    const char* sD = sQ + TILE_B;
-    float* sL = ldsL + (t & 1) * 2 * BKV;
-    if (tid < BKV) { sL[tid] = rl; sL[BKV + tid] = rdl; }
-    __syncthreads();
-    if (t + 1 < T) issue(t + 1);
-    if (!wave_active) continue;
-#pragma unroll
-    for (int sub = 0; sub < 2; sub++) {
-      f32x4 s[2][2], dp[2][2];          // [q tile][key tile]
-#pragma unroll
-      for (int qt = 0; qt < 2; qt++)
-#pragma unroll
-        for (int kt = 0; kt < 2; kt++) { s[qt][kt] = f32x4{0.f, 0.f, 0.f, 0.f}; dp[qt][kt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-#pragma unroll
-      for (int ks = 0; ks < KS32; ks++)
-#pragma unroll
-        for (int qt = 0; qt < 2; qt++) {
-          const bf16x8 qa = rowfrag16(sQ, rb, sub, qt, ks), da = rowfrag16(sD, rb, sub, qt, ks);
-#pragma unroll
-          for (int kt = 0; kt < 2; kt++) {
-            s[qt][kt] = mfma16(qa, kf[kt][ks], s[qt][kt]);     // S[q][kv]: rows = q (4 R4 + g -> tile row qoff + g), column = key 16 kt + c16
-            dp[qt][kt] = mfma16(da, vf[kt][ks], dp[qt][kt]);   // dP[q][kv]
-          }
-        }
-#pragma unroll
-      for (int qt = 0; qt < 2; qt++) {
-        const int ql = sub * 32 + qt * 16 + qoff;
-        const float4 L4 = *reinterpret_cast<const float4*>(&sL[ql]);
-        const float4 D4 = *reinterpret_cast<const float4*>(&sL[BKV + ql]);
-        const float Lv[4] = {L4.x, L4.y, L4.z, L4.w}, Dv[4] = {D4.x, D4.y, D4.z, D4.w};
-#pragma unroll
-        for (int kt = 0; kt < 2; kt++)
-#pragma unroll
-          for (int g = 0; g < 4; g++) {
-            const float pr = __builtin_amdgcn_exp2f(s[qt][kt][g] * c - Lv[g]);
-            s[qt][kt][g] = pr;
-            dp[qt][kt][g] = pr * (dp[qt][kt][g] - Dv[g]);
-          }
-      }
-      // lane (R4, c16) holds rows qoff + g (q tile 0) and 16 + qoff + g (q tile 1) of column c16: chunk R4 of the second products' K = 32
-      mma16(dv, sD, ta, sub, pack44(s[0][0], s[1][0]), pack44(s[0][1], s[1][1]));       // dV^T[d][kv] += dO^T[d][q] P[q][kv]
-      mma16(dk, sQ, ta, sub, pack44(dp[0][0], dp[1][0]), pack44(dp[0][1], dp[1][1]));   // dK^T[d][kv] += Q^T[d][q] dS[q][kv]
-    }
-  }
-  store_rows16(p.dK + dkbase + (long)kv0w * p.dk_ts + (long)h * p.dk_hs, p.dk_ts, dk, p.scale, p.scale, ok0, ok1, lane);
-  store_rows16(p.dV + dvbase + (long)kv0w * p.dv_ts + (long)h * p.dv_hs, p.dv_ts, dv, 1.f, 1.f, ok0, ok1, lane);
-  if (p.dk_colsum) colsum_rows16(p.dk_colsum + (b % PXA_COLSUM_SLOTS) * p.colsum_stride + h * DH, dk, p.scale, ok0, ok1, lane);
-  if (p.dv_colsum) colsum_rows16(p.dv_colsum + (b % PXA_COLSUM_SLOTS) * p.colsum_stride + h * DH, dv, 1.f, ok0, ok1, lane);
-}
-
 int fill(AttnParams& p, const pxa_attn_args* a) {
   PXA_CHECK(a, "attn: null args");
   PXA_CHECK(a->head_dim == DH, "attn: head_dim %d unsupported (PixArt XL/2 uses 72)", a->head_dim);
@@ -1074,9 +926,7 @@ extern "C" int pxa_attn_bwd(const pxa_attn_args* a, hipStream_t stream) {
     const int max_k = a->max_kv_len > 0 ? a->max_kv_len : p.Nk;
     p.nx = (max_k + 127) / 128;
     PXA_CHECK((long)p.nx * p.H * p.B < (1L << 31), "pxa_attn_bwd: grid too large");
-    static const bool all16 = getenv("PXA_ATTN_DKV16") != nullptr;   // experimental kernel, see attn_bwd_dkv16_kernel
-    if (p.nx > 0 && all16) hipLaunchKernelGGL(attn_bwd_dkv16_kernel, dim3(p.nx * p.H * p.B), dim3(256), 0, stream, p);
-    else if (p.nx > 0) hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3(p.nx * p.H * p.B), dim3(256), 0, stream, p);
+    if (p.nx > 0) hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3(p.nx * p.H * p.B), dim3(256), 0, stream, p);
     PXA_LAUNCH_CHECK();
   }
   return 0;

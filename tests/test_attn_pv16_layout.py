@@ -34,23 +34,22 @@ def tr_read(img, addr):            # addr[64] byte addresses -> [64][4]
     return out
 
 
-def tr16_addr(lane, alt=False):    # attn.hip tr16_addr(): tb[e][par]
+def tr16_addr(lane):               # attn.hip tr16_addr(): tb[e][par]
     gg, tt = lane >> 4, lane & 15
     x = (tt & 3) >> 1
-    quad = (2 * (gg & 1) + (gg >> 1)) ^ (2 * (gg >> 1) if alt else 0)
     tb = [[0, 0], [0, 0]]
     for e in range(2):
-        row = 4 * quad + (tt >> 2) + 16 * e
+        row = 8 * (gg & 1) + 4 * (gg >> 1) + (tt >> 2) + 16 * e
         sw = (row >> 2) & 3
         for par in range(2):
             tb[e][par] = row * ROWB + (((2 * par + x) ^ sw) << 4) + (tt & 1) * 8
     return tb
 
 
-def trfrag16(img, t, sub, alt=False):   # -> [64 lanes][8]
+def trfrag16(img, t, sub):         # -> [64 lanes][8]
     off = sub * 32 * ROWB + (t >> 1) * 64
-    a0 = [tr16_addr(l, alt)[0][t & 1] + off for l in range(64)]
-    a1 = [tr16_addr(l, alt)[1][t & 1] + off for l in range(64)]
+    a0 = [tr16_addr(l)[0][t & 1] + off for l in range(64)]
+    a1 = [tr16_addr(l)[1][t & 1] + off for l in range(64)]
     return np.concatenate([tr_read(img, a0), tr_read(img, a1)], axis=1)
 
 
@@ -126,12 +125,10 @@ def test_tr16_reads_are_bank_conflict_free():
         for e in range(2):
             for grp in range(2):
                 banks = []
-                for alt in (False, True):
-                    banks = []
-                    for l in range(32 * grp, 32 * grp + 32):
-                        a = tr16_addr(l, alt)[e][t & 1] + (t >> 1) * 64
-                        banks += [(a // 4) % 64, (a // 4 + 1) % 64]
-                    assert sorted(banks) == list(range(64)), (t, e, grp, alt)
+                for l in range(32 * grp, 32 * grp + 32):
+                    a = tr16_addr(l)[e][t & 1] + (t >> 1) * 64
+                    banks += [(a // 4) % 64, (a // 4 + 1) % 64]
+                assert sorted(banks) == list(range(64)), (t, e, grp)
 
 
 def block_coords(blk, T, nx, H):    # attn.hip block_coords(): flat workgroup index -> (row block, head, batch)
@@ -153,73 +150,3 @@ def test_block_order_is_a_bijection_and_keeps_heads_on_one_xcd():
             for h in range(H):
                 for b in range(B):
                     assert len({seen[(x, h, b)] for x in range(nx)}) == 1
-
-
-# ---- the experimental dK/dV kernel with every product on 16 x 16 x 32 (attn_bwd_dkv16_kernel): first products + hand-over to the second
-def qmap(i):                        # MFMA row index of a q tile -> tile row: lane row R = i >> 2 owns row quad (0, 2, 3, 1)[R]
-    R = i >> 2
-    return 4 * ((2 * (R & 1) + (R >> 1)) ^ (2 * (R >> 1))) + (i & 3)
-
-
-def row16_addr(lane):               # attn.hip row16_addr()
-    i, q4 = lane & 15, lane >> 4
-    rq = qmap(i)
-    return rq * ROWB + ((q4 ^ ((rq >> 2) & 3)) << 4)
-
-
-def rowfrag16(img, sub, qt, ks):    # -> [64 lanes][8]
-    out = np.zeros((64, 8))
-    for l in range(64):
-        a = row16_addr(l) + (sub * 32 + qt * 16) * ROWB + ks * 64
-        out[l] = img[(a >> 1):(a >> 1) + 8]
-    return out
-
-
-def test_all16_dkv_kernel_layout():
-    rng = np.random.default_rng(1)
-    Q = rng.standard_normal((64, DH))                  # the q tile (rows = queries) feeding S = Q K^T
-    X = rng.standard_normal((64, DH))                  # the tile whose transpose feeds the second product (dO for dV, Q for dK)
-    K = rng.standard_normal((32, DH))                  # this wave's 32 keys
-    imgQ, imgX = build_tile(Q), build_tile(X)
-    Kp = np.zeros((32, 96)); Kp[:, :DH] = K
-    acc = np.zeros((5, 2, 64, 4))
-    for sub in range(2):
-        S = np.zeros((2, 2, 64, 4))                    # [q tile][key tile][lane][g]
-        for ks in range(3):
-            for qt in range(2):
-                qa = rowfrag16(imgQ, sub, qt, ks)
-                for kt in range(2):
-                    kf = np.array([Kp[16 * kt + (l & 15), 32 * ks + 8 * (l >> 4):32 * ks + 8 * (l >> 4) + 8] for l in range(64)])
-                    S[qt, kt] = mfma16(qa, kf, S[qt, kt])
-        for qt in range(2):                            # S[q][kv]: lane (R, c), g -> q = 32 sub + 16 qt + qmap(4 R + g), kv = 16 kt + c
-            for kt in range(2):
-                for l in range(64):
-                    for g in range(4):
-                        q = 32 * sub + 16 * qt + qmap(4 * (l >> 4) + g)
-                        assert abs(S[qt, kt, l, g] - Q[q] @ K[16 * kt + (l & 15)]) < 1e-10
-        # no lane exchange: {S[0][kt], S[1][kt]} is operand B of the second product for key tile kt
-        px = np.concatenate([S[0, 0], S[1, 0]], axis=1)
-        py = np.concatenate([S[0, 1], S[1, 1]], axis=1)
-        for t in range(5):
-            af = trfrag16(imgX, t, sub, alt=True)
-            acc[t, 0] = mfma16(af, px, acc[t, 0])
-            acc[t, 1] = mfma16(af, py, acc[t, 1])
-    out = np.zeros((32, 80))                           # store_rows16 mapping: out[key][d]
-    for t in range(5):
-        for half in range(2):
-            for l in range(64):
-                for g in range(4):
-                    out[(l & 15) + 16 * half, 16 * t + 4 * (l >> 4) + g] = acc[t, half, l, g]
-    ref = (Q @ K.T).T @ X                              # Z[kv][d] = sum_q S[q][kv] X[q][d]
-    assert np.allclose(out[:, :DH], ref, atol=1e-9)
-
-
-def test_all16_row_fragment_reads_are_bank_conflict_free():
-    groups = [list(range(0, 4)) + list(range(12, 16)) + list(range(20, 28)), list(range(4, 12)) + list(range(16, 20)) + list(range(28, 32)),
-              list(range(32, 36)) + list(range(44, 48)) + list(range(52, 60)), list(range(36, 44)) + list(range(48, 52)) + list(range(60, 64))]
-    for sub in range(2):
-        for qt in range(2):
-            for ks in range(3):
-                for grp in groups:                     # ds_read_b128: 16 distinct 16-byte slots mod 256 B per lane group
-                    slots = [((row16_addr(l) + (sub * 32 + qt * 16) * ROWB + ks * 64) // 16) % 16 for l in grp]
-                    assert len(set(slots)) == 16, (sub, qt, ks, slots)
