@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define PXA_ABI_VERSION 4
+#define PXA_ABI_VERSION 5
 /* Kernels that fuse a bias-gradient column sum add into one of PXA_COLSUM_SLOTS partial rows ([slot][stride] fp32, caller-zeroed),
  * chosen per sample / row tile, so no address sees thousands of atomics; pxa_colsum_reduce folds the partials into the gradient. */
 #define PXA_COLSUM_SLOTS 16
@@ -140,10 +140,13 @@ typedef struct {
   float scale;
   float* dq_colsum; float* dk_colsum; float* dv_colsum;  /* optional (bwd) slotted partials: += column sums of dq / dk / dv (bias gradients) */
   long colsum_stride;
+  void* bwd_stats;   /* optional (bwd) workspace of pxa_attn_bwd_stats_bytes(B, H, Nq) bytes, 16-byte aligned: lse / delta as operand-type rows, which the
+                        dK/dV kernel takes through its matrix products (round 3).  NULL: the round-2 dK/dV kernel runs. */
 } pxa_attn_args;
 int pxa_attn_fwd(const pxa_attn_args* args, hipStream_t stream);
 /* backward: delta pre-pass, then the dQ kernel (skipped when dq == NULL) and the dK/dV kernel (skipped when dk == dv == NULL) */
 int pxa_attn_bwd(const pxa_attn_args* args, hipStream_t stream);
+long pxa_attn_bwd_stats_bytes(int B, int H, int Nq);
 
 /* ---------------------------------------------------------------------------------------------- token boundary
  * PatchEmbed conv (k=2,s=2) + bias + pos_embed -> fp32 tokens (PixArtMS.py:38-44,184); its weight/bias gradient;

@@ -56,6 +56,18 @@ CASES = {
     "cfg_d2": (dict(depth=2, input_size=16, model_max_length=20), dict(B=4, Hl=16, Wl=16, L=20, lens=[20, 9, 20, 20])),
     # BASELINE.json configs[0]: XL/2 256px, batch 2, 2 DPM-Solver steps, CFG 4.5, random-init, CPU
     "cfg1_xl2_256": (dict(depth=28, input_size=32, model_max_length=300, pe_interpolation=0.5), dict(B=2, Hl=32, Wl=32, L=300, lens=[300, 77])),
+    # ---- round 3: the model bench.py times, FULL DEPTH at the headline geometry (PixArtMS_XL_2, depth 28, PixArtMS.py:291-293; 1024px: N = 4096,
+    # L = 300, pe_interpolation 2: configs/pixart_sigma_config/PixArt_sigma_xl2_img1024_internalms.py).  Batch 1 keeps the CPU run to minutes.
+    "fwd_xl2_1024_b1": (dict(depth=28, input_size=128, model_max_length=300, pe_interpolation=2.0), dict(B=1, Hl=128, Wl=128, L=300, lens=[213])),
+    "train_xl2_1024_b1": (dict(depth=28, input_size=128, model_max_length=300, pe_interpolation=2.0), dict(B=1, Hl=128, Wl=128, L=300, lens=[187])),
+    # 'uniform_every' KV sampling (every scale_factor-th token of the flattened sequence, PixArt_blocks.py:82,102): forward and a training step
+    "fwd_d2_kvevery": (dict(depth=2, input_size=16, model_max_length=20, kv_sampling="uniform_every", kv_scale_factor=2, kv_layers=(0, 1)),
+                       dict(B=2, Hl=16, Wl=24, L=20, lens=[20, 11])),
+    "train_d2_kvevery": (dict(depth=2, input_size=16, model_max_length=20, kv_sampling="uniform_every", kv_scale_factor=4, kv_layers=(1,)),
+                         dict(B=2, Hl=16, Wl=16, L=20, lens=[20, 9])),
+    # full-depth 2K with the shipped KV-compression layout (conv x2 on blocks 14..27: PixArt_sigma_xl2_img2K_internalms_kvcompress.py:44-49)
+    "fwd_xl2_2k_kv_b1": (dict(depth=28, input_size=256, model_max_length=300, pe_interpolation=4.0, kv_sampling="conv", kv_scale_factor=2,
+                              kv_layers=tuple(range(14, 28))), dict(B=1, Hl=256, Wl=256, L=300, lens=[300])),
 }
 
 
@@ -102,19 +114,21 @@ def gen_case(name):
         m.train()
         diff = IDDPM(str(1000), learn_sigma=True, pred_sigma=True, snr=False)
         t = inp["t"].clone()
-        t[0] = 0  # exercise the decoder-NLL branch (gaussian_diffusion.py:741)
+        if t.numel() > 1:
+            t[0] = 0  # exercise the decoder-NLL branch (gaussian_diffusion.py:741)
         terms = diff.training_losses(m, inp["x"], t, model_kwargs=dict(y=inp["y"], mask=mask[:, None, None, :], data_info=data_info), noise=inp["noise"])
         loss = terms["loss"].mean()
         loss.backward()
         out.update(t=t, loss=terms["loss"].detach().clone(), mse=terms["mse"].detach().clone(), vb=terms["vb"].detach().clone())
         grads = {}
+        full_max, nsample = (8192, 4096) if cfg.depth <= 2 else (1152, 1024)   # full depth: 28 x the tensors, keep the fixture small
         for k, p in m.named_parameters():
             g = p.grad
             grads[k] = {"norm": g.norm().item(), "head": g.flatten()[:16].clone(), "sum": g.double().sum().item()}
-            if g.numel() > 8192:           # evenly strided sample of the big tensors (every row / column region is hit)
-                grads[k]["stride"] = g.numel() // 4096
-                grads[k]["sample"] = g.flatten()[:: g.numel() // 4096].clone()
-            if g.numel() <= 8192:
+            if g.numel() > full_max:       # evenly strided sample of the big tensors (every row / column region is hit)
+                grads[k]["stride"] = g.numel() // nsample
+                grads[k]["sample"] = g.flatten()[:: g.numel() // nsample].clone()
+            if g.numel() <= full_max:
                 grads[k]["full"] = g.clone()
         out["grads"] = grads
     elif name.startswith("dpms") or name.startswith("cfg1"):

@@ -17,6 +17,7 @@
 // from the saved log2-sum-exp.  Grids are flat and keep the blocks of a head on one XCD (block_coords).
 #include "common.h"
 #include "../../include/pixart_hip.h"
+#include <utility>
 
 namespace {
 using namespace pxa;
@@ -56,6 +57,8 @@ struct AttnParams {
   const int* kv_start; const int* kv_len;  // optional per-batch varlen (rows into the packed K/V)
   float scale, scale_log2;
   int nx;              // blocks per (batch, head) of the launch: the grid is the flat nx * H * B, see block_coords()
+  const bf16_t* stats; // dK/dV kernel, round 3: [2][B][H][Nq64] rows of 8 operands {hi, lo, 0 x 6}: lse / scale_log2 and delta, see "stats rows"
+  int Nq64;            // Nq rounded up to the 64-query tile
 };
 
 // Block -> (row block, head, batch).  Every block of one (batch, head) streams the same rows (K / V in the forward and dQ kernels,
@@ -220,6 +223,7 @@ __device__ __forceinline__ void zero3(f32x16 (&a)[3]) {
     for (int g = 0; g < 16; g++) a[i][g] = 0.f;
 }
 template <bool B> struct BoolC { static constexpr bool value = B; };
+template <int I> struct IntC { static constexpr int value = I; };
 
 // ------------------------------------------------------------------------------------------------ second products on 16x16x32 MFMAs
 // O^T = V^T P^T, dQ^T = K^T dS^T, dV^T = dO^T P, dK^T = Q^T dS: the products whose OUTPUT rows are the head dimension.  With 32-row tiles
@@ -432,8 +436,31 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
 }
 
 // ------------------------------------------------------------------------------------------------ delta = rowsum(dO * O)
+// "stats rows" (round 3).  The dK/dV kernel needs lse and delta of every QUERY of a tile, i.e. along its accumulator rows - 16 LDS reads, 32 subtractions
+// and a staging write per tile when they are applied on the VALU.  Instead the pre-pass also writes them as 16-byte rows of the operand type,
+//   Lrow[b][h][q] = {hi, lo, 0 x 6} with hi + lo = lse / scale_log2,        Drow[b][h][q] = {hi, lo, 0 x 6} with hi + lo = delta,
+// the dK/dV kernel brings 64 of each per tile into LDS with ONE 1 KiB LDS-DMA instruction, and its lanes read them as the k-slots 72..79 of the Q / dO
+// operand (the zero padding of head_dim 72 -> 80) against -1.0 in the K / V registers: the first products return S - lse / c and dP - delta.
+// hi + lo carries 16 (bf16) / 22 (fp16) mantissa bits.  Rows [Nq, Nq64) hold a huge finite lse (P = 0 for queries that do not exist) and delta 0.
+#ifdef PXA_OPERAND_F16
+#define PXA_STAT_SENTINEL 60000.0f   // fits fp16; exp2(c (S - 6e4)) underflows to 0 for every scale this model uses (c = 0.17)
+#else
+#define PXA_STAT_SENTINEL 1.0e30f
+#endif
+__device__ __forceinline__ void write_stat_rows(bf16_t* __restrict__ stats, long rows_total, long row, float l_over_c, float dl) {
+  if (!stats) return;
+  *reinterpret_cast<uint4*>(stats + row * 8) = make_uint4(split_hi_lo(l_over_c), 0, 0, 0);
+  *reinterpret_cast<uint4*>(stats + (rows_total + row) * 8) = make_uint4(split_hi_lo(dl), 0, 0, 0);
+}
+__global__ __launch_bounds__(256) void attn_stats_pad_kernel(bf16_t* __restrict__ stats, int BH, int Nq, int Nq64) {
+  const int pad = Nq64 - Nq, idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= BH * pad) return;
+  const int bh = idx / pad, q = Nq + idx - bh * pad;
+  write_stat_rows(stats, (long)BH * Nq64, (long)bh * Nq64 + q, PXA_STAT_SENTINEL, 0.f);
+}
 __global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* __restrict__ O, const bf16_t* __restrict__ dO, float* __restrict__ delta,
-                                                         long o_bs, long o_ts, int o_hs, long do_bs, long do_ts, int do_hs, int B, int H, int Nq) {
+                                                         long o_bs, long o_ts, int o_hs, long do_bs, long do_ts, int do_hs, int B, int H, int Nq,
+                                                         const float* __restrict__ lse, bf16_t* __restrict__ stats, int Nq64, float inv_c) {
   const long idx = blockIdx.x * 256L + threadIdx.x;  // (b, q, h) with h fastest -> adjacent threads read adjacent 144-byte rows
   if (idx >= (long)B * Nq * H) return;
   const int h = idx % H;
@@ -451,6 +478,7 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* __restric
     for (int e = 0; e < 8; e++) acc += a[e] * d[e];
   }
   delta[((long)b * H + h) * Nq + q] = acc;
+  if (stats) write_stat_rows(stats, (long)B * H * Nq64, ((long)b * H + h) * Nq64 + q, lse[((long)b * H + h) * Nq + q] * inv_c, acc);
 }
 
 // Same for token-contiguous O / dO ([B][Nq][H][72], what the engine passes): the kernel above reads adjacent 144-byte rows from adjacent
@@ -459,7 +487,8 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* __restric
 // lets thread (h, q) add the 9 partials of its head: 64-byte runs of delta per head.
 constexpr int DELTA_TOK = 16;
 __global__ __launch_bounds__(256) void attn_delta_rows_kernel(const bf16_t* __restrict__ O, const bf16_t* __restrict__ dO, float* __restrict__ delta,
-                                                              int H, int Nq, long tokens) {
+                                                              int H, int Nq, long tokens, const float* __restrict__ lse, bf16_t* __restrict__ stats,
+                                                              int Nq64, float inv_c) {
   __shared__ float part[DELTA_TOK * 16 * NCH + 16];
   const long tok0 = (long)blockIdx.x * DELTA_TOK;
   const int cpt = H * NCH;                                 // chunks per token (144)
@@ -492,6 +521,7 @@ __global__ __launch_bounds__(256) void attn_delta_rows_kernel(const bf16_t* __re
     for (int i = 0; i < NCH; i++) acc += part[ql * cpt + h * NCH + i];
     const long b = tok / Nq, q = tok - b * Nq;
     delta[(b * H + h) * Nq + q] = acc;
+    if (stats) write_stat_rows(stats, (tokens / Nq) * H * Nq64, (b * H + h) * Nq64 + q, lse[(b * H + h) * Nq + q] * inv_c, acc);
   }
 }
 
@@ -642,6 +672,9 @@ __global__ __launch_bounds__(256, 2) void attn_fwd2_kernel(AttnParams p) {
 // ------------------------------------------------------------------------------------------------ backward: dQ
 #ifndef ATTN_BWD_WAVES
 #define ATTN_BWD_WAVES 2
+#endif
+#ifndef PXA_ATTN_DKV_DEFAULT
+#define PXA_ATTN_DKV_DEFAULT 2
 #endif
 #ifndef ATTN_ABL
 #define ATTN_ABL 0      // ablation study of the dK/dV kernel (tools/build_variant.py; results in profiles/r02_attention_bwd_experiments.md):
@@ -861,6 +894,282 @@ __global__ __launch_bounds__(256, ATTN_BWD_WAVES) void attn_bwd_dkv_kernel(AttnP
   if (p.dv_colsum) colsum_rows(p.dv_colsum + (b % PXA_COLSUM_SLOTS) * p.colsum_stride + h * DH, dv, 1.f, kvvalid, hi, lane);
 }
 
+
+// ------------------------------------------------------------------------------------------------ backward: dK, dV (round 3)
+// Same products, layouts and fragments as attn_bwd_dkv_kernel above; what changes is the instruction stream (the old loop ran
+// 61 cycles per MFMA against a 32-cycle floor with 6.7 other issues per MFMA, the two waves of a SIMD each alternating long MFMA-only and VALU-only stretches):
+//   * lse and delta ride in the first products ("stats rows" above): per element mul, exp2, mul and half a cvt_pk are left (4 instead of 5 VALU), the 16
+//     broadcast reads and the staging write per tile are gone, and so is every branch inside the tile loop.
+//   * MODE 1, software pipeline over 32-query sub-tiles j: the dV / dK MFMAs of sub-tile j-1 are issued BETWEEN the softmax instructions of sub-tile j
+//     (hand-placed slots of one MFMA, the two transpose reads of the MFMA two slots ahead and 4-6 VALU, fenced with sched_barrier(0):
+//     sched_group_barrier pipelines were not honoured by the scheduler at this register pressure - it fell back to read / wait / MFMA triplets), then the
+//     S / dP MFMAs of j+1 with their row reads.  A wave's stream is MFMA-dense from the first to the last tile; the exp2 / mul / cvt work sits in the
+//     issue slots one 32-cycle MFMA leaves (probe/overlap_probe2.hip).  The packed P / dS of one sub-tile are kept across (16 registers); S / dP reuse
+//     one register set because softmax j is complete before A(j+1) issues.
+//   * three-stage LDS ring {Q tile, L rows, dO tile, D rows} (78 KiB per workgroup, two workgroups per CU): C(j-1) of a tile's last sub-tile runs in the next
+//     iteration, so a tile's stage is released one barrier later; the DMA of tile t+2 is issued behind that barrier.  One barrier per tile as before.
+//   MODE 0 keeps the old order (A, softmax, C per sub-tile) on the same ring and stats rows: the A/B partner that isolates the pipeline.
+constexpr int STAT_B = BKV * 16;                   // 64 rows x 16 B
+constexpr int STAGE_B = 2 * (TILE_B + STAT_B);     // [Q tile][L rows][dO tile][D rows]
+constexpr int NSTAGE = 3;
+template <typename F, int... K> __device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, K...>) { (f(IntC<K>{}), ...); }
+template <int N, typename F> __device__ __forceinline__ void static_for(F&& f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
+// LDS reads the compiler does not see (no s_waitcnt of its own: every use is preceded by lds_wait on the destination)
+template <int OFF> __device__ __forceinline__ void lds_row_asm(bf16x8& d, unsigned addr) {
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(d) : "v"(addr), "n"(OFF) : "memory");
+}
+template <int OFF> __device__ __forceinline__ void lds_tr_asm(bf16x8& d, unsigned a0, unsigned a1) {
+  s16x4 lo, hi;
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(lo) : "v"(a0), "n"(OFF) : "memory");
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(hi) : "v"(a1), "n"(OFF) : "memory");
+  d = concat_tr(lo, hi);
+}
+template <int N> __device__ __forceinline__ void lds_wait(bf16x8& d) { asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(d) : "n"(N)); }
+template <int MODE>
+__global__ __launch_bounds__(256, 2) void attn_bwd_dkv2_kernel(AttnParams p) {
+  __shared__ __attribute__((aligned(16))) char smem[NSTAGE * STAGE_B];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), hi = lane >> 5;
+  int bx, h, b;
+  block_coords(p, bx, h, b);
+  long kbase, vbase, dkbase, dvbase; int kvlen;
+  kv_range(p, b, kbase, vbase, dkbase, dvbase, kvlen);
+  if (bx * 128 >= kvlen) return;  // whole block beyond this sample's keys (uniform across the block)
+  const int kv = bx * 128 + wave * 32 + (lane & 31);
+  const bool kvvalid = kv < kvlen;
+  const bool wave_active = bx * 128 + wave * 32 < kvlen;   // see attn_bwd_dkv_kernel
+
+  bf16x8 kf[KSTEPS], vf[KSTEPS];
+  load_row_frags(kf, p.K + kbase + (long)kv * p.k_ts + (long)h * p.k_hs, kvvalid, hi);
+  load_row_frags(vf, p.V + vbase + (long)kv * p.v_ts + (long)h * p.v_hs, kvvalid, hi);
+  if (hi == 1) {                                            // k-slots 72 / 73 (k-step 4, upper half): -1.0 against the stats rows' {hi, lo}
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    u32x4 w = __builtin_bit_cast(u32x4, kf[KSTEPS - 1]);
+    w[0] = PXA_OPERAND_MINUS_ONE_X2;
+    kf[KSTEPS - 1] = __builtin_bit_cast(bf16x8, w);
+    w = __builtin_bit_cast(u32x4, vf[KSTEPS - 1]);
+    w[0] = PXA_OPERAND_MINUS_ONE_X2;
+    vf[KSTEPS - 1] = __builtin_bit_cast(bf16x8, w);
+  }
+  const bf16_t* Qp = p.Q + (long)b * p.q_bs + (long)h * p.q_hs;
+  const bf16_t* Dp = p.dO + (long)b * p.o_bs + (long)h * p.o_hs;
+  const bf16_t* Ls = p.stats + ((long)b * p.H + h) * p.Nq64 * 8;
+  const bf16_t* Ds = Ls + (long)p.B * p.H * p.Nq64 * 8;
+  const int qts = (int)p.q_ts, ots = (int)p.o_ts;
+  DmaPlan pl;
+  dma_plan(pl, wave, lane);
+  FragAddr fa;
+  frag_addr(fa, lane);
+  // k-step 4 of the row operand: lanes of the lower half read chunk 8 of the tile (d = 64..71), lanes of the upper half the stats row of their query
+  // (16 B at tile base + TILE_B + 16 row): one ds_read_b128 whose 16-lane groups each lie entirely in one of the two regions.
+  int r4[2];
+#pragma unroll
+  for (int sub = 0; sub < 2; sub++) r4[sub] = hi ? TILE_B + (sub * 32 + (lane & 31)) * 16 : fa.rb[0] + 2 * 64 + sub * 32 * ROWB;
+
+  for (int st = 0; st < NSTAGE; st++) {
+    init_pads(smem + st * STAGE_B, 0, tid);
+    init_pads(smem + st * STAGE_B + TILE_B + STAT_B, 0, tid);
+  }
+  f32x16 dk[3], dv[3];
+  zero3(dk);
+  zero3(dv);
+  const float c = p.scale_log2;
+  const int T = (p.Nq + BKV - 1) / BKV, Tfull = p.Nq / BKV;
+  auto issue = [&](int t, char* st) {       // tile t -> stage st: 6 tile pieces per wave + the two stats rows blocks (waves 0 / 1)
+    if (t < Tfull) {
+      dma_tile<true>(st, Qp, qts, t * BKV, p.Nq, pl, wave);
+      dma_tile<true>(st + TILE_B + STAT_B, Dp, ots, t * BKV, p.Nq, pl, wave);
+    } else {
+      dma_tile<false>(st, Qp, qts, t * BKV, p.Nq, pl, wave);
+      dma_tile<false>(st + TILE_B + STAT_B, Dp, ots, t * BKV, p.Nq, pl, wave);
+    }
+    if (wave < 2) {
+      const bf16_t* src = (wave == 0 ? Ls : Ds) + ((long)t * BKV + lane) * 8;
+      char* dst = st + (wave == 0 ? TILE_B : 2 * TILE_B + STAT_B);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+    }
+  };
+  auto rowA = [&](const char* tile, int sub, int ks) -> bf16x8 {
+    return ks < KSTEPS - 1 ? rowfrag(tile, fa, sub, ks) : *reinterpret_cast<const bf16x8*>(tile + r4[sub]);
+  };
+  // A(j): S' = Q K^T - lse / c and dP' = dO V^T - delta of one 32-query sub-tile
+  auto phaseA = [&](const char* sQ, const char* sD, int sub, f32x16& s, f32x16& dp) {
+#pragma unroll
+    for (int g = 0; g < 16; g++) { s[g] = 0.f; dp[g] = 0.f; }
+#pragma unroll
+    for (int ks = 0; ks < KSTEPS; ks++) {
+      s = mfma32(rowA(sQ, sub, ks), kf[ks], s);
+      dp = mfma32(rowA(sD, sub, ks), vf[ks], dp);
+    }
+  };
+  // B(j): P = exp2(c S'), dS = P dP' (softmax scale applied at the store), packed to the B operands of the second products
+  auto phaseB = [&](f32x16& s, f32x16& dp, bf16x8 (&pb)[2], bf16x8 (&db)[2]) {
+#pragma unroll
+    for (int g = 0; g < 16; g++) {
+      const float pr = __builtin_amdgcn_exp2f(s[g] * c);
+      s[g] = pr;
+      dp[g] = pr * dp[g];
+    }
+#pragma unroll
+    for (int uu = 0; uu < 2; uu++) { pb[uu] = pack8(s, 8 * uu); db[uu] = pack8(dp, 8 * uu); }
+  };
+  // C(j): dV^T += dO^T P, dK^T += Q^T dS
+  auto phaseC = [&](const char* sQ, const char* sD, int sub, const bf16x8 (&pb)[2], const bf16x8 (&db)[2]) {
+#pragma unroll
+    for (int uu = 0; uu < 2; uu++)
+#pragma unroll
+      for (int dt = 0; dt < 3; dt++) {
+        dv[dt] = mfma32(trfrag(sD, fa, dt, sub * 2 + uu), pb[uu], dv[dt]);
+        dk[dt] = mfma32(trfrag(sQ, fa, dt, sub * 2 + uu), db[uu], dk[dt]);
+      }
+  };
+  auto stage = [&](int i) -> char* { return smem + i * STAGE_B; };
+
+  // Ring protocol (both modes): iteration t = barrier (tile t landed; every wave has left the stage of tile t - 2), DMA of tile t + 1 into that
+  // stage, compute.  MODE 1 still reads tile t - 1 during iteration t, hence three stages.
+  issue(0, stage(0));
+  if (!wave_active) {                        // serves DMA and barriers only (same barrier count as the compute path)
+    int in = 1;
+    for (int t = 0; t < T; t++) {
+      __syncthreads();
+      if (t + 1 < T) issue(t + 1, stage(in));
+      in = in == NSTAGE - 1 ? 0 : in + 1;
+    }
+    return;
+  }
+  if (MODE == 0) {
+    int ic = 0;
+    for (int t = 0; t < T; t++) {
+      const int in = ic == NSTAGE - 1 ? 0 : ic + 1;
+      __syncthreads();
+      if (t + 1 < T) issue(t + 1, stage(in));
+      const char* sQ = stage(ic);
+      const char* sD = sQ + TILE_B + STAT_B;
+#pragma unroll
+      for (int sub = 0; sub < 2; sub++) {
+        f32x16 s, dp;
+        bf16x8 pb[2], db[2];
+        phaseA(sQ, sD, sub, s, dp);
+        phaseB(s, dp, pb, db);
+        phaseC(sQ, sD, sub, pb, db);
+      }
+      ic = in;
+    }
+  } else {
+    // Hand-placed stream.  Slot = {counted wait; one MFMA; the LDS reads of the MFMA two slots ahead; a slice of the softmax}, closed by
+    // sched_barrier(0) so the compiler keeps the order written here.  Fragments rotate through f[0..2].
+    //   region X (10 slots): A of a sub-tile (row fragment k = 2 ks + w; w = 0: Q -> S, w = 1: dO -> dP)
+    //   region Y (12 slots): C of the previous sub-tile (tr fragment k = uu 6 + dt 2 + w; w = 0: dO^T -> dV, w = 1: Q^T -> dK) || B of the current one
+    // B in place, per slot k: exp2 of elements 2k, 2k+1 (k < 8), dP multiplies one slot behind (1 <= k <= 8), the four cvt_pk groups in slots 8..11:
+    // 4 6 6 6 6 6 6 6 6 4 4 4 VALU.
+    // The LDS reads are inline asm with hand-counted lgkmcnt waits: (1) the compiler puts s_waitcnt vmcnt(0) in front of every ds_read_b64_tr_b16 that
+    // follows an LDS-DMA still in flight (the intrinsic's memory operand carries no alias scope) - in this loop that would expose the whole DMA
+    // latency once per tile; (2) it re-used one register quad for every fragment (read, wait, MFMA).  lgkmcnt counts in issue order, so a wait in
+    // front of MFMA k names the reads issued after fragment k's own: exactly fragment k + 1 (fragment k + 2 follows the MFMA).  tr fragment = 2 reads,
+    // row fragment = 1.  Iteration = barrier; DMA of tile t + 1; X: A(t, 0) [cold start]; Y: C(t-1, 1) || B(t, 0); X: A(t, 1); Y: C(t, 0) || B(t, 1):
+    // nothing is in flight at the loop's back edge.  tools/check_lds_waits.py replays the emitted ISA against these rules.
+    const unsigned lds0 = (unsigned)(uintptr_t)LDS_PTR(char, smem);
+    f32x16 s, dp;
+    bf16x8 pb[2], db[2], pb1[2], db1[2], f[3];
+#pragma unroll
+    for (int uu = 0; uu < 2; uu++)
+#pragma unroll
+      for (int e = 0; e < 8; e++) { pb1[uu][e] = (bf16_t)0.f; db1[uu][e] = (bf16_t)0.f; }
+    struct Bases { unsigned r0, r1, r40, r41, t0, t1; };   // per-lane LDS byte addresses inside one stage (the dO tile is an immediate offset away)
+    auto bases = [&](unsigned st) -> Bases { return Bases{st + (unsigned)fa.rb[0], st + (unsigned)fa.rb[1], st + (unsigned)r4[0], st + (unsigned)r4[1],
+                                                          st + (unsigned)fa.tb[0], st + (unsigned)fa.tb[1]}; };
+    constexpr int DOFF = TILE_B + STAT_B;                  // dO tile relative to the Q tile of its stage
+    auto rd_row = [&](auto subc, auto kc, bf16x8& d, const Bases& bs) {
+      constexpr int sub = decltype(subc)::value, k = decltype(kc)::value, ks = k >> 1, w = k & 1;
+      if constexpr (ks < KSTEPS - 1) lds_row_asm<w * DOFF + sub * 32 * ROWB + (ks >> 1) * 64>(d, (ks & 1) ? bs.r1 : bs.r0);
+      else lds_row_asm<w * DOFF>(d, sub ? bs.r41 : bs.r40);
+    };
+    auto rd_tr = [&](auto subc, auto kc, bf16x8& d, unsigned t0, unsigned t1) {
+      constexpr int sub = decltype(subc)::value, k = decltype(kc)::value, uu = k / 6, dt = (k % 6) >> 1, w = k & 1;
+      lds_tr_asm<(w ? 0 : DOFF) + (sub * 2 + uu) * 16 * ROWB + dt * 64>(d, t0, t1);
+    };
+    // (the empty asm statements pin each slice to its slot: SelectionDAG otherwise emits pure arithmetic next to its first use, i.e. behind the
+    // region's last sched_barrier - seen with the 16 cvt_pk)
+    auto softmax_slot = [&](auto kc, bf16x8 (&npb)[2], bf16x8 (&ndb)[2]) {
+      constexpr int k = decltype(kc)::value;
+      if constexpr (k < 8) {
+        s[2 * k] = __builtin_amdgcn_exp2f(s[2 * k] * c);
+        s[2 * k + 1] = __builtin_amdgcn_exp2f(s[2 * k + 1] * c);
+        asm volatile("" : "+v"(s[2 * k]), "+v"(s[2 * k + 1]));
+      }
+      if constexpr (k >= 1 && k <= 8) {
+        dp[2 * k - 2] *= s[2 * k - 2];
+        dp[2 * k - 1] *= s[2 * k - 1];
+        asm volatile("" : "+v"(dp[2 * k - 2]), "+v"(dp[2 * k - 1]));
+      }
+      if constexpr (k == 8) { npb[0] = pack8(s, 0); asm volatile("" : "+v"(npb[0])); }
+      if constexpr (k == 9) { ndb[0] = pack8(dp, 0); asm volatile("" : "+v"(ndb[0])); }
+      if constexpr (k == 10) { npb[1] = pack8(s, 8); asm volatile("" : "+v"(npb[1])); }
+      if constexpr (k == 11) { ndb[1] = pack8(dp, 8); asm volatile("" : "+v"(ndb[1])); }
+    };
+    // BASE: fragment k of the region sits in f[(k + BASE) % 3]; fragments 0 and 1 are in flight on entry.
+    // region X: A(sub ASUB of the stage `ab`); PRE: its last two slots load tr fragments 0, 1 of C(sub NSUB) from the tr bases nt0 / nt1
+    auto regionX = [&](auto basec, auto asubc, auto prec, auto nsubc, const Bases& ab, unsigned nt0, unsigned nt1) {
+      constexpr int BASE = decltype(basec)::value;
+      constexpr bool PRE = decltype(prec)::value;
+      static_for<10>([&](auto kc) {
+        constexpr int k = decltype(kc)::value;
+        lds_wait<(k < 9) ? 1 : (PRE ? 2 : 0)>(f[(k + BASE) % 3]);
+        if constexpr (k == 0) { f32x16 z; for (int g = 0; g < 16; g++) z[g] = 0.f; s = mfma32(f[(k + BASE) % 3], kf[0], z); }
+        else if constexpr (k == 1) { f32x16 z; for (int g = 0; g < 16; g++) z[g] = 0.f; dp = mfma32(f[(k + BASE) % 3], vf[0], z); }
+        else if constexpr (k & 1) dp = mfma32(f[(k + BASE) % 3], vf[k >> 1], dp);
+        else s = mfma32(f[(k + BASE) % 3], kf[k >> 1], s);
+        if constexpr (k + 2 < 10) rd_row(asubc, IntC<k + 2>{}, f[(k + 2 + BASE) % 3], ab);
+        else if constexpr (PRE) rd_tr(nsubc, IntC<k + 2 - 10>{}, f[(k + 2 + BASE) % 3], nt0, nt1);
+        __builtin_amdgcn_sched_barrier(0);
+      });
+    };
+    // region Y: C(sub CSUB, tr bases ct0 / ct1, operands cpb / cdb) || B(s, dp -> npb, ndb); PRE: the last two slots load row fragments 0, 1 of
+    // A(sub ASUB of the stage `ab`)
+    auto regionY = [&](auto basec, auto csubc, auto prec, auto asubc, unsigned ct0, unsigned ct1, const bf16x8 (&cpb)[2], const bf16x8 (&cdb)[2],
+                       bf16x8 (&npb)[2], bf16x8 (&ndb)[2], const Bases& ab) {
+      constexpr int BASE = decltype(basec)::value;
+      constexpr bool PRE = decltype(prec)::value;
+      static_for<12>([&](auto kc) {
+        constexpr int k = decltype(kc)::value, uu = k / 6, dt = (k % 6) >> 1;
+        lds_wait<(k < 11) ? 2 : (PRE ? 1 : 0)>(f[(k + BASE) % 3]);
+        if constexpr (k & 1) dk[dt] = mfma32(f[(k + BASE) % 3], cdb[uu], dk[dt]);
+        else dv[dt] = mfma32(f[(k + BASE) % 3], cpb[uu], dv[dt]);
+        if constexpr (k + 2 < 12) rd_tr(csubc, IntC<k + 2>{}, f[(k + 2 + BASE) % 3], ct0, ct1);
+        else if constexpr (PRE) rd_row(asubc, IntC<k + 2 - 12>{}, f[(k + 2 + BASE) % 3], ab);
+        softmax_slot(kc, npb, ndb);
+        __builtin_amdgcn_sched_barrier(0);
+      });
+    };
+    int ic = 0;                               // stage of tile t
+    unsigned cur = lds0, prv = lds0;          // LDS addresses of the stages of tile t and t - 1 (tile 0 itself at t = 0, where pb1 = db1 = 0)
+    for (int t = 0; t < T; t++) {
+      const int in = ic == NSTAGE - 1 ? 0 : ic + 1;
+      __syncthreads();                        // tile t has landed (vmcnt(0)) for every wave; every wave has left the stage of tile t - 2
+      if (t + 1 < T) issue(t + 1, stage(in));
+      const Bases cb = bases(cur);
+      const unsigned pt0 = prv + (unsigned)fa.tb[0], pt1 = prv + (unsigned)fa.tb[1];
+      __builtin_amdgcn_sched_barrier(0);
+      rd_row(IntC<0>{}, IntC<0>{}, f[0], cb);                                     // cold start: row fragments 0, 1 of A(t, 0)
+      rd_row(IntC<0>{}, IntC<1>{}, f[1], cb);
+      __builtin_amdgcn_sched_barrier(0);
+      regionX(IntC<0>{}, IntC<0>{}, BoolC<true>{}, IntC<1>{}, cb, pt0, pt1);                          // A(t, 0)               -> tr of C(t-1, 1)
+      regionY(IntC<1>{}, IntC<1>{}, BoolC<true>{}, IntC<1>{}, pt0, pt1, pb1, db1, pb, db, cb);        // C(t-1, 1) || B(t, 0)  -> rows of A(t, 1)
+      regionX(IntC<1>{}, IntC<1>{}, BoolC<true>{}, IntC<0>{}, cb, cb.t0, cb.t1);                      // A(t, 1)               -> tr of C(t, 0)
+      regionY(IntC<2>{}, IntC<0>{}, BoolC<false>{}, IntC<0>{}, cb.t0, cb.t1, pb, db, pb1, db1, cb);   // C(t, 0) || B(t, 1)
+      prv = cur;
+      cur = lds0 + in * STAGE_B;
+      ic = in;
+    }
+    phaseC(smem + (prv - lds0), smem + (prv - lds0) + TILE_B + STAT_B, 1, pb1, db1);
+  }
+  if (kvvalid) {
+    store_rows(p.dK + dkbase + (long)kv * p.dk_ts + (long)h * p.dk_hs, dk, p.scale, hi);
+    store_rows(p.dV + dvbase + (long)kv * p.dv_ts + (long)h * p.dv_hs, dv, 1.f, hi);
+  }
+  if (p.dk_colsum) colsum_rows(p.dk_colsum + (b % PXA_COLSUM_SLOTS) * p.colsum_stride + h * DH, dk, p.scale, kvvalid, hi, lane);
+  if (p.dv_colsum) colsum_rows(p.dv_colsum + (b % PXA_COLSUM_SLOTS) * p.colsum_stride + h * DH, dv, 1.f, kvvalid, hi, lane);
+}
+
 int fill(AttnParams& p, const pxa_attn_args* a) {
   PXA_CHECK(a, "attn: null args");
   PXA_CHECK(a->head_dim == DH, "attn: head_dim %d unsupported (PixArt XL/2 uses 72)", a->head_dim);
@@ -880,6 +1189,7 @@ int fill(AttnParams& p, const pxa_attn_args* a) {
   p.B = a->B; p.H = a->H; p.Nq = a->Nq; p.Nk = a->Nk;
   p.kv_start = a->kv_start; p.kv_len = a->kv_len;
   p.scale = a->scale; p.scale_log2 = a->scale * 1.4426950408889634f;
+  p.stats = (const bf16_t*)a->bwd_stats; p.Nq64 = (a->Nq + BKV - 1) / BKV * BKV;
   const long strides[] = {p.q_ts, p.k_ts, p.v_ts, p.o_ts, p.q_hs, p.k_hs, p.v_hs, p.o_hs, p.q_bs, p.k_bs, p.v_bs, p.o_bs};
   for (long s : strides) PXA_CHECK(s % 8 == 0, "attn: strides must be multiples of 8 elements (16-byte rows)");
   return 0;
@@ -900,6 +1210,8 @@ extern "C" int pxa_attn_fwd(const pxa_attn_args* a, hipStream_t stream) {
   return 0;
 }
 
+extern "C" long pxa_attn_bwd_stats_bytes(int B, int H, int Nq) { return 2L * B * H * ((Nq + BKV - 1) / BKV * BKV) * 16; }
+
 extern "C" int pxa_attn_bwd(const pxa_attn_args* a, hipStream_t stream) {
   AttnParams p;
   if (int rc = fill(p, a)) return rc;
@@ -908,12 +1220,24 @@ extern "C" int pxa_attn_bwd(const pxa_attn_args* a, hipStream_t stream) {
   for (long s : {p.dq_ts, p.dk_ts, p.dv_ts, (long)p.dq_hs, (long)p.dk_hs, (long)p.dv_hs, p.dq_bs, p.dk_bs, p.dv_bs})
     PXA_CHECK(s % 4 == 0, "pxa_attn_bwd: gradient strides must be multiples of 4 elements");
   const long total = (long)p.B * p.Nq * p.H;
+  // dK/dV kernel: 0 = round-2 kernel (lse / delta on the VALU), 1 = stats rows + three-stage ring, old issue order, 2 = + software pipeline.
+  // 1 and 2 need the caller's bwd_stats workspace (pxa_attn_bwd_stats_bytes); without it the round-2 kernel runs.
+  const char* env = getenv("PXA_ATTN_DKV");
+  int dkv_mode = env ? atoi(env) : PXA_ATTN_DKV_DEFAULT;
+  if (!p.stats || !p.dK) dkv_mode = 0;
+  bf16_t* stats = dkv_mode ? (bf16_t*)a->bwd_stats : nullptr;
+  const float inv_c = 1.0f / p.scale_log2;
+  if (stats && p.Nq64 != p.Nq) {
+    const int n = p.B * p.H * (p.Nq64 - p.Nq);
+    hipLaunchKernelGGL(attn_stats_pad_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, stats, p.B * p.H, p.Nq, p.Nq64);
+  }
   if (p.o_hs == DH && p.o_ts == (long)p.H * DH && p.o_bs == (long)p.Nq * p.o_ts && p.H <= 16 && ((uintptr_t)p.O % 16) == 0 && ((uintptr_t)p.dO % 16) == 0) {
     const long tokens = (long)p.B * p.Nq;                  // token-contiguous rows: the coalesced form
-    hipLaunchKernelGGL(attn_delta_rows_kernel, dim3((tokens + DELTA_TOK - 1) / DELTA_TOK), dim3(256), 0, stream, p.O, p.dO, a->delta, p.H, p.Nq, tokens);
+    hipLaunchKernelGGL(attn_delta_rows_kernel, dim3((tokens + DELTA_TOK - 1) / DELTA_TOK), dim3(256), 0, stream, p.O, p.dO, a->delta, p.H, p.Nq, tokens,
+                       p.LSE, stats, p.Nq64, inv_c);
   } else {
     hipLaunchKernelGGL(attn_delta_kernel, dim3((total + 255) / 256), dim3(256), 0, stream, p.O, p.dO, a->delta,
-                       p.o_bs, p.o_ts, p.o_hs, p.o_bs, p.o_ts, p.o_hs, p.B, p.H, p.Nq);
+                       p.o_bs, p.o_ts, p.o_hs, p.o_bs, p.o_ts, p.o_hs, p.B, p.H, p.Nq, p.LSE, stats, p.Nq64, inv_c);
   }
   PXA_LAUNCH_CHECK();
   if (p.dQ) {
@@ -926,7 +1250,11 @@ extern "C" int pxa_attn_bwd(const pxa_attn_args* a, hipStream_t stream) {
     const int max_k = a->max_kv_len > 0 ? a->max_kv_len : p.Nk;
     p.nx = (max_k + 127) / 128;
     PXA_CHECK((long)p.nx * p.H * p.B < (1L << 31), "pxa_attn_bwd: grid too large");
-    if (p.nx > 0) hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3(p.nx * p.H * p.B), dim3(256), 0, stream, p);
+    if (p.nx > 0) {
+      if (dkv_mode == 2) hipLaunchKernelGGL(attn_bwd_dkv2_kernel<1>, dim3(p.nx * p.H * p.B), dim3(256), 0, stream, p);
+      else if (dkv_mode == 1) hipLaunchKernelGGL(attn_bwd_dkv2_kernel<0>, dim3(p.nx * p.H * p.B), dim3(256), 0, stream, p);
+      else hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3(p.nx * p.H * p.B), dim3(256), 0, stream, p);
+    }
     PXA_LAUNCH_CHECK();
   }
   return 0;

@@ -167,9 +167,24 @@ def attention_fwd(q, k, v, o, lse, B, H, Nq, Nk, strides, **kw):
     return o
 
 
+_bwd_stats = {}
+
+
+def attn_bwd_stats(B, H, Nq, device):
+    """The dK/dV kernel's lse / delta workspace (include/pixart_hip.h: pxa_attn_args.bwd_stats): written by the backward's own pre-pass and consumed
+    by its last kernel on one stream, so every call of a device shares the largest buffer asked for so far."""
+    n = lib.load().pxa_attn_bwd_stats_bytes(B, H, Nq)
+    buf = _bwd_stats.get(device)
+    if buf is None or buf.numel() < n:
+        buf = _bwd_stats[device] = torch.empty(n, dtype=torch.uint8, device=device)
+    return buf
+
+
 def attention_bwd(q, k, v, o, d_o, lse, delta, dq, dk, dv, B, H, Nq, Nk, strides, dstrides, colsums=(None, None, None), **kw):
     """colsums: optional fp32 (H*72,) accumulators receiving the column sums of dq / dk / dv (bias gradients)."""
     a = _attn_args(q, k, v, o, B, H, Nq, Nk, strides, **kw)
+    if dk is not None:
+        a.bwd_stats = ptr(attn_bwd_stats(B, H, Nq, q.device))
     a.dq_colsum, a.dk_colsum, a.dv_colsum = (ptr(t) for t in colsums)
     a.colsum_stride = next((t.stride(0) for t in colsums if t is not None), 0)
     a.lse, a.delta, a.d_o, a.dq, a.dk, a.dv = ptr(lse), ptr(delta), ptr(d_o), ptr(dq), ptr(dk), ptr(dv)

@@ -8,7 +8,7 @@ from conftest import rel_l2
 from oracle import pixart_oracle as po
 from oracle.weights import make_inputs, make_state_dict
 
-FWD_CASES = ["fwd_d2_sq", "fwd_d2_kvconv", "fwd_d2_kvuniform", "fwd_d2_kvave", "fwd_d2_nomask", "fwd_d2_qknorm", "fwd_d2_micro",
+FWD_CASES = ["fwd_d2_sq", "fwd_d2_kvconv", "fwd_d2_kvuniform", "fwd_d2_kvave", "fwd_d2_kvevery", "fwd_d2_nomask", "fwd_d2_qknorm", "fwd_d2_micro",
              # BASELINE.json configs[1..4] token geometries (depth 2): 512px L=300 / L=120 multi-aspect, 1024px, 2K with KV compression
              "fwd_512_l300", "fwd_512_l120", "fwd_1024_b2", "fwd_2k_kv"]
 
@@ -52,7 +52,7 @@ def test_micro_condition_changes_the_output(golden):
     assert rel_l2(y, g["y"]) > 1e-3
 
 
-@pytest.mark.parametrize("gname", ["train_d2", "train_d2_qknorm", "train_d2_micro", "train_1024_b2"])
+@pytest.mark.parametrize("gname", ["train_d2", "train_d2_qknorm", "train_d2_micro", "train_d2_kvevery", "train_1024_b2"])
 def test_training_losses_and_grads_match_reference(golden, gname):
     g = golden(gname)
     cfg, sd, inp, mask = _setup(g)
@@ -93,6 +93,17 @@ def test_dpm_solver_matches_reference(golden):
         assert rel_l2(po.forward(sd, cfg, inp["x"], inp["t"], inp["y"], mask), g["fwd"]) < 2e-5
         s = _sample(g, cfg, sd, inp, mask)
     assert rel_l2(s, g["sample"]) < 5e-5
+
+
+@pytest.mark.slow
+def test_full_depth_xl2_1024_matches_reference(golden):
+    """Round 3: PixArtMS_XL_2 (depth 28) at the benchmark's geometry (1024px: N = 4096, L = 300), forward, batch 1 (fwd_xl2_1024_b1; the reference took
+    55 s for it here).  The training golden of the same model (train_xl2_1024_b1) and the depth-28 2K forward are checked on the GPU tier only."""
+    g = golden("fwd_xl2_1024_b1")
+    cfg, sd, inp, mask = _setup(g)
+    with torch.no_grad():
+        y = po.forward(sd, cfg, inp["x"], inp["t"], inp["y"], mask)
+    assert rel_l2(y, g["y"]) < 5e-5
 
 
 @pytest.mark.slow
