@@ -118,7 +118,7 @@ __device__ __forceinline__ void dma_tile(char* lds, const bf16_t* __restrict__ b
   }
 }
 // delta folded into dP (dQ kernel).  dS = P (dP - delta) with dP = dO V^T reduced over the head dimension in 5 steps of 16 = 80 slots, of which 72..79 are
-// zero padding: the lane's dO row (registers) carries delta in slots 72 / 73 (split hi + lo in the operand type: exact to 2^-16 relative in bf16) and the V
+// zero padding: the lane's dO row (registers) carries delta in slots 72 .. 74 (split3: three terms of the operand type, fp32 precision) and the V
 // tiles carry -1.0 there (written once with the pads), so the MFMA returns dP - delta and the 32 subtractions per tile leave the VALU; nothing is added to
 // the matrix work: dQ kernel 1.990 -> 1.916 ms (profiles/r02n_attn_fold_ab.txt).  The dK/dV kernel would have to write delta into the dO tile's pad chunk
 // every tile (its dO rows come by DMA): measured +5 % there, not used.
@@ -132,18 +132,26 @@ __device__ __forceinline__ void dma_tile(char* lds, const bf16_t* __restrict__ b
 #endif
 #endif
 #define PXA_OPERAND_MINUS_ONE_X2 (((PXA_OPERAND_ONE_BITS | 0x8000u) << 16) | PXA_OPERAND_ONE_BITS | 0x8000u)
-__device__ __forceinline__ uint32_t split_hi_lo(float x) {      // {hi, lo} in the operand type with hi + lo ~= x
-  const bf16_t h = (bf16_t)x, l = (bf16_t)(x - (float)h);
-  bf16x2 v; v[0] = h; v[1] = l;
-  return __builtin_bit_cast(uint32_t, v);
+#define PXA_OPERAND_MINUS_ONE_X1 (PXA_OPERAND_ONE_BITS | 0x8000u)     // {-1.0, 0}
+// x as THREE operand-type terms {hi, mid}, {lo, 0} with hi + mid + lo = x to 24 (bf16) / 33 (fp16) mantissa bits - fp32 precision.  Round 3: the two-term
+// form (16 bits in bf16) is not enough where the softmax saturates: there dP - delta vanishes for the dominant key while delta itself is large, and a
+// 2^-17 relative error on delta becomes a spurious dS that dwarfs the true (vanishing) gradient - measured on the depth-28 1024px training golden
+// (train_xl2_1024_b1: gradients of blocks 22 and below off by 1e5 .. 1e6 in the bf16 build; the fp16 build, 22 bits, passed).
+__device__ __forceinline__ uint2 split3(float x) {
+  const bf16_t h = (bf16_t)x;
+  const float r1 = x - (float)h;
+  const bf16_t m = (bf16_t)r1;
+  const bf16_t l = (bf16_t)(r1 - (float)m);
+  bf16x2 a, b; a[0] = h; a[1] = m; b[0] = l; b[1] = (bf16_t)0.f;
+  return make_uint2(__builtin_bit_cast(uint32_t, a), __builtin_bit_cast(uint32_t, b));
 }
-// one-time pad initialisation of a [64][12-chunk] tile: chunks 9..11 <- 0; pad 1: element (row, 72) <- 1.0; pad 2: (row, 72) and (row, 73) <- -1.0
+// one-time pad initialisation of a [64][12-chunk] tile: chunks 9..11 <- 0; pad 1: element (row, 72) <- 1.0; pad 2: (row, 72 .. 74) <- -1.0
 __device__ __forceinline__ void init_pads(char* tile, int pad, int tid) {
   for (int i = tid; i < BKV * 3; i += 256) {
     const int r = i / 3, c = NCH + (i - r * 3);
     uint4 v = make_uint4(0, 0, 0, 0);
     if (pad == 1 && c == NCH) v.x = PXA_OPERAND_ONE_BITS;     // 1.0 in the low half = column 72
-    if (pad == 2 && c == NCH) v.x = PXA_OPERAND_MINUS_ONE_X2; // -1.0 in columns 72 and 73
+    if (pad == 2 && c == NCH) { v.x = PXA_OPERAND_MINUS_ONE_X2; v.y = PXA_OPERAND_MINUS_ONE_X1; }   // -1.0 in columns 72, 73, 74
     *reinterpret_cast<uint4*>(tile + soff(r, c)) = v;
   }
 }
@@ -438,10 +446,10 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
 // ------------------------------------------------------------------------------------------------ delta = rowsum(dO * O)
 // "stats rows" (round 3).  The dK/dV kernel needs lse and delta of every QUERY of a tile, i.e. along its accumulator rows - 16 LDS reads, 32 subtractions
 // and a staging write per tile when they are applied on the VALU.  Instead the pre-pass also writes them as 16-byte rows of the operand type,
-//   Lrow[b][h][q] = {hi, lo, 0 x 6} with hi + lo = lse / scale_log2,        Drow[b][h][q] = {hi, lo, 0 x 6} with hi + lo = delta,
+//   Lrow[b][h][q] = {hi, mid, lo, 0 x 5} summing to lse / scale_log2,        Drow[b][h][q] = {hi, mid, lo, 0 x 5} summing to delta     (split3),
 // the dK/dV kernel brings 64 of each per tile into LDS with ONE 1 KiB LDS-DMA instruction, and its lanes read them as the k-slots 72..79 of the Q / dO
 // operand (the zero padding of head_dim 72 -> 80) against -1.0 in the K / V registers: the first products return S - lse / c and dP - delta.
-// hi + lo carries 16 (bf16) / 22 (fp16) mantissa bits.  Rows [Nq, Nq64) hold a huge finite lse (P = 0 for queries that do not exist) and delta 0.
+// Three terms carry 24 (bf16) / 33 (fp16) mantissa bits.  Rows [Nq, Nq64) hold a huge finite lse (P = 0 for queries that do not exist) and delta 0.
 #ifdef PXA_OPERAND_F16
 #define PXA_STAT_SENTINEL 60000.0f   // fits fp16; exp2(c (S - 6e4)) underflows to 0 for every scale this model uses (c = 0.17)
 #else
@@ -449,8 +457,9 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
 #endif
 __device__ __forceinline__ void write_stat_rows(bf16_t* __restrict__ stats, long rows_total, long row, float l_over_c, float dl) {
   if (!stats) return;
-  *reinterpret_cast<uint4*>(stats + row * 8) = make_uint4(split_hi_lo(l_over_c), 0, 0, 0);
-  *reinterpret_cast<uint4*>(stats + (rows_total + row) * 8) = make_uint4(split_hi_lo(dl), 0, 0, 0);
+  const uint2 l3 = split3(l_over_c), d3 = split3(dl);
+  *reinterpret_cast<uint4*>(stats + row * 8) = make_uint4(l3.x, l3.y, 0, 0);
+  *reinterpret_cast<uint4*>(stats + (rows_total + row) * 8) = make_uint4(d3.x, d3.y, 0, 0);
 }
 __global__ __launch_bounds__(256) void attn_stats_pad_kernel(bf16_t* __restrict__ stats, int BH, int Nq, int Nq64) {
   const int pad = Nq64 - Nq, idx = blockIdx.x * 256 + threadIdx.x;
@@ -698,10 +707,11 @@ __global__ __launch_bounds__(256, ATTN_BWD_WAVES) void attn_bwd_dq_kernel(AttnPa
   const long sidx = ((long)b * p.H + h) * p.Nq + q;
   const float lse = qvalid ? p.LSE[sidx] : 0.f;
   const float delta = qvalid ? p.Delta[sidx] : 0.f;
-  if (ATTN_FOLD_DELTA && hi == 1) {                             // slots 72 / 73 of this lane's dO row (k-step 4, upper half: d = 72 .. 79)
+  if (ATTN_FOLD_DELTA && hi == 1) {                             // slots 72 .. 74 of this lane's dO row (k-step 4, upper half: d = 72 .. 79)
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
     u32x4 w = __builtin_bit_cast(u32x4, dof[KSTEPS - 1]);
-    w[0] = split_hi_lo(delta);
+    const uint2 d3 = split3(delta);
+    w[0] = d3.x; w[1] = d3.y;
     dof[KSTEPS - 1] = __builtin_bit_cast(bf16x8, w);
   }
   DmaPlan pl;
@@ -709,7 +719,7 @@ __global__ __launch_bounds__(256, ATTN_BWD_WAVES) void attn_bwd_dq_kernel(AttnPa
   FragAddr fa;
   frag_addr(fa, lane);
 
-  for (int st = 0; st < 4; st++) init_pads(smem + st * TILE_B, (ATTN_FOLD_DELTA && (st & 1)) ? 2 : 0, tid);   // odd tiles = V: -1.0 in slots 72 / 73
+  for (int st = 0; st < 4; st++) init_pads(smem + st * TILE_B, (ATTN_FOLD_DELTA && (st & 1)) ? 2 : 0, tid);   // odd tiles = V: -1.0 in slots 72 .. 74
   Acc16 dq;
   zero16(dq);
   Tr16Addr ta;
@@ -941,13 +951,13 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv2_kernel(AttnParams p) {
   bf16x8 kf[KSTEPS], vf[KSTEPS];
   load_row_frags(kf, p.K + kbase + (long)kv * p.k_ts + (long)h * p.k_hs, kvvalid, hi);
   load_row_frags(vf, p.V + vbase + (long)kv * p.v_ts + (long)h * p.v_hs, kvvalid, hi);
-  if (hi == 1) {                                            // k-slots 72 / 73 (k-step 4, upper half): -1.0 against the stats rows' {hi, lo}
+  if (hi == 1) {                                            // k-slots 72 .. 74 (k-step 4, upper half): -1.0 against the stats rows' {hi, mid, lo}
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
     u32x4 w = __builtin_bit_cast(u32x4, kf[KSTEPS - 1]);
-    w[0] = PXA_OPERAND_MINUS_ONE_X2;
+    w[0] = PXA_OPERAND_MINUS_ONE_X2; w[1] = PXA_OPERAND_MINUS_ONE_X1;
     kf[KSTEPS - 1] = __builtin_bit_cast(bf16x8, w);
     w = __builtin_bit_cast(u32x4, vf[KSTEPS - 1]);
-    w[0] = PXA_OPERAND_MINUS_ONE_X2;
+    w[0] = PXA_OPERAND_MINUS_ONE_X2; w[1] = PXA_OPERAND_MINUS_ONE_X1;
     vf[KSTEPS - 1] = __builtin_bit_cast(bf16x8, w);
   }
   const bf16_t* Qp = p.Q + (long)b * p.q_bs + (long)h * p.q_hs;
@@ -974,10 +984,23 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv2_kernel(AttnParams p) {
   zero3(dv);
   const float c = p.scale_log2;
   const int T = (p.Nq + BKV - 1) / BKV, Tfull = p.Nq / BKV;
-  auto issue = [&](int t, char* st) {       // tile t -> stage st: 6 tile pieces per wave + the two stats rows blocks (waves 0 / 1)
+  // DMA of tile t -> stage st: 6 tile pieces per wave + the two stats rows blocks (waves 0 / 1).  Full tiles (every tile but a ragged last one) run the
+  // lean form: per-lane source offsets fixed at kernel start, the Q and dO pieces of one mask under ONE exec region (3 regions per tile, not 6), no clamp.
+  unsigned offQ[NDMA], offD[NDMA];
+#pragma unroll
+  for (int i = 0; i < NDMA; i++) { offQ[i] = (unsigned)(pl.row[i] * qts + pl.coff[i]); offD[i] = (unsigned)(pl.row[i] * ots + pl.coff[i]); }
+  auto issue = [&](int t, char* st) {
     if (t < Tfull) {
-      dma_tile<true>(st, Qp, qts, t * BKV, p.Nq, pl, wave);
-      dma_tile<true>(st + TILE_B + STAT_B, Dp, ots, t * BKV, p.Nq, pl, wave);
+      const bf16_t* qb = Qp + (long)t * BKV * qts;
+      const bf16_t* db = Dp + (long)t * BKV * ots;
+#pragma unroll
+      for (int i = 0; i < NDMA; i++)
+        if (pl.coff[i] >= 0) {
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(qb + offQ[i]),
+                                           (__attribute__((address_space(3))) void*)(st + (i * 4 + wave) * 1024), 16, 0, 0);
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(db + offD[i]),
+                                           (__attribute__((address_space(3))) void*)(st + TILE_B + STAT_B + (i * 4 + wave) * 1024), 16, 0, 0);
+        }
     } else {
       dma_tile<false>(st, Qp, qts, t * BKV, p.Nq, pl, wave);
       dma_tile<false>(st + TILE_B + STAT_B, Dp, ots, t * BKV, p.Nq, pl, wave);
@@ -1026,11 +1049,18 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv2_kernel(AttnParams p) {
 
   // Ring protocol (both modes): iteration t = barrier (tile t landed; every wave has left the stage of tile t - 2), DMA of tile t + 1 into that
   // stage, compute.  MODE 1 still reads tile t - 1 during iteration t, hence three stages.
+  // The wait for this wave's own DMA pieces is written out: the compiler only waits for an LDS-DMA in front of LDS reads IT emits (and at workgroup
+  // scope a fence needs no vmcnt), so where the loop's reads are inline asm - or a wave reads nothing at all - __syncthreads() alone compiles to a
+  // bare s_barrier and tiles were read before they had landed (round 3, first GPU run: run-to-run different dK in 18 of 256 heads at B16).
+  auto ring_sync = [&]() {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  };
   issue(0, stage(0));
   if (!wave_active) {                        // serves DMA and barriers only (same barrier count as the compute path)
     int in = 1;
     for (int t = 0; t < T; t++) {
-      __syncthreads();
+      ring_sync();
       if (t + 1 < T) issue(t + 1, stage(in));
       in = in == NSTAGE - 1 ? 0 : in + 1;
     }
@@ -1040,7 +1070,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv2_kernel(AttnParams p) {
     int ic = 0;
     for (int t = 0; t < T; t++) {
       const int in = ic == NSTAGE - 1 ? 0 : ic + 1;
-      __syncthreads();
+      ring_sync();
       if (t + 1 < T) issue(t + 1, stage(in));
       const char* sQ = stage(ic);
       const char* sD = sQ + TILE_B + STAT_B;
@@ -1118,6 +1148,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv2_kernel(AttnParams p) {
         else if constexpr (k == 1) { f32x16 z; for (int g = 0; g < 16; g++) z[g] = 0.f; dp = mfma32(f[(k + BASE) % 3], vf[0], z); }
         else if constexpr (k & 1) dp = mfma32(f[(k + BASE) % 3], vf[k >> 1], dp);
         else s = mfma32(f[(k + BASE) % 3], kf[k >> 1], s);
+        __builtin_amdgcn_sched_barrier(0);       // the MFMA leads its slot: the fillers issue in its shadow
         if constexpr (k + 2 < 10) rd_row(asubc, IntC<k + 2>{}, f[(k + 2 + BASE) % 3], ab);
         else if constexpr (PRE) rd_tr(nsubc, IntC<k + 2 - 10>{}, f[(k + 2 + BASE) % 3], nt0, nt1);
         __builtin_amdgcn_sched_barrier(0);
@@ -1134,6 +1165,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv2_kernel(AttnParams p) {
         lds_wait<(k < 11) ? 2 : (PRE ? 1 : 0)>(f[(k + BASE) % 3]);
         if constexpr (k & 1) dk[dt] = mfma32(f[(k + BASE) % 3], cdb[uu], dk[dt]);
         else dv[dt] = mfma32(f[(k + BASE) % 3], cpb[uu], dv[dt]);
+        __builtin_amdgcn_sched_barrier(0);
         if constexpr (k + 2 < 12) rd_tr(csubc, IntC<k + 2>{}, f[(k + 2 + BASE) % 3], ct0, ct1);
         else if constexpr (PRE) rd_row(asubc, IntC<k + 2 - 12>{}, f[(k + 2 + BASE) % 3], ab);
         softmax_slot(kc, npb, ndb);
@@ -1144,7 +1176,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv2_kernel(AttnParams p) {
     unsigned cur = lds0, prv = lds0;          // LDS addresses of the stages of tile t and t - 1 (tile 0 itself at t = 0, where pb1 = db1 = 0)
     for (int t = 0; t < T; t++) {
       const int in = ic == NSTAGE - 1 ? 0 : ic + 1;
-      __syncthreads();                        // tile t has landed (vmcnt(0)) for every wave; every wave has left the stage of tile t - 2
+      ring_sync();                        // tile t has landed (vmcnt(0)) for every wave; every wave has left the stage of tile t - 2
       if (t + 1 < T) issue(t + 1, stage(in));
       const Bases cb = bases(cur);
       const unsigned pt0 = prv + (unsigned)fa.tb[0], pt1 = prv + (unsigned)fa.tb[1];
