@@ -1263,7 +1263,9 @@ extern "C" int pxa_attn_bwd(const pxa_attn_args* a, hipStream_t stream) {
     const int n = p.B * p.H * (p.Nq64 - p.Nq);
     hipLaunchKernelGGL(attn_stats_pad_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, stats, p.B * p.H, p.Nq, p.Nq64);
   }
-  if (p.o_hs == DH && p.o_ts == (long)p.H * DH && p.o_bs == (long)p.Nq * p.o_ts && p.H <= 16 && ((uintptr_t)p.O % 16) == 0 && ((uintptr_t)p.dO % 16) == 0) {
+  const bool no_prepass = getenv("PXA_ATTN_BWD_NO_PREPASS") != nullptr;   // measurement only (bench.py): delta / stats rows of the SAME inputs are still in the workspace
+  if (no_prepass) {
+  } else if (p.o_hs == DH && p.o_ts == (long)p.H * DH && p.o_bs == (long)p.Nq * p.o_ts && p.H <= 16 && ((uintptr_t)p.O % 16) == 0 && ((uintptr_t)p.dO % 16) == 0) {
     const long tokens = (long)p.B * p.Nq;                  // token-contiguous rows: the coalesced form
     hipLaunchKernelGGL(attn_delta_rows_kernel, dim3((tokens + DELTA_TOK - 1) / DELTA_TOK), dim3(256), 0, stream, p.O, p.dO, a->delta, p.H, p.Nq, tokens,
                        p.LSE, stats, p.Nq64, inv_c);

@@ -205,6 +205,11 @@ class FusedAdamW:
         self.m.copy_(sd["m"])
         self.v.copy_(sd["v"])
         self.t, self.lr = sd["t"], sd.get("lr", self.lr)
+        if self.scaler is not None:
+            # the loss-scaled step takes its bias-correction count from the scaler's device record (applied steps): seed it from this state, so warmed-up
+            # moments resumed without a 'loss_scaler' entry (a bf16 run's checkpoint) are not corrected as if t = 1.  A scaler state loaded AFTERWARDS
+            # (train.py's order) overwrites it with the checkpoint's own count.
+            self.scaler.state[3] = float(self.t)
 
 
 def came_tables(names, offset, shape, numel, tile_elems):

@@ -5,7 +5,12 @@ plain float per step (no parameter groups to walk), so a schedule is a pure func
     batch is train_batch_size x world_size x gradient_accumulation_steps, train_scripts/train.py:448-452)
   * `LRSchedule`     - reference diffusion/utils/lr_scheduler.py:10-40: 'constant' (diffusers get_constant_schedule_with_warmup: linear
     warm-up over num_warmup_steps, then 1), 'cosine' (get_cosine_schedule_with_warmup) and 'cosine_decay_to_constant' (lines 43-88).
-    `step()` is called once per optimizer step, like `lr_scheduler.step()` at train.py:184; state = the step count (checkpointed).
+    `step()` is called once per optimizer step, like `lr_scheduler.step()` at train.py:184; state = the scheduler's step count (checkpointed).
+    What one call advances (round 3): the reference passes its scheduler through `accelerator.prepare` with the default
+    `split_batches=False`, and accelerate's AcceleratedScheduler then steps the wrapped scheduler `num_processes` times per optimizer step and
+    not at all when the fp16 GradScaler skipped the step.  So on 8 GPUs the 1000-step warm-up of the Sigma configs is over after 125 optimizer
+    steps, and a reference checkpoint's `scheduler.last_epoch` counts world x applied steps.  `steps_per_call` (= world size in train.py) and
+    `step(applied=...)` reproduce both.
 """
 import math
 
@@ -19,11 +24,14 @@ def auto_scale_lr(effective_bs, base_lr, rule="linear", base_batch_size=256):
 
 class LRSchedule:
     def __init__(self, base_lr, schedule="constant", num_warmup_steps=0, num_training_steps=None, lr_scale_ratio=1.0, num_decay=0.667,
-                 num_cycles=0.5):
+                 num_cycles=0.5, steps_per_call=1):
         if schedule not in ("constant", "cosine", "cosine_decay_to_constant"):
             raise RuntimeError(f"Unrecognized lr schedule {schedule}.")          # same error as lr_scheduler.py:39
         if schedule != "constant" and not num_training_steps:
             raise ValueError(f"lr schedule {schedule!r} needs num_training_steps")
+        if schedule == "cosine_decay_to_constant" and lr_scale_ratio < 1.0:
+            raise AssertionError(f"lr_scale_ratio {lr_scale_ratio} < 1")           # reference lr_scheduler.py:31 asserts the same
+        self.steps_per_call = int(steps_per_call)
         self.base_lr, self.schedule = base_lr, schedule
         self.warmup, self.total = int(num_warmup_steps), num_training_steps
         self.final = 1.0 / lr_scale_ratio
@@ -49,8 +57,10 @@ class LRSchedule:
         """learning rate of the NEXT optimizer step (torch LambdaLR semantics: lr after k scheduler steps = base * factor(k))"""
         return self.base_lr * self.factor(self.last_step)
 
-    def step(self):
-        self.last_step += 1
+    def step(self, applied=True):
+        """one optimizer step of the job; `applied=False` = the loss scaler skipped it (the schedule does not move)"""
+        if applied:
+            self.last_step += self.steps_per_call
         return self.lr
 
     def state_dict(self):

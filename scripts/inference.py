@@ -2,7 +2,7 @@
 """Text-to-image sampling entry point with the reference's CLI (reference scripts/inference.py:24-44), on the MI355X
 denoiser.  The frozen side nets are outside this repo's scope: captions are read as
 precomputed T5 features (tools/extract_features.py format: .npz with `caption_feature` (1,L,4096) and `attention_mask`
-(1,L)), or encoded with transformers' T5 when `--pipeline_load_from` holds the weights; latents are decoded by the HIP VAE
+(1,L)) from `--caption_feats`, or drawn at random with `--synthetic` (there is no T5 in this repo); latents are decoded by the HIP VAE
 (pixart_sigma_amd.vae.AutoencoderKL, reference inference.py:136,191-196) when the diffusers-format `vae/` directory exists, else
 saved as latents (`--random_vae` decodes with a random-init VAE: plumbing / timing runs without weights).
 
@@ -19,7 +19,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 # The reference samples with fp16 weights for both the denoiser and the VAE (scripts/inference.py:191-196 `weight_dtype = torch.float16`),
 # so this entry point defaults to the fp16-operand build of the kernels (forward parity <= 1e-3 incl. the VAE at 1.5e-3..2.0e-3; the bf16
 # build sits at 3e-3 / 1.4e-2).  The operand type is a per-process choice made before the package is imported: --dtype bf16 overrides.
-_dt = sys.argv[sys.argv.index("--dtype") + 1] if "--dtype" in sys.argv[:-1] else "fp16"
+_early = argparse.ArgumentParser(add_help=False)               # both `--dtype bf16` and `--dtype=bf16`
+_early.add_argument("--dtype", default="fp16")
+_dt = _early.parse_known_args(sys.argv[1:])[0].dtype
 if _dt not in ("fp16", "bf16"):
     raise SystemExit(f"--dtype must be fp16 or bf16, got {_dt!r}")
 os.environ["PXA_OPERAND_DTYPE"] = "f16" if _dt == "fp16" else "bf16"

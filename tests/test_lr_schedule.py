@@ -70,3 +70,25 @@ def test_state_roundtrip_and_reference_checkpoint_key():
     assert t.lr == s.lr and t.last_step == 37
     t.load_state_dict({"last_epoch": 50})          # torch LambdaLR state of a reference checkpoint
     assert t.last_step == 50 and t.lr == 1e-5
+
+
+def test_world_steps_per_optimizer_step_and_skipped_steps():
+    """accelerate's AcceleratedScheduler (the reference prepares its scheduler without split_batches): `world` scheduler steps per optimizer step,
+    none when the GradScaler skipped the step - a 1000-step warm-up is over after 125 optimizer steps on 8 GPUs."""
+    s = LRSchedule(2e-5, "constant", num_warmup_steps=1000, steps_per_call=8)
+    for _ in range(124):
+        s.step()
+    assert s.last_step == 992 and s.lr < 2e-5
+    s.step(applied=False)                     # overflow step: the schedule does not move
+    assert s.last_step == 992
+    s.step()
+    assert s.last_step == 1000 and s.lr == 2e-5
+    t = LRSchedule(2e-5, "constant", num_warmup_steps=1000, steps_per_call=8)
+    t.load_state_dict({"last_epoch": 1000})   # a reference checkpoint written after 125 optimizer steps on 8 GPUs
+    assert t.lr == s.lr
+
+
+def test_cosine_decay_to_constant_rejects_ratio_below_one():
+    import pytest
+    with pytest.raises(AssertionError):
+        LRSchedule(2e-5, "cosine_decay_to_constant", num_warmup_steps=10, num_training_steps=100, lr_scale_ratio=0.7)

@@ -2,7 +2,7 @@
 # dominant kernels.  Writes text/CSV summaries under gpurun_out/; copy the ones to keep into profiles/.
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 tag=${1:-r02}
-rocprofv3 --kernel-trace --stats -d gpurun_out/prof_$tag -o step -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-roofline --no-torch-baseline > gpurun_out/prof_${tag}_step.log 2>&1
+rocprofv3 --kernel-trace --stats -d gpurun_out/prof_$tag -o step -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-roofline --no-torch-baseline --no-other-dtype > gpurun_out/prof_${tag}_step.log 2>&1
 python tools/export_profile.py gpurun_out/prof_$tag/step_results.db gpurun_out/${tag}_step_kernel_stats.csv 3
 rm -rf gpurun_out/prof_$tag
 for ctr in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum"; do

@@ -24,6 +24,21 @@ import torch
 import torch.distributed as dist
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+def _run_config(path, _seen=()):
+    """A reference config file as a dict, with its `_base_` parents (mmcv convention, paths relative to the file: 13 of the reference configs inherit
+    ../PixArt_xl2_internal.py) resolved first and overridden by the child."""
+    path = os.path.abspath(path)
+    if path in _seen:
+        raise SystemExit(f"{path}: circular _base_")
+    ns = runpy.run_path(path)
+    out = {}
+    bases = ns.get("_base_", [])
+    for b in ([bases] if isinstance(bases, str) else bases):
+        out.update(_run_config(os.path.join(os.path.dirname(path), b), _seen + (path,)))
+    out.update({k: v for k, v in ns.items() if not k.startswith("_") and not callable(v) and not isinstance(v, type(os))})
+    return out
+
+
 def _early_dtype():
     """The MFMA operand type is a per-process choice (one library per type) and must be known before pixart_sigma_amd is imported:
     `mixed_precision = 'fp16'` in the config (every reference config: configs/PixArt_xl2_internal.py:57) selects the fp16-operand build +
@@ -31,10 +46,10 @@ def _early_dtype():
     cfgs = [a for a in sys.argv[1:] if a.endswith(".py") and os.path.exists(a)]
     mp = "bf16"
     if cfgs:
-        mp = runpy.run_path(cfgs[0]).get("mixed_precision", "bf16")
-    for i, a in enumerate(sys.argv):
-        if a == "--mixed-precision" and i + 1 < len(sys.argv):
-            mp = sys.argv[i + 1]
+        mp = _run_config(cfgs[0]).get("mixed_precision", "bf16")
+    early = argparse.ArgumentParser(add_help=False)          # both `--mixed-precision fp16` and `--mixed-precision=fp16`
+    early.add_argument("--mixed-precision", default=None)
+    mp = early.parse_known_args(sys.argv[1:])[0].mixed_precision or mp
     if mp not in ("fp16", "bf16"):
         raise SystemExit(f"mixed_precision={mp!r}: this path computes with bf16 or fp16 MFMA operands only")
     if mp == "fp16":
@@ -56,14 +71,18 @@ DEFAULTS = dict(model="PixArtMS_XL_2", image_size=1024, train_batch_size=16, num
                 # schedule / scaling keys of the reference configs (configs/PixArt_xl2_internal.py:34-57)
                 gradient_accumulation_steps=1, auto_lr=None, lr_schedule="constant", lr_schedule_args=dict(num_warmup_steps=0),
                 mixed_precision="bf16", aspect_ratio_type=None, valid_num=0, num_steps_per_epoch=None)
-# keys of reference configs that name subsystems outside this path: accepted and ignored.  Anything else that is
-# not in DEFAULTS raises: a recognised-but-unsupported option must not silently change what is trained.
+# keys of reference configs that name subsystems outside this path and cannot change what is trained: accepted and ignored.
+# Anything else that is not in DEFAULTS raises: a recognised-but-unsupported option must not silently change what is trained.
 IGNORED_KEYS = {"data", "image_list_json", "num_workers", "work_dir", "log_interval", "eval_sampling_steps", "visualize", "resume_from", "load_from",
-                "validation_prompts", "save_model_epochs", "ema_rate", "mask_type", "mask_loss_coef", "multi_scale", "real_prompt_ratio",
-                "window_block_indexes", "window_size", "use_rel_pos", "lewei_scale", "pe_interpolation", "qk_norm", "skip_step", "roots",
-                "vae_pretrained", "load_from", "tracker_project_name", "name", "loss_type", "huber_c", "num_ddim_timesteps", "w_max", "w_min",
-                "ema_decay", "cfg_scale", "image_size", "data_root", "load_mask_index", "aspect_ratio_type", "eval_metric", "use_fsdp", "conditional_dropout",
-                "model_max_length", "max_length"}
+                "validation_prompts", "save_model_epochs", "window_block_indexes", "window_size", "use_rel_pos", "lewei_scale", "pe_interpolation", "roots",
+                "vae_pretrained", "tracker_project_name", "name", "num_ddim_timesteps", "w_max", "w_min", "cfg_scale", "image_size", "data_root",
+                "aspect_ratio_type", "eval_metric", "model_max_length", "max_length"}
+# keys that DO change what is trained and that this path implements for one value only: that value (or absence) is accepted, anything else refused
+# (round-2 ADVICE: real_prompt_ratio = 0.5 of the Sigma configs mixes sharegpt4v captions in; FeatureDatasetMS always takes the real prompt).
+SEMANTIC_KEYS = {"real_prompt_ratio": (1.0,), "qk_norm": (False,), "mask_loss_coef": (0.0, 0), "mask_type": ("null", None), "load_mask_index": (False,),
+                 "loss_type": (None, "mse", "l2"), "huber_c": None, "ema_rate": None, "ema_decay": None, "skip_step": (0,), "conditional_dropout": (False, None),
+                 "multi_scale": None, "use_fsdp": (False,)}      # None = any value: EMA is not kept, huber_c only matters under loss_type 'huber', multi_scale is the
+                                                                  # dataset class choice (the bucketed FeatureDatasetMS handles both)
 
 
 def parse_args():
@@ -103,10 +122,14 @@ def batches(cfg, B, lat, L, dev, rank, world, synthetic):
 def load_config(path, debug=False):
     cfg = dict(DEFAULTS)
     if path:
-        user = {k: v for k, v in runpy.run_path(path).items() if not k.startswith("_") and not callable(v) and not isinstance(v, type(os))}
-        unknown = sorted(k for k in user if k not in DEFAULTS and k not in IGNORED_KEYS)
+        user = _run_config(path)
+        unknown = sorted(k for k in user if k not in DEFAULTS and k not in IGNORED_KEYS and k not in SEMANTIC_KEYS)
         if unknown:
             raise SystemExit(f"{path}: config keys this training path does not implement: {unknown} (supported: {sorted(DEFAULTS)})")
+        bad = {k: user[k] for k, ok in SEMANTIC_KEYS.items() if k in user and ok is not None and user[k] not in ok}
+        if bad:
+            raise SystemExit(f"{path}: these settings change what is trained and only one value is implemented here: "
+                             + ", ".join(f"{k}={v!r} (implemented: {SEMANTIC_KEYS[k][0]!r})" for k, v in bad.items()))
         cfg.update({k: v for k, v in user.items() if k in DEFAULTS})
     if debug:
         cfg.update(train_batch_size=2, log_interval=1)
@@ -177,7 +200,8 @@ def main():
     ratio = 1.0
     if cfg["auto_lr"]:
         o["lr"], ratio = auto_scale_lr(B * world * accum, o["lr"], **cfg["auto_lr"])
-    sched = LRSchedule(o["lr"], cfg["lr_schedule"], lr_scale_ratio=max(ratio, 1.0),
+    # accelerate steps the prepared scheduler `world` times per optimizer step (split_batches=False, the reference's setting): steps_per_call
+    sched = LRSchedule(o["lr"], cfg["lr_schedule"], lr_scale_ratio=ratio, steps_per_call=world,
                        num_training_steps=(cfg["num_steps_per_epoch"] or 0) * cfg["num_epochs"] or None, **(cfg["lr_schedule_args"] or {}))
     scaler = LossScaler(dev) if cfg["mixed_precision"] == "fp16" else None      # GradScaler protocol of accelerate's fp16 mode, on the device
     if o.get("type", "AdamW") in ("CAMEWrapper", "CAME"):      # the optimizer of the PixArt-Sigma configs (reference optimizer.py:242-246)
@@ -211,6 +235,7 @@ def main():
     use_ds = bool(cfg["data_root"]) and not a.synthetic and os.path.exists(os.path.join(cfg["data_root"], "data_info.json"))
     it = feature_batches(cfg, B, L, dev, rank, world) if use_ds else batches(cfg, B, lat, L, dev, rank, world, a.synthetic)
     t0, step = time.time(), start_step
+    sched_skips_seen = scaler.steps_skipped if scaler else 0
     while a.max_steps is None or step < start_step + a.max_steps:
         opt.zero_grad()
         opt.lr = sched.lr
@@ -233,6 +258,10 @@ def main():
         opt.step()
         sched.step()
         step += 1
+        if scaler and step % cfg["log_interval"] == 0:          # accelerate does not advance the schedule on a step the GradScaler skipped; the skip count lives
+            skipped = scaler.steps_skipped                     # on the device, so the schedule is reconciled where the host syncs anyway (skips are rare)
+            sched.last_step -= world * (skipped - sched_skips_seen)
+            sched_skips_seen = skipped
         if step % cfg["log_interval"] == 0 and rank == 0:      # host sync only here (the reference syncs every step, train.py:187)
             extra = f" loss_scale {scaler.value:g} skipped {scaler.steps_skipped}" if scaler else ""
             print(f"step {step} loss {loss.item() * accum:.4f} grad_norm {opt.last_norm.item():.4f} lr {opt.lr:.3e}{extra} "
