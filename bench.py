@@ -224,6 +224,8 @@ def main():
                          "GradScaler) with dynamic loss scaling on the device - the build whose parity tests assert BASELINE.json's <= 1e-3; bf16 = the "
                          "scaler-free build (one bf16 rounding alone is 1.6e-3: it cannot meet that bound).  One library per operand type and process; "
                          "at N = 1 the other build is timed in a subprocess and reported under `other_dtype`.")
+    ap.add_argument("--ragged-text", action="store_true",
+                    help="SURVEY.md section 8d secondary: caption lengths drawn from 12..300 per sample (packed varlen cross-attention) instead of all 300")
     ap.add_argument("--no-other-dtype", action="store_true", help="skip the subprocess run of the other operand build (N = 1 only)")
     ap.add_argument("--no-torch-baseline", action="store_true", help="skip the stock-PyTorch-ROCm leg (N = 1 only)")
     ap.add_argument("--optimizer", choices=["adamw", "came"], default="adamw",
@@ -273,6 +275,11 @@ def main():
     y = torch.randn(B, 1, LTXT, 4096, generator=g).to(dev)
     t = torch.randint(0, 1000, (B,), generator=g).to(dev)
     mask = torch.ones(B, LTXT, dtype=torch.int64)            # host-side mask: no device sync for y_lens
+    if a.ragged_text:
+        lens = torch.randint(12, LTXT + 1, (B,), generator=g)
+        lens[0] = LTXT
+        for i, n in enumerate(lens.tolist()):
+            mask[i, n:] = 0
 
     def step():
         opt.zero_grad()
@@ -314,7 +321,8 @@ def main():
             "dtype": a.dtype, "data": "synthetic",
             "config": {"workload": f"PixArt-Sigma-XL/2 {a.image_size}px training step (fwd+bwd+clip+{'CAME' if a.optimizer == 'came' else 'AdamW'}), batch {B}/GPU, L=300 text tokens, "
                                    f"DP={world} RCCL all-reduce", "model": "PixArtMS_XL_2", "global_batch": B * world, "seq_len": N,
-                       "parallelism": f"dp{world}", "grad_checkpoint": bool(a.grad_checkpoint), "optimizer": a.optimizer},
+                       "parallelism": f"dp{world}", "grad_checkpoint": bool(a.grad_checkpoint), "optimizer": a.optimizer,
+                       "text_lens": "ragged 12..300" if a.ragged_text else "all 300"},
             "steps_per_s_per_gpu": 1.0 / sec_per_step, "images_per_s": B * world / sec_per_step, "final_loss": loss_v, "process_group": "nccl" if use_pg else None,
             **({"loss_scale": scaler.value, "steps_skipped": scaler.steps_skipped} if scaler is not None else {}),
             "step_tflops_per_gpu": flops_step / sec_per_step / 1e12,

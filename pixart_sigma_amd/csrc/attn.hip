@@ -94,6 +94,15 @@ __device__ __forceinline__ void kv_range(const AttnParams& p, int b, long& kbase
 
 __device__ __forceinline__ int soff(int r, int c) { return r * ROWB + ((c ^ ((r >> 2) & 3)) << 4); }
 
+// The wait for this wave's own LDS-DMA pieces is written out (common.h lds_dma16: the compiler does not see the DMA), then the workgroup barrier.
+__device__ __forceinline__ void tile_sync() {
+  lds_dma_wait<0>();
+  __syncthreads();
+}
+// Row fragments loaded from global memory at kernel start: make the compiler wait for them HERE.  Left alone it waits at their first use, inside the
+// tile loop, with a vmcnt that counts only the loads it knows - and with the LDS-DMA invisible to it (lds_dma16) that wait would drain the next tile's
+// DMA in every iteration.
+__device__ __forceinline__ void settle(bf16x8 (&f)[5]) { asm volatile("" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]), "+v"(f[4])); }
 struct DmaPlan { int row[NDMA], coff[NDMA]; };   // per-lane constants: tile row and source element offset of each DMA chunk
 __device__ __forceinline__ void dma_plan(DmaPlan& pl, int wave, int lane) {
 #pragma unroll
@@ -113,23 +122,20 @@ __device__ __forceinline__ void dma_tile(char* lds, const bf16_t* __restrict__ b
     const int gr = FULL ? row0 + pl.row[i] : min(row0 + pl.row[i], nrows - 1);
     const unsigned off = (unsigned)(gr * ts + pl.coff[i]);
     if (pl.coff[i] >= 0)                       // exec-masked: inactive lanes write nothing (LDS address = M0 + lane*16)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + off),
-                                       (__attribute__((address_space(3))) void*)(lds + (i * 4 + wave) * 1024), 16, 0, 0);
+      lds_dma16(base + off, lds + (i * 4 + wave) * 1024);
   }
 }
 // delta folded into dP (dQ kernel).  dS = P (dP - delta) with dP = dO V^T reduced over the head dimension in 5 steps of 16 = 80 slots, of which 72..79 are
 // zero padding: the lane's dO row (registers) carries delta in slots 72 .. 74 (split3: three terms of the operand type, fp32 precision) and the V
 // tiles carry -1.0 there (written once with the pads), so the MFMA returns dP - delta and the 32 subtractions per tile leave the VALU; nothing is added to
 // the matrix work: dQ kernel 1.990 -> 1.916 ms (profiles/r02n_attn_fold_ab.txt).  The dK/dV kernel would have to write delta into the dO tile's pad chunk
-// every tile (its dO rows come by DMA): measured +5 % there, not used.
-// bf16 operands only: delta = rowsum(dO o O) of a loss-scaled fp16 backward can leave the fp16 range (dO itself is kept inside it by the scaler, a sum of
-// 72 products is not), so the fp16-operand build keeps the fp32 subtraction.
+// every tile (its dO rows come by DMA): measured +5 % there; round 3's dK/dV kernel gets them as DMA'd stats rows instead.
+// Both operand builds since round 3.  In the fp16 build a loss-scaled delta = rowsum(dO o O) can in principle leave the fp16 range while dO itself is
+// still inside it (the scaler keeps dO finite, not a sum of 72 products): its leading term then is inf, dS and the gradients are non-finite, and the
+// device-side scaler treats the step exactly like any other overflow - skipped, scale halved (dp.LossScaler, GradScaler's protocol) - i.e. the scale
+// settles at most one notch lower than with an fp32 subtraction.  bench.py's fp16 runs report steps_skipped (0 at the initial 65536).
 #ifndef ATTN_FOLD_DELTA
-#ifdef PXA_OPERAND_F16
-#define ATTN_FOLD_DELTA 0
-#else
 #define ATTN_FOLD_DELTA 1   // 0 = subtract delta on the VALU (A/B builds)
-#endif
 #endif
 #define PXA_OPERAND_MINUS_ONE_X2 (((PXA_OPERAND_ONE_BITS | 0x8000u) << 16) | PXA_OPERAND_ONE_BITS | 0x8000u)
 #define PXA_OPERAND_MINUS_ONE_X1 (PXA_OPERAND_ONE_BITS | 0x8000u)     // {-1.0, 0}
@@ -345,6 +351,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
 
   bf16x8 qf[KSTEPS];
   load_row_frags(qf, p.Q + (long)b * p.q_bs + (long)q * p.q_ts + (long)h * p.q_hs, qvalid, hi);
+  settle(qf);
   DmaPlan pl;
   dma_plan(pl, wave, lane);
   FragAddr fa;
@@ -423,13 +430,13 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_kernel(AttnParams p) {
   };
   if (T > 0) issue(0);
   for (int t = 0; t < Tfull; t++) {
-    __syncthreads();                       // own DMA drained (vmcnt(0)) + stage hand-over; ONE barrier per tile
+    tile_sync();                           // own DMA drained (vmcnt(0)) + stage hand-over; ONE barrier per tile
     if (t + 1 < T) issue(t + 1);
     const char* st = smem + (t & 1) * 2 * TILE_B;
     tile(BoolC<false>{}, st, st + TILE_B, t * BKV);
   }
   if (rem) {                               // ragged last tile: the only place that pays for masking
-    __syncthreads();
+    tile_sync();
     const char* st = smem + (Tfull & 1) * 2 * TILE_B;
     tile(BoolC<true>{}, st, st + TILE_B, Tfull * BKV);
   }
@@ -558,6 +565,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd2_kernel(AttnParams p) {
     q[s] = bx * 256 + wave * 64 + s * 32 + (lane & 31);
     qvalid[s] = q[s] < p.Nq;
     load_row_frags(qf[s], p.Q + (long)b * p.q_bs + (long)q[s] * p.q_ts + (long)h * p.q_hs, qvalid[s], hi);
+    settle(qf[s]);
   }
   DmaPlan pl;
   dma_plan(pl, wave, lane);
@@ -656,13 +664,13 @@ __global__ __launch_bounds__(256, 2) void attn_fwd2_kernel(AttnParams p) {
   };
   if (T > 0) issue(0);
   for (int t = 0; t < Tfull; t++) {
-    __syncthreads();                       // own DMA drained (vmcnt(0)) + stage hand-over; ONE barrier per tile
+    tile_sync();                           // own DMA drained (vmcnt(0)) + stage hand-over; ONE barrier per tile
     if (t + 1 < T) issue(t + 1);
     const char* st = smem + (t & 1) * 2 * TILE_B;
     tile(BoolC<false>{}, st, st + TILE_B, t * BKV);
   }
   if (rem) {
-    __syncthreads();
+    tile_sync();
     const char* st = smem + (Tfull & 1) * 2 * TILE_B;
     tile(BoolC<true>{}, st, st + TILE_B, Tfull * BKV);
   }
@@ -704,6 +712,8 @@ __global__ __launch_bounds__(256, ATTN_BWD_WAVES) void attn_bwd_dq_kernel(AttnPa
   bf16x8 qf[KSTEPS], dof[KSTEPS];
   load_row_frags(qf, p.Q + (long)b * p.q_bs + (long)q * p.q_ts + (long)h * p.q_hs, qvalid, hi);
   load_row_frags(dof, p.dO + (long)b * p.o_bs + (long)q * p.o_ts + (long)h * p.o_hs, qvalid, hi);
+  settle(qf);
+  settle(dof);
   const long sidx = ((long)b * p.H + h) * p.Nq + q;
   const float lse = qvalid ? p.LSE[sidx] : 0.f;
   const float delta = qvalid ? p.Delta[sidx] : 0.f;
@@ -766,13 +776,13 @@ __global__ __launch_bounds__(256, ATTN_BWD_WAVES) void attn_bwd_dq_kernel(AttnPa
   };
   if (T > 0) issue(0);
   for (int t = 0; t < Tfull; t++) {
-    __syncthreads();                       // own DMA drained (vmcnt(0)) + stage hand-over; ONE barrier per tile
+    tile_sync();                           // own DMA drained (vmcnt(0)) + stage hand-over; ONE barrier per tile
     if (t + 1 < T) issue(t + 1);
     const char* st = smem + (t & 1) * 2 * TILE_B;
     tile(BoolC<false>{}, st, st + TILE_B, t * BKV);
   }
   if (rem) {                               // ragged last tile: the only place that pays for masking
-    __syncthreads();
+    tile_sync();
     const char* st = smem + (Tfull & 1) * 2 * TILE_B;
     tile(BoolC<true>{}, st, st + TILE_B, Tfull * BKV);
   }
@@ -801,6 +811,8 @@ __global__ __launch_bounds__(256, ATTN_BWD_WAVES) void attn_bwd_dkv_kernel(AttnP
   bf16x8 kf[KSTEPS], vf[KSTEPS];
   load_row_frags(kf, p.K + kbase + (long)kv * p.k_ts + (long)h * p.k_hs, kvvalid, hi);
   load_row_frags(vf, p.V + vbase + (long)kv * p.v_ts + (long)h * p.v_hs, kvvalid, hi);
+  settle(kf);
+  settle(vf);
   const bf16_t* Qp = p.Q + (long)b * p.q_bs + (long)h * p.q_hs;
   const bf16_t* Dp = p.dO + (long)b * p.o_bs + (long)h * p.o_hs;
   const float* Lp = p.LSE + ((long)b * p.H + h) * p.Nq;
@@ -843,7 +855,7 @@ __global__ __launch_bounds__(256, ATTN_BWD_WAVES) void attn_bwd_dkv_kernel(AttnP
     const char* sD = sQ + TILE_B;
     float* sL = ldsL + (t & 1) * 2 * BKV;
     if (tid < BKV) { sL[tid] = rl; sL[BKV + tid] = rdl; }   // buffer (t&1) was last read two iterations ago
-    __syncthreads();
+    tile_sync();
     if (!(ATTN_ABL & 16) && t + 1 < T) issue(t + 1);
     if (!wave_active) continue;
 #pragma unroll
@@ -935,8 +947,17 @@ template <int OFF> __device__ __forceinline__ void lds_tr_asm(bf16x8& d, unsigne
   d = concat_tr(lo, hi);
 }
 template <int N> __device__ __forceinline__ void lds_wait(bf16x8& d) { asm volatile("s_waitcnt lgkmcnt(%1)" : "+v"(d) : "n"(N)); }
+#ifndef DKV2_WAVES
+#define DKV2_WAVES 2        // A/B: 1 = one workgroup per CU (one wave per SIMD)
+#endif
+#ifndef DKV2_PRIO_X
+#define DKV2_PRIO_X 0       // A/B: s_setprio of the MFMA-dense row-operand regions (0 = never raised)
+#endif
+#ifndef DKV2_MFMA_FIRST
+#define DKV2_MFMA_FIRST 0   // A/B: fence between a slot's MFMA and its fillers (measured 1.4 % slower: profiles/r03f_dkv2_variants.txt)
+#endif
 template <int MODE>
-__global__ __launch_bounds__(256, 2) void attn_bwd_dkv2_kernel(AttnParams p) {
+__global__ __launch_bounds__(256, DKV2_WAVES) void attn_bwd_dkv2_kernel(AttnParams p) {
   __shared__ __attribute__((aligned(16))) char smem[NSTAGE * STAGE_B];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), hi = lane >> 5;
   int bx, h, b;
@@ -951,6 +972,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv2_kernel(AttnParams p) {
   bf16x8 kf[KSTEPS], vf[KSTEPS];
   load_row_frags(kf, p.K + kbase + (long)kv * p.k_ts + (long)h * p.k_hs, kvvalid, hi);
   load_row_frags(vf, p.V + vbase + (long)kv * p.v_ts + (long)h * p.v_hs, kvvalid, hi);
+  settle(kf);
+  settle(vf);
   if (hi == 1) {                                            // k-slots 72 .. 74 (k-step 4, upper half): -1.0 against the stats rows' {hi, mid, lo}
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
     u32x4 w = __builtin_bit_cast(u32x4, kf[KSTEPS - 1]);
@@ -996,10 +1019,8 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv2_kernel(AttnParams p) {
 #pragma unroll
       for (int i = 0; i < NDMA; i++)
         if (pl.coff[i] >= 0) {
-          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(qb + offQ[i]),
-                                           (__attribute__((address_space(3))) void*)(st + (i * 4 + wave) * 1024), 16, 0, 0);
-          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(db + offD[i]),
-                                           (__attribute__((address_space(3))) void*)(st + TILE_B + STAT_B + (i * 4 + wave) * 1024), 16, 0, 0);
+          lds_dma16(qb + offQ[i], st + (i * 4 + wave) * 1024);
+          lds_dma16(db + offD[i], st + TILE_B + STAT_B + (i * 4 + wave) * 1024);
         }
     } else {
       dma_tile<false>(st, Qp, qts, t * BKV, p.Nq, pl, wave);
@@ -1008,7 +1029,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv2_kernel(AttnParams p) {
     if (wave < 2) {
       const bf16_t* src = (wave == 0 ? Ls : Ds) + ((long)t * BKV + lane) * 8;
       char* dst = st + (wave == 0 ? TILE_B : 2 * TILE_B + STAT_B);
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src, (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+      lds_dma16(src, dst);
     }
   };
   auto rowA = [&](const char* tile, int sub, int ks) -> bf16x8 {
@@ -1052,10 +1073,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv2_kernel(AttnParams p) {
   // The wait for this wave's own DMA pieces is written out: the compiler only waits for an LDS-DMA in front of LDS reads IT emits (and at workgroup
   // scope a fence needs no vmcnt), so where the loop's reads are inline asm - or a wave reads nothing at all - __syncthreads() alone compiles to a
   // bare s_barrier and tiles were read before they had landed (round 3, first GPU run: run-to-run different dK in 18 of 256 heads at B16).
-  auto ring_sync = [&]() {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-  };
+  auto ring_sync = [&]() { tile_sync(); };
   issue(0, stage(0));
   if (!wave_active) {                        // serves DMA and barriers only (same barrier count as the compute path)
     int in = 1;
@@ -1141,6 +1159,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv2_kernel(AttnParams p) {
     auto regionX = [&](auto basec, auto asubc, auto prec, auto nsubc, const Bases& ab, unsigned nt0, unsigned nt1) {
       constexpr int BASE = decltype(basec)::value;
       constexpr bool PRE = decltype(prec)::value;
+      if (DKV2_PRIO_X) __builtin_amdgcn_s_setprio(DKV2_PRIO_X);
       static_for<10>([&](auto kc) {
         constexpr int k = decltype(kc)::value;
         lds_wait<(k < 9) ? 1 : (PRE ? 2 : 0)>(f[(k + BASE) % 3]);
@@ -1148,7 +1167,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv2_kernel(AttnParams p) {
         else if constexpr (k == 1) { f32x16 z; for (int g = 0; g < 16; g++) z[g] = 0.f; dp = mfma32(f[(k + BASE) % 3], vf[0], z); }
         else if constexpr (k & 1) dp = mfma32(f[(k + BASE) % 3], vf[k >> 1], dp);
         else s = mfma32(f[(k + BASE) % 3], kf[k >> 1], s);
-        __builtin_amdgcn_sched_barrier(0);       // the MFMA leads its slot: the fillers issue in its shadow
+        if (DKV2_MFMA_FIRST) __builtin_amdgcn_sched_barrier(0);       // the MFMA leads its slot: the fillers issue in its shadow
         if constexpr (k + 2 < 10) rd_row(asubc, IntC<k + 2>{}, f[(k + 2 + BASE) % 3], ab);
         else if constexpr (PRE) rd_tr(nsubc, IntC<k + 2 - 10>{}, f[(k + 2 + BASE) % 3], nt0, nt1);
         __builtin_amdgcn_sched_barrier(0);
@@ -1160,12 +1179,13 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dkv2_kernel(AttnParams p) {
                        bf16x8 (&npb)[2], bf16x8 (&ndb)[2], const Bases& ab) {
       constexpr int BASE = decltype(basec)::value;
       constexpr bool PRE = decltype(prec)::value;
+      if (DKV2_PRIO_X) __builtin_amdgcn_s_setprio(0);
       static_for<12>([&](auto kc) {
         constexpr int k = decltype(kc)::value, uu = k / 6, dt = (k % 6) >> 1;
         lds_wait<(k < 11) ? 2 : (PRE ? 1 : 0)>(f[(k + BASE) % 3]);
         if constexpr (k & 1) dk[dt] = mfma32(f[(k + BASE) % 3], cdb[uu], dk[dt]);
         else dv[dt] = mfma32(f[(k + BASE) % 3], cpb[uu], dv[dt]);
-        __builtin_amdgcn_sched_barrier(0);
+        if (DKV2_MFMA_FIRST) __builtin_amdgcn_sched_barrier(0);
         if constexpr (k + 2 < 12) rd_tr(csubc, IntC<k + 2>{}, f[(k + 2 + BASE) % 3], ct0, ct1);
         else if constexpr (PRE) rd_row(asubc, IntC<k + 2 - 12>{}, f[(k + 2 + BASE) % 3], ab);
         softmax_slot(kc, npb, ndb);

@@ -168,6 +168,26 @@ __device__ __forceinline__ uint4 ld_u4(const void* p) {
   return *reinterpret_cast<const uint4*>(p);
 }
 
+// LDS-DMA (global_load_lds_dwordx4: 16 bytes per lane from a per-lane global address to the wave-uniform LDS address `lds` + 16 lane) issued as inline
+// asm, so that the compiler's waitcnt pass does not know an LDS-DMA is in flight (round 3).  With the builtin it puts `s_waitcnt vmcnt(0)` in front of
+// every ds_read_b64_tr_b16 that follows (the transpose-read intrinsic's memory operand has no alias scope; plain LDS loads have one and are left
+// alone): the persistent GEMM's NN / TN main loops drained their four-deep DMA ring once per k-unit, the attention kernels waited for the NEXT tile's
+// DMA at their first transpose read of the current one.  The price: the compiler no longer waits for a DMA at all - every consumer barrier must be
+// preceded by an EXPLICIT `s_waitcnt vmcnt(N)` (lds_dma_wait / the GEMM's wait_vmcnt<N>).  M0 is written inside the statement (s_nop: the M0 hazard of
+// LDS-DMA); no kernel that uses this helper may also use the builtin (the compiler tracks M0 only for its own).  PXA_ASM_DMA = 0: the builtin (A/B).
+#ifndef PXA_ASM_DMA
+#define PXA_ASM_DMA 1
+#endif
+__device__ __forceinline__ void lds_dma16(const void* gptr, const char* lds) {
+#if PXA_ASM_DMA
+  const unsigned l = (unsigned)(uintptr_t)LDS_PTR(const char, lds);
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(l), "v"(gptr) : "memory");
+#else
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gptr, (__attribute__((address_space(3))) void*)lds, 16, 0, 0);
+#endif
+}
+template <int N> __device__ __forceinline__ void lds_dma_wait() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
 __device__ __forceinline__ float half_wave_sum(float v) {  // reduce inside each 32-lane half
   v += __shfl_xor(v, 16); v += __shfl_xor(v, 8); v += __shfl_xor(v, 4); v += __shfl_xor(v, 2); v += __shfl_xor(v, 1);
   return v;

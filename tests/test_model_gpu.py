@@ -28,6 +28,11 @@ FWD_DEEP_TOL = 1e-3 if F16 else 2e-2            # depth-28 XL/2 (error grows wit
 SAMPLE_TOL = 2e-3 if F16 else 2e-2              # 2-step CFG-4.5 sampler amplifies the forward error
 LOSS_TOL = 1e-3 if F16 else 5e-3
 GRAD_TOL = 1.2e-3 if F16 else 3e-2          # fp16: worst tensor measured 1.08e-3 (cross-attention q gradient: dP - delta cancellation)
+# Full depth (train_xl2_1024_b1): rounding noise accumulates over 28 blocks of backward.  The yardstick is the REFERENCE's own mixed-precision path
+# (oracle/ref_fp16_noise.py -> profiles/r03_reference_fp16_autocast_grad_noise.txt: the unmodified reference under torch.autocast(float16) against its own
+# fp32 run on the same inputs): worst tensor 1.19e-3 (y_embedder fc1), cross_attn.q_linear 1.09e-3, at depth 2 up to 1.29e-3.  This path measures
+# 1.26e-3 worst (blocks.5.mlp.fc1.weight), q_linear 1.06e-3 - the same noise floor; the bound sits just above both.
+GRAD_TOL_DEEP = 1.5e-3 if F16 else 3e-2
 
 
 @pytest.fixture(scope="module", autouse=True)
@@ -184,7 +189,7 @@ def test_training_step_loss_and_grads(golden, gname):
     worst.sort(reverse=True)
     for w in worst[:8]:
         print("grad err (max, norm, elementwise) %.2e %.2e %.2e %s" % w)
-    assert worst[0][0] < GRAD_TOL, worst[0]
+    assert worst[0][0] < (GRAD_TOL_DEEP if cfg.depth > 2 else GRAD_TOL), worst[0]
     # gradients live in the flat buffer the fused optimizer / all-reduce work on
     st = m._store
     assert all(p.grad.data_ptr() == st.grad.data_ptr() + 4 * st.offset[n] for n, p in st.params.items())
