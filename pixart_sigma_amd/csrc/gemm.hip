@@ -623,7 +623,7 @@ __device__ __forceinline__ void mfma_abl16(f32x4 (&q)[4], bf16x8 b0, bf16x8 a0, 
 #define GEMM_NT_STORE 0     // bf16 output rows of the persistent kernel as non-temporal stores (A/B builds)
 #endif
 #ifndef GEMM_M16_PRIO
-#define GEMM_M16_PRIO 1     // s_setprio 1 around the 16-row matrix phases (0: none; A/B builds)
+#define GEMM_M16_PRIO 1     // s_setprio 1 around the 16-row matrix phases of the NT instances (0: none; A/B builds).  NN measured +1.2 % WITHOUT it (profiles/r03h_kbench_gemm_variants.txt)
 #endif
 #ifndef GEMM_PHASE16
 #define GEMM_PHASE16 -1     // matrix phases per k-unit: -1 = per layout (below), 0 = two 8-MFMA phases everywhere, 1 = one 16-MFMA phase everywhere
@@ -988,12 +988,12 @@ __global__ __launch_bounds__(512) void gemm_pers_kernel(GemmParams p) {
         else if (REM == 1) wait_vmcnt<0>();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         PXA_SB(); __builtin_amdgcn_s_barrier(); PXA_SB();
-        if (GEMM_M16_PRIO) __builtin_amdgcn_s_setprio(1);
+        if (GEMM_M16_PRIO && LAYOUT != 1) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int i = 0; i < 4 * TH; i++)
 #pragma unroll
           for (int j = 0; j < 2 * TN; j++) acc4[i][j] = mfma16(bq[j], aq[i], acc4[i][j]);
-        if (GEMM_M16_PRIO) __builtin_amdgcn_s_setprio(0);
+        if (GEMM_M16_PRIO && LAYOUT != 1) __builtin_amdgcn_s_setprio(0);
         PXA_SB(); __builtin_amdgcn_s_barrier(); PXA_SB();
         return;
       }

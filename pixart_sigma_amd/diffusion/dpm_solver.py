@@ -39,7 +39,22 @@ class NoiseScheduleVP:
         return la - 0.5 * torch.log(1.0 - torch.exp(2.0 * la))
 
 
+def _capturing():
+    return torch.cuda.is_available() and torch.cuda.is_current_stream_capturing()
+
+
 class DPM_Solver:
+    def _captions(self):
+        """[uncondition ; condition] as ONE tensor that keeps its identity over the sampler's steps (rebuilt only when either source was modified in
+        place): the denoiser's inference cache of text-only work (engine.Engine._text_cache: caption MLP + 28 cross-attention kv_linear GEMMs) keys on it."""
+        ver = (self.uncondition._version, self.condition._version, self.uncondition.data_ptr(), self.condition.data_ptr())
+        if getattr(self, "_cap", None) is None or self._cap[0] != ver or _capturing():
+            cap = torch.cat([self.uncondition, self.condition])
+            if _capturing():
+                return cap
+            self._cap = (ver, cap)
+        return self._cap[1]
+
     def __init__(self, model, noise_schedule, condition, uncondition, cfg_scale, model_kwargs):
         self.model, self.ns = model, noise_schedule
         self.condition, self.uncondition, self.cfg_scale = condition, uncondition, cfg_scale
@@ -51,7 +66,7 @@ class DPM_Solver:
         t_in = torch.full((B,), (t_cont - 1.0 / self.ns.total_N) * 1000.0, device=x.device, dtype=torch.float32)   # :280
         if self.cfg_scale == 1.0 or self.uncondition is None:
             return self.model(x, t_in, self.condition, **self.model_kwargs)
-        out = self.model(torch.cat([x] * 2), torch.cat([t_in] * 2), torch.cat([self.uncondition, self.condition]), **self.model_kwargs)
+        out = self.model(torch.cat([x] * 2), torch.cat([t_in] * 2), self._captions(), **self.model_kwargs)
         e_u, e_c = out.chunk(2)
         return e_u + self.cfg_scale * (e_c - e_u)
 

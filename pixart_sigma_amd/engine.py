@@ -19,6 +19,8 @@ gradients are accumulated straight into the flat fp32 gradient buffer (ParamStor
 """
 import math
 
+import os
+
 import numpy as np
 import torch
 
@@ -42,6 +44,10 @@ def sincos_pos_embed(embed_dim, h, w, pe_interpolation, base_size):
         out = np.einsum("m,d->md", pos.reshape(-1), omega)
         return np.concatenate([np.sin(out), np.cos(out)], axis=1)
     return np.concatenate([enc(gw), enc(gh)], axis=1)
+
+
+def _capturing():
+    return torch.cuda.is_available() and torch.cuda.is_current_stream_capturing()
 
 
 class ParamStore:
@@ -160,6 +166,11 @@ class Engine:
         self.S, self.cfg = store, cfg
         self._pos_cache = {}
         self._len_cache = {}
+        # Inference-only cache of everything that depends on the text alone: the caption MLP output and every block's cross-attention K / V
+        # (kv_linear of the packed caption rows).  A sampler calls the model 20+ times with the SAME caption tensor (scripts/inference.py,
+        # DPM_Solver.sample): those 1 + depth GEMMs per call (28 of them on M <= 4,800 rows: the 512px inference tail) run once.
+        # Key = identity + version of y / the drop mask / y_null and the lengths; any training forward (save != None) clears it - weights may change.
+        self._text_cache = None
         self.grad_ready_hook = None   # callable(prefix) fired when a parameter group's gradients are complete
 
     # ------------------------------------------------------------------ helpers
@@ -255,7 +266,11 @@ class Engine:
         x1, x1b = r["x"], r["xb"]
         qc = self._lin(x1b, p + "cross_attn.q_linear")
         ye = ctx["ye"]
-        kvc = self._lin(ye, p + "cross_attn.kv_linear")
+        kvc = ctx["kvc"][l] if ctx.get("kvc") is not None else None      # inference: constant over the sampler's steps (Engine._text_cache)
+        if kvc is None:
+            kvc = self._lin(ye, p + "cross_attn.kv_linear")
+            if ctx.get("kvc") is not None:
+                ctx["kvc"][l] = kvc
         cr = torch.empty((B * N, D), dtype=BF16, device=qkv.device)
         lse_c = torch.empty((B, H, N), dtype=F32, device=qkv.device)
         sc_str = ((N * D, D, 72), (0, 2 * D, 72), (0, 2 * D, 72), (N * D, D, 72))
@@ -375,7 +390,22 @@ class Engine:
         kv_len, kv_start = self._len_cache[lk]
         ctx = dict(B=B, N=N, hw=(h, w), mod=mod, kv_len=kv_len, kv_start=kv_start, max_len=int(max(lens)))
         L = y.shape[0] // B
-        ye, cap_saved = self.caption_fwd(y, row_idx, L, drop, y_null)
+        tkey = None
+        if save or torch.is_grad_enabled():
+            self._text_cache = None
+        elif _capturing() or os.environ.get("PXA_TEXT_CACHE", "1") == "0":
+            pass                                  # a captured graph must own every buffer it reads: no cache inside sample_graphed's capture
+        else:
+            tkey = (y.data_ptr(), y._version, tuple(y.shape), lk, None if drop is None else (drop.data_ptr(), drop._version),
+                    None if y_null is None else (y_null.data_ptr(), y_null._version), row_idx.data_ptr())
+        if tkey is not None and self._text_cache is not None and self._text_cache["key"] == tkey:
+            ye, cap_saved = self._text_cache["ye"], None
+            ctx["kvc"] = self._text_cache["kvc"]
+        else:
+            ye, cap_saved = self.caption_fwd(y, row_idx, L, drop, y_null)
+            if tkey is not None:
+                ctx["kvc"] = [None] * depth
+                self._text_cache = dict(key=tkey, ye=ye, kvc=ctx["kvc"], y=y)      # holds y so that its address cannot be reused by another tensor
         ctx["ye"] = ye
         xt = ops.patch_embed_fwd(x, S.f("x_embedder.proj.weight"), S.f("x_embedder.proj.bias"), self.pos_table(h, w))
         x_prev, u_prev, gate_prev = xt, None, None

@@ -228,6 +228,36 @@ def test_dpm_solver_sampling_matches_reference(golden):
     assert e < (SAMPLE_TOL if F16 else FWD_F32_TOL)
 
 
+def test_inference_text_cache_is_exact_and_invalidated(golden, monkeypatch):
+    """engine.Engine._text_cache (round 3): the caption MLP and the 28 cross-attention kv_linear outputs depend on the text alone, so a sampler's
+    steps reuse them.  Same sample bit for bit with the cache off; a different caption tensor, an in-place edit of the same one, and a training
+    forward in between (weights may have changed) all miss."""
+    from pixart_sigma_amd import DPMS
+    g = golden("dpms_d2")
+    cfg, sd, inp, mask, m = _build(g)
+    gen = torch.Generator().manual_seed(g["null_seed"])
+    null_y = torch.randn(1, 1, g["inputs"]["L"], 4096, generator=gen).repeat(inp["x"].shape[0], 1, 1, 1).cuda()
+    y = inp["y"].cuda()
+    kw = dict(steps=3, order=2, skip_type="time_uniform", method="multistep")
+    x = inp["x"].cuda()
+    with torch.no_grad():
+        solver = DPMS(m.forward_with_dpmsolver, condition=y, uncondition=null_y, cfg_scale=4.5, model_kwargs=dict(data_info=None, mask=mask))
+        a = solver.sample(x, **kw)
+        assert m._engine._text_cache is not None and all(k is not None for k in m._engine._text_cache["kvc"])
+        monkeypatch.setenv("PXA_TEXT_CACHE", "0")
+        b = DPMS(m.forward_with_dpmsolver, condition=y, uncondition=null_y, cfg_scale=4.5, model_kwargs=dict(data_info=None, mask=mask)).sample(x, **kw)
+        monkeypatch.delenv("PXA_TEXT_CACHE")
+        assert torch.equal(a, b)
+        key0 = m._engine._text_cache["key"]
+        y.mul_(0.5)                                           # in-place edit of the caption tensor: version bump -> miss -> different sample
+        c = solver.sample(x, **kw)
+        assert m._engine._text_cache["key"] != key0 and not torch.equal(c, a)
+    m.train()
+    from pixart_sigma_amd import IDDPM
+    IDDPM(str(1000)).training_losses(m, x, inp["t"].cuda(), model_kwargs=dict(y=y, mask=mask.cuda()), noise=inp["noise"].cuda())["loss"].mean().backward()
+    assert m._engine._text_cache is None                      # any training forward drops it
+
+
 def test_dpm_solver_graphed_loop_replays_bit_exact(golden):
     """the sampling loop captured as one HIP graph reproduces the eager loop bit for bit, also for new latents."""
     from pixart_sigma_amd import DPMS
