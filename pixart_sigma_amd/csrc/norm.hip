@@ -274,6 +274,11 @@ __global__ __launch_bounds__(CS_CT * CS_RL) void colsum_kernel(const bf16_t* __r
   const int c = (blockIdx.x * CS_CT + ct) * 8;
   const int r0 = blockIdx.y * rows_per_block, r1 = min(R, r0 + rows_per_block);
   float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  // (1, 0) and (0, 1) in the operand type, kept in registers the compiler cannot see through: as a literal, 0x00003f80 is emitted as the INLINE constant
+  // "1.0" of v_dot2c_f32_bf16, which the hardware expands to fp32 1.0 = 0x3f800000 - i.e. (0, 1), the wrong half (first GPU run of this loop: every
+  // even column received its odd neighbour's sum).
+  uint32_t one_lo = PXA_OPERAND_ONE_BITS, one_hi = PXA_OPERAND_ONE_BITS << 16;
+  asm volatile("" : "+s"(one_lo), "+s"(one_hi));
   if (c < N) {
     for (int r = r0 + rl; r < r1; r += 8 * CS_RL) {
       uint4 v[8];
@@ -289,8 +294,8 @@ __global__ __launch_bounds__(CS_CT * CS_RL) void colsum_kernel(const bf16_t* __r
         const uint32_t w[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
 #pragma unroll
         for (int j = 0; j < 4; j++) {
-          acc[2 * j] = dot2_acc(w[j], PXA_OPERAND_ONE_BITS, acc[2 * j]);
-          acc[2 * j + 1] = dot2_acc(w[j], PXA_OPERAND_ONE_BITS << 16, acc[2 * j + 1]);
+          acc[2 * j] = dot2_acc(w[j], one_lo, acc[2 * j]);
+          acc[2 * j + 1] = dot2_acc(w[j], one_hi, acc[2 * j + 1]);
         }
       }
     }
