@@ -592,7 +592,7 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_
 #endif
 template <bool ON>
 __device__ __forceinline__ int opaque(int v) {
-  if constexpr (ON && GEMM_OPAQUE) asm volatile("" : "+v"(v));
+  if constexpr ((ON && GEMM_OPAQUE) || GEMM_OPAQUE == 2) asm volatile("" : "+v"(v));
   return v;
 }
 
