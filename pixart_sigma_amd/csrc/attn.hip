@@ -693,6 +693,9 @@ __global__ __launch_bounds__(256, 2) void attn_fwd2_kernel(AttnParams p) {
 #ifndef PXA_ATTN_DKV_DEFAULT
 #define PXA_ATTN_DKV_DEFAULT 2
 #endif
+#ifndef PXA_ATTN_DQ_DEFAULT
+#define PXA_ATTN_DQ_DEFAULT 1
+#endif
 #ifndef ATTN_ABL
 #define ATTN_ABL 0      // ablation study of the dK/dV kernel (tools/build_variant.py; results in profiles/r02_attention_bwd_experiments.md):
 #endif                  // 1 no softmax VALU, 2 no dV/dK MFMAs, 4 no S/dP MFMAs, 8 no LDS fragment reads, 16 no LDS-DMA.  0 = the product kernel.
@@ -1222,6 +1225,211 @@ __global__ __launch_bounds__(256, DKV2_WAVES) void attn_bwd_dkv2_kernel(AttnPara
   if (p.dv_colsum) colsum_rows(p.dv_colsum + (b % PXA_COLSUM_SLOTS) * p.colsum_stride + h * DH, dv, 1.f, kvvalid, hi, lane);
 }
 
+
+// ------------------------------------------------------------------------------------------------ backward: dQ (round 3)
+// attn_bwd_dq_kernel's products, layouts and fragments with the dK/dV kernel's treatment of the instruction stream: a software pipeline over 32-key
+// sub-tiles j, placed by hand in slots {counted lgkmcnt wait; one MFMA; the LDS reads of the MFMA two slots ahead; a slice of the softmax}.
+//   region R (10 slots of v_mfma_f32_32x32x16): A(j+1) - S and dP of the NEXT sub-tile into the other S / dP register set (fragment k = 2 ks + w;
+//            w = 0: K rows -> S, w = 1: V rows -> dP - delta) - with B(j), the softmax of the current one, in their shadow: exp2 + the dP multiply of
+//            elements 2k, 2k+1 in slots 0..7 (6 VALU), the eight cvt_pk in slot 8, the four v_permlane16_swap in slot 9
+//   region C (10 slots of v_mfma_f32_16x16x32): dQ^T += K^T dS^T of sub-tile j (5 transpose-read fragments, each feeding the x and the y MFMA)
+// Iteration (tile t of 64 keys) = barrier; DMA of tile t+2; R: A(t, 1) || B(t, 0); C(t, 0); R: A(t+1, 0) || B(t, 1); C(t, 1): tile t+1 is read while
+// tile t is still in use, hence a three-stage ring {K, V} (72 KiB, two workgroups per CU), and nothing is in flight at the back edge.  Full tiles
+// only; a ragged last tile (text keys) runs the compiler-scheduled masked path after the loop.  delta rides in the dP product (ATTN_FOLD_DELTA).
+__global__ __launch_bounds__(256, 2) void attn_bwd_dq2_kernel(AttnParams p) {
+  __shared__ __attribute__((aligned(16))) char smem[NSTAGE * 2 * TILE_B];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), hi = lane >> 5;
+  int bx, h, b;
+  block_coords(p, bx, h, b);
+  const int q = bx * 128 + wave * 32 + (lane & 31);
+  const bool qvalid = q < p.Nq;
+  long kbase, vbase, d0_, d1_; int kvlen;
+  kv_range(p, b, kbase, vbase, d0_, d1_, kvlen);
+  const bf16_t* Kp = p.K + kbase + (long)h * p.k_hs;
+  const bf16_t* Vp = p.V + vbase + (long)h * p.v_hs;
+  const int kts = (int)p.k_ts, vts = (int)p.v_ts;
+
+  bf16x8 qf[KSTEPS], dof[KSTEPS];
+  load_row_frags(qf, p.Q + (long)b * p.q_bs + (long)q * p.q_ts + (long)h * p.q_hs, qvalid, hi);
+  load_row_frags(dof, p.dO + (long)b * p.o_bs + (long)q * p.o_ts + (long)h * p.o_hs, qvalid, hi);
+  settle(qf);
+  settle(dof);
+  const long sidx = ((long)b * p.H + h) * p.Nq + q;
+  const float lse = qvalid ? p.LSE[sidx] : 0.f;
+  const float delta = qvalid ? p.Delta[sidx] : 0.f;
+  if (hi == 1) {                                            // slots 72 .. 74 of this lane's dO row: delta as three operand-type terms (split3)
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    u32x4 w = __builtin_bit_cast(u32x4, dof[KSTEPS - 1]);
+    const uint2 d3 = split3(delta);
+    w[0] = d3.x; w[1] = d3.y;
+    dof[KSTEPS - 1] = __builtin_bit_cast(bf16x8, w);
+  }
+  DmaPlan pl;
+  dma_plan(pl, wave, lane);
+  FragAddr fa;
+  frag_addr(fa, lane);
+  Tr16Addr ta;
+  tr16_addr(ta, lane);
+  for (int st = 0; st < 2 * NSTAGE; st++) init_pads(smem + st * TILE_B, (st & 1) ? 2 : 0, tid);   // odd tiles = V: -1.0 in slots 72 .. 74
+  Acc16 dq;
+  zero16(dq);
+  const float c = p.scale_log2;
+  const int Tfull = kvlen / BKV, rem = kvlen - Tfull * BKV, T = Tfull + (rem ? 1 : 0);
+  auto stage = [&](int i) -> char* { return smem + i * 2 * TILE_B; };
+  auto issue = [&](int t, char* st) {
+    if (t < Tfull) {
+      dma_tile<true>(st, Kp, kts, t * BKV, kvlen, pl, wave);
+      dma_tile<true>(st + TILE_B, Vp, vts, t * BKV, kvlen, pl, wave);
+    } else {
+      dma_tile<false>(st, Kp, kts, t * BKV, kvlen, pl, wave);
+      dma_tile<false>(st + TILE_B, Vp, vts, t * BKV, kvlen, pl, wave);
+    }
+  };
+  // the compiler-scheduled tile of attn_bwd_dq_kernel: prologue sub-tile, pipeline drain and the ragged last tile
+  auto firstA = [&](const char* sK, const char* sV, int sub, f32x16& sv, f32x16& dpv) {
+#pragma unroll
+    for (int g = 0; g < 16; g++) { sv[g] = 0.f; dpv[g] = 0.f; }
+#pragma unroll
+    for (int ks = 0; ks < KSTEPS; ks++) {
+      sv = mfma32(rowfrag(sK, fa, sub, ks), qf[ks], sv);
+      dpv = mfma32(rowfrag(sV, fa, sub, ks), dof[ks], dpv);
+    }
+  };
+  auto tail_tile = [&](const char* sK, const char* sV, int kv0) {
+    f32x16 sv[2], dpv[2];
+#pragma unroll
+    for (int sub = 0; sub < 2; sub++) firstA(sK, sV, sub, sv[sub], dpv[sub]);
+#pragma unroll
+    for (int sub = 0; sub < 2; sub++)
+#pragma unroll
+      for (int g = 0; g < 16; g++) {
+        float pr = __builtin_amdgcn_exp2f(sv[sub][g] * c - lse);
+        if (kv0 + sub * 32 + (g & 3) + 8 * (g >> 2) + 4 * hi >= kvlen) pr = 0.f;
+        sv[sub][g] = pr * dpv[sub][g];
+      }
+#pragma unroll
+    for (int sub = 0; sub < 2; sub++) {
+      bf16x8 dx, dy;
+      pack_xy(sv[sub], dx, dy);
+      mma16(dq, sK, ta, sub, dx, dy);
+    }
+  };
+
+  if (T > 0) issue(0, stage(0));
+  if (T > 1) issue(1, stage(1));
+  if (Tfull > 0) {
+    const unsigned lds0 = (unsigned)(uintptr_t)LDS_PTR(char, smem);
+    f32x16 S[2], DP[2];
+    bf16x8 dx, dy, f[3];
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    u32x4 ua, ub;                                            // pack_xy split over two slots: the cvt_pk half, then the lane exchange
+    struct RowB { unsigned r0, r1; };
+    struct TrB { unsigned t00, t01, t10, t11; };             // [read e][tile parity]
+    auto rowb = [&](unsigned st) -> RowB { return RowB{st + (unsigned)fa.rb[0], st + (unsigned)fa.rb[1]}; };
+    auto trb = [&](unsigned st) -> TrB { return TrB{st + (unsigned)ta.tb[0][0], st + (unsigned)ta.tb[0][1], st + (unsigned)ta.tb[1][0], st + (unsigned)ta.tb[1][1]}; };
+    auto rd_row = [&](auto subc, auto kc, bf16x8& d, const RowB& rb) {       // row fragment k = 2 ks + w of sub-tile SUB: w = 0 K tile, w = 1 V tile
+      constexpr int sub = decltype(subc)::value, k = decltype(kc)::value, ks = k >> 1, w = k & 1;
+      lds_row_asm<w * TILE_B + sub * 32 * ROWB + (ks >> 1) * 64>(d, (ks & 1) ? rb.r1 : rb.r0);
+    };
+    auto rd_tr = [&](auto subc, auto tc, bf16x8& d, const TrB& tb) {         // K^T fragment of output tile t (16 head dims) of sub-tile SUB
+      constexpr int sub = decltype(subc)::value, t = decltype(tc)::value;
+      lds_tr_asm<sub * 32 * ROWB + (t >> 1) * 64>(d, (t & 1) ? tb.t01 : tb.t00, (t & 1) ? tb.t11 : tb.t10);
+    };
+    auto softmax_slot = [&](auto kc, f32x16& sv, f32x16& dpv) {
+      constexpr int k = decltype(kc)::value;
+      if constexpr (k < 8) {
+        sv[2 * k] = __builtin_amdgcn_exp2f(sv[2 * k] * c - lse) * dpv[2 * k];         // dS^T (without the softmax scale, applied at the store)
+        sv[2 * k + 1] = __builtin_amdgcn_exp2f(sv[2 * k + 1] * c - lse) * dpv[2 * k + 1];
+        asm volatile("" : "+v"(sv[2 * k]), "+v"(sv[2 * k + 1]));
+      }
+      if constexpr (k == 8) {                                 // pack_xy, first half: a = rows {0-3, 16-19} + 4 hi, b = rows {8-11, 24-27} + 4 hi
+        bf16x8 a, bb;
+#pragma unroll
+        for (int j = 0; j < 4; j++) { a[j] = (bf16_t)sv[j]; a[4 + j] = (bf16_t)sv[8 + j]; bb[j] = (bf16_t)sv[4 + j]; bb[4 + j] = (bf16_t)sv[12 + j]; }
+        ua = __builtin_bit_cast(u32x4, a);
+        ub = __builtin_bit_cast(u32x4, bb);
+        asm volatile("" : "+v"(ua), "+v"(ub));
+      }
+      if constexpr (k == 9) {
+        u32x4 ux, uy;
+#pragma unroll
+        for (int w = 0; w < 4; w++) {
+          const auto r = __builtin_amdgcn_permlane16_swap(ua[w], ub[w], false, false);
+          ux[w] = r[0]; uy[w] = r[1];
+        }
+        dx = __builtin_bit_cast(bf16x8, ux);
+        dy = __builtin_bit_cast(bf16x8, uy);
+        asm volatile("" : "+v"(dx), "+v"(dy));
+      }
+    };
+    // R: A(sub ASUB of the stage behind `ab`) -> S[NB], DP[NB] || B on S[CB], DP[CB]; fragments 0, 1 in flight on entry (f[0], f[1]); its last two
+    // slots load transpose fragments 0, 1 of C(sub CSUB, bases ct)
+    auto regionR = [&](auto asubc, auto nbc, auto csubc, const RowB& ab, const TrB& ct) {
+      constexpr int NB = decltype(nbc)::value, CB = 1 - NB;
+      static_for<10>([&](auto kc) {
+        constexpr int k = decltype(kc)::value, ks = k >> 1;
+        lds_wait<(k < 9) ? 1 : 2>(f[k % 3]);
+        if constexpr (k & 1) {
+          if constexpr (ks == 0) { f32x16 z; for (int g = 0; g < 16; g++) z[g] = 0.f; DP[NB] = mfma32(f[k % 3], dof[0], z); }
+          else DP[NB] = mfma32(f[k % 3], dof[ks], DP[NB]);
+        } else {
+          if constexpr (ks == 0) { f32x16 z; for (int g = 0; g < 16; g++) z[g] = 0.f; S[NB] = mfma32(f[k % 3], qf[0], z); }
+          else S[NB] = mfma32(f[k % 3], qf[ks], S[NB]);
+        }
+        if constexpr (k + 2 < 10) rd_row(asubc, IntC<k + 2>{}, f[(k + 2) % 3], ab);
+        else rd_tr(csubc, IntC<k + 2 - 10>{}, f[(k + 2) % 3], ct);
+        softmax_slot(kc, S[CB], DP[CB]);
+        __builtin_amdgcn_sched_barrier(0);
+      });
+    };
+    // C: dQ^T += K^T dS^T of sub-tile CSUB; transpose fragment i sits in f[(i + 1) % 3] (10 row fragments went before); PRE: its last two fragment
+    // slots load row fragments 0, 1 of the next A (sub ASUB of the stage behind `ab`)
+    auto regionC = [&](auto csubc, auto prec, auto asubc, const TrB& ct, const RowB& ab) {
+      constexpr bool PRE = decltype(prec)::value;
+      static_for<10>([&](auto kc) {
+        constexpr int k = decltype(kc)::value, fi = k >> 1;
+        if constexpr ((k & 1) == 0) {
+          lds_wait<(fi < 4) ? 2 : (PRE ? 1 : 0)>(f[(fi + 1) % 3]);
+          dq.v[fi][0] = mfma16(f[(fi + 1) % 3], dx, dq.v[fi][0]);
+          if constexpr (fi + 2 < NT16) rd_tr(csubc, IntC<fi + 2>{}, f[(fi + 3) % 3], ct);
+          else if constexpr (PRE) rd_row(asubc, IntC<fi + 2 - NT16>{}, f[(fi + 3) % 3], ab);
+        } else {
+          dq.v[fi][1] = mfma16(f[(fi + 1) % 3], dy, dq.v[fi][1]);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      });
+    };
+    tile_sync();                                             // tiles 0 (and 1) have landed, pads written
+    firstA(stage(0), stage(0) + TILE_B, 0, S[0], DP[0]);     // A(0, 0), cold
+    int ic = 0;
+    for (int t = 0; t < Tfull; t++) {
+      const int in = ic == NSTAGE - 1 ? 0 : ic + 1;
+      if (t > 0) tile_sync();                                // tile t+1 has landed; every wave has left the stage of tile t-1
+      if (t + 2 < T) issue(t + 2, stage(in == NSTAGE - 1 ? 0 : in + 1));
+      const unsigned cur = lds0 + ic * 2 * TILE_B, nxt = lds0 + ((t + 1 < Tfull) ? in : ic) * 2 * TILE_B;   // last full tile: A(t+1, 0) re-reads tile t (unused)
+      const RowB crb = rowb(cur), nrb = rowb(nxt);
+      const TrB ctb = trb(cur);
+      __builtin_amdgcn_sched_barrier(0);
+      rd_row(IntC<1>{}, IntC<0>{}, f[0], crb);               // cold start: row fragments 0, 1 of A(t, 1)
+      rd_row(IntC<1>{}, IntC<1>{}, f[1], crb);
+      __builtin_amdgcn_sched_barrier(0);
+      regionR(IntC<1>{}, IntC<1>{}, IntC<0>{}, crb, ctb);                   // A(t, 1) -> S[1] || B(t, 0) on S[0]      -> tr of C(t, 0)
+      regionC(IntC<0>{}, BoolC<true>{}, IntC<0>{}, ctb, nrb);                // C(t, 0)                                 -> rows of A(t+1, 0)
+      regionR(IntC<0>{}, IntC<0>{}, IntC<1>{}, nrb, ctb);                   // A(t+1, 0) -> S[0] || B(t, 1) on S[1]    -> tr of C(t, 1)
+      regionC(IntC<1>{}, BoolC<false>{}, IntC<0>{}, ctb, nrb);               // C(t, 1)
+      ic = in;
+    }
+    if (rem) tail_tile(stage(ic), stage(ic) + TILE_B, Tfull * BKV);         // landed and visible since the last iteration's barrier
+  } else if (rem) {
+    tile_sync();
+    tail_tile(stage(0), stage(0) + TILE_B, 0);
+  }
+  const int q0w = bx * 128 + wave * 32;
+  const bool ok0 = q0w + (lane & 15) < p.Nq, ok1 = q0w + 16 + (lane & 15) < p.Nq;
+  store_rows16(p.dQ + (long)b * p.dq_bs + (long)q0w * p.dq_ts + (long)h * p.dq_hs, p.dq_ts, dq, p.scale, p.scale, ok0, ok1, lane);
+  if (p.dq_colsum) colsum_rows16(p.dq_colsum + (b % PXA_COLSUM_SLOTS) * p.colsum_stride + h * DH, dq, p.scale, ok0, ok1, lane);
+}
+
 int fill(AttnParams& p, const pxa_attn_args* a) {
   PXA_CHECK(a, "attn: null args");
   PXA_CHECK(a->head_dim == DH, "attn: head_dim %d unsupported (PixArt XL/2 uses 72)", a->head_dim);
@@ -1297,7 +1505,10 @@ extern "C" int pxa_attn_bwd(const pxa_attn_args* a, hipStream_t stream) {
   if (p.dQ) {
     p.nx = (p.Nq + 127) / 128;
     PXA_CHECK((long)p.nx * p.H * p.B < (1L << 31), "pxa_attn_bwd: grid too large");
-    hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3(p.nx * p.H * p.B), dim3(256), 0, stream, p);
+    const char* dqe = getenv("PXA_ATTN_DQ");                // 0 = round-2 kernel (compiler-scheduled), 1 = hand-placed pipeline (needs the delta fold)
+    const int dq_mode = (dqe ? atoi(dqe) : PXA_ATTN_DQ_DEFAULT) && ATTN_FOLD_DELTA;
+    if (dq_mode) hipLaunchKernelGGL(attn_bwd_dq2_kernel, dim3(p.nx * p.H * p.B), dim3(256), 0, stream, p);
+    else hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3(p.nx * p.H * p.B), dim3(256), 0, stream, p);
     PXA_LAUNCH_CHECK();
   }
   if (p.dK) {

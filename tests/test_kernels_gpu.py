@@ -536,14 +536,16 @@ def test_attention_headline_shapes(ops, B, H, Nq, Nk):
     assert max(errs["dq"], errs["dk"], errs["dv"]) < 2 * BF16_TOL
 
 
-@pytest.mark.parametrize("mode", ["0", "1", "2"])
+@pytest.mark.parametrize("mode,dqm", [("0", "0"), ("1", "1"), ("2", "1"), ("2", "0")])
 @pytest.mark.parametrize("B,H,Nq,Nk,lens", [(2, 3, 130, 77, None), (1, 2, 64, 1024, None), (2, 2, 520, 200, None), (1, 4, 96, 96, None),
-                                             (3, 16, 160, 300, [300, 7, 64]), (2, 16, 1024, 1024, None)])
-def test_attention_dkv_kernel_modes(ops, monkeypatch, mode, B, H, Nq, Nk, lens):
+                                             (3, 16, 160, 300, [300, 7, 64]), (2, 16, 1024, 1024, None), (1, 2, 200, 40, None)])
+def test_attention_dkv_kernel_modes(ops, monkeypatch, mode, dqm, B, H, Nq, Nk, lens):
     """The three dK/dV kernels of csrc/attn.hip (PXA_ATTN_DKV: 0 = round-2 kernel, 1 = lse / delta through the matrix products + three-stage ring,
-    2 = + hand-placed software pipeline with asm LDS reads) against fp32 attention per head: ragged query tiles (Nq % 64 != 0: sentinel stats rows),
-    one / many key blocks, partial key waves, packed varlen text keys with inactive waves, and the bias-gradient column sums."""
+    2 = + hand-placed software pipeline with asm LDS reads) and the two dQ kernels (PXA_ATTN_DQ: 0 = round-2 kernel, 1 = hand-placed pipeline; its ragged
+    last key tile runs the masked compiler-scheduled path) against fp32 attention per head: ragged query tiles (Nq % 64 != 0: sentinel stats rows),
+    one / many key blocks, fewer than 64 keys, partial key waves, packed varlen text keys with inactive waves, and the bias-gradient column sums."""
     monkeypatch.setenv("PXA_ATTN_DKV", mode)
+    monkeypatch.setenv("PXA_ATTN_DQ", dqm)
     C = H * 72
     q, do = bf(_gpu_rnd(B, Nq, C, seed=1)), bf(_gpu_rnd(B, Nq, C, seed=4))
     o = torch.empty(B, Nq, C, dtype=torch.bfloat16, device="cuda")
@@ -575,7 +577,7 @@ def test_attention_dkv_kernel_modes(ops, monkeypatch, mode, B, H, Nq, Nk, lens):
                                            do[b:b + 1].view(1, Nq, H, 72))
             rdq[b], rdk[s0:s0 + n], rdv[s0:s0 + n] = a[0], bk.reshape(n, C), bv.reshape(n, C)
     errs = {"dq": rel_l2(dq.float().view_as(rdq), rdq), "dk": rel_l2(dk.float(), rdk), "dv": rel_l2(dv.float(), rdv)}
-    print(f"\n[dK/dV kernel mode {mode} B{B} H{H} Nq{Nq} Nk{Nk}] " + " ".join(f"{n} {e:.2e}" for n, e in errs.items()))
+    print(f"\n[dK/dV kernel mode {mode}, dQ kernel {dqm}, B{B} H{H} Nq{Nq} Nk{Nk}] " + " ".join(f"{n} {e:.2e}" for n, e in errs.items()))
     assert max(errs.values()) < 2 * BF16_TOL, errs
     for i, ref in enumerate((rdk, rdv)):                        # fused bias-gradient column sums
         got, want = part.sum(0)[i * C:(i + 1) * C], ref.reshape(-1, C).sum(0)
