@@ -1430,6 +1430,236 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq2_kernel(AttnParams p) {
   if (p.dq_colsum) colsum_rows16(p.dq_colsum + (b % PXA_COLSUM_SLOTS) * p.colsum_stride + h * DH, dq, p.scale, ok0, ok1, lane);
 }
 
+
+// ------------------------------------------------------------------------------------------------ backward: dK, dV as a phase ping-pong (round 3, second form)
+// What the hand-placed kernel above could not fix: its two waves per SIMD come from different workgroups, are in-order and uncoordinated - each blocks
+// on the matrix pipe while the partner's MFMA runs and cannot issue its softmax meanwhile (47 cycles per MFMA against a 32-cycle floor).  Here ONE
+// 512-thread workgroup (256 keys) owns the CU: waves w and w + 4 share a SIMD and alternate, in lock-step through s_barrier, between
+//     phase M: C(j) + A(j+1) - 22 MFMAs with their LDS reads, no VALU        and        phase V: B(j+1) - the softmax, no MFMA
+// with waves 4-7 one phase behind waves 0-3, so on every SIMD one wave is in M while the other is in V: the MFMAs of the two never collide and the
+// softmax sits entirely in the partner's matrix phase (the persistent GEMM's two-phase scheme, csrc/gemm.hip).  S / dP are updated in place (B(j) is
+// complete before A(j+1) issues), one packed P / dS set.  The Q / dO tiles are shared by 8 waves (half the LDS-DMA traffic per key).
+//   per wave and tile t:  V: B(2t) | M: C(2t), A(2t+1) | V: B(2t+1) | M: C(2t+1), A(2t+2)      four barriers; group 1 (waves 4-7) runs one phase later
+// MEASURED (profiles/r03o_attn_dkv_modes.txt, r03p_dkv3_depth.txt): parity green on the first run, bit-reproducible on all 256 heads at B = 16 - and
+// 2.56 ms against 2.51 ms for the kernel above: no faster.  Nor does the prefetch distance of its matrix phase matter (2 / 3 / 4 / 6 fragments:
+// 2.666 / 2.666 / 2.682 / 2.691 ms on one box).  Two uncoordinated waves, a hand-placed pipeline and a lock-step ping-pong all land within 3 % of each
+// other: the kernel is not waiting for issue slots or LDS latency, it sits at the chip's POWER limit for this instruction mix (effective clock 1.75 GHz,
+// DESIGN.md section 4 fact 2) - what moved the time this round was removing work (the stats rows: -6 %), not re-ordering it.  Kept as PXA_ATTN_DKV=3 for
+// the record; mode 2 stays the default.
+//   ring: tile t+2 -> stage (t+2) % 3 is issued at global phase 4t+1 (group 0: start of its first M, group 1: start of its first V - every wave has left
+//   tile t-1 by then) and waited for (vmcnt(0), each wave its own pieces) in front of the barrier that ends global phase 4t+6, one phase before group 0
+//   first reads it.
+template <int DK>     // DK = prefetch distance of the matrix phase in fragments (DK + 1 fragment register quads)
+__global__ __launch_bounds__(512, 2) void attn_bwd_dkv3_kernel(AttnParams p) {
+  constexpr int NF = DK + 1;
+  __shared__ __attribute__((aligned(16))) char smem[NSTAGE * STAGE_B];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), hi = lane >> 5;
+  const int grp = wave >> 2;
+  int bx, h, b;
+  block_coords(p, bx, h, b);
+  long kbase, vbase, dkbase, dvbase; int kvlen;
+  kv_range(p, b, kbase, vbase, dkbase, dvbase, kvlen);
+  if (bx * 256 >= kvlen) return;  // whole block beyond this sample's keys (uniform across the block)
+  const int kv = bx * 256 + wave * 32 + (lane & 31);
+  const bool kvvalid = kv < kvlen;
+  const bool wave_active = bx * 256 + wave * 32 < kvlen;
+
+  bf16x8 kf[KSTEPS], vf[KSTEPS];
+  load_row_frags(kf, p.K + kbase + (long)kv * p.k_ts + (long)h * p.k_hs, kvvalid, hi);
+  load_row_frags(vf, p.V + vbase + (long)kv * p.v_ts + (long)h * p.v_hs, kvvalid, hi);
+  settle(kf);
+  settle(vf);
+  if (hi == 1) {                                            // k-slots 72 .. 74: -1.0 against the stats rows' {hi, mid, lo}
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    u32x4 w = __builtin_bit_cast(u32x4, kf[KSTEPS - 1]);
+    w[0] = PXA_OPERAND_MINUS_ONE_X2; w[1] = PXA_OPERAND_MINUS_ONE_X1;
+    kf[KSTEPS - 1] = __builtin_bit_cast(bf16x8, w);
+    w = __builtin_bit_cast(u32x4, vf[KSTEPS - 1]);
+    w[0] = PXA_OPERAND_MINUS_ONE_X2; w[1] = PXA_OPERAND_MINUS_ONE_X1;
+    vf[KSTEPS - 1] = __builtin_bit_cast(bf16x8, w);
+  }
+  const bf16_t* Qp = p.Q + (long)b * p.q_bs + (long)h * p.q_hs;
+  const bf16_t* Dp = p.dO + (long)b * p.o_bs + (long)h * p.o_hs;
+  const bf16_t* Ls = p.stats + ((long)b * p.H + h) * p.Nq64 * 8;
+  const bf16_t* Ds = Ls + (long)p.B * p.H * p.Nq64 * 8;
+  const int qts = (int)p.q_ts, ots = (int)p.o_ts;
+  FragAddr fa;
+  frag_addr(fa, lane);
+  int r4[2];
+#pragma unroll
+  for (int sub = 0; sub < 2; sub++) r4[sub] = hi ? TILE_B + (sub * 32 + (lane & 31)) * 16 : fa.rb[0] + 2 * 64 + sub * 32 * ROWB;
+  // DMA: the 24 one-KiB pieces of a {Q, dO} tile pair over 8 waves: wave w takes pieces w, w + 8, w + 16 (0..11 = Q tile, 12..23 = dO tile)
+  constexpr int DOFF = TILE_B + STAT_B;                    // dO tile relative to the Q tile of its stage
+  int prow[3], pcoff[3];
+#pragma unroll
+  for (int i = 0; i < 3; i++) {
+    const int g = i * 8 + wave, piece = g % 12, pp = piece * 64 + lane, r = pp / 12, cl = pp - r * 12, cc = cl ^ ((r >> 2) & 3);
+    prow[i] = r;
+    pcoff[i] = cc < NCH ? cc * 8 : -1;
+  }
+  const int T = (p.Nq + BKV - 1) / BKV;
+  auto issue = [&](int t, char* st) {
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+      const int g = i * 8 + wave;                           // wave-uniform: which tile, which piece
+      const bool isd = g >= 12;
+      const int gr = min(t * BKV + prow[i], p.Nq - 1);
+      if (pcoff[i] >= 0)
+        lds_dma16((isd ? Dp : Qp) + (long)gr * (isd ? ots : qts) + pcoff[i], st + (isd ? DOFF : 0) + (g % 12) * 1024);
+    }
+    if (wave < 2) lds_dma16((wave == 0 ? Ls : Ds) + ((long)t * BKV + lane) * 8, st + (wave == 0 ? TILE_B : 2 * TILE_B + STAT_B));
+  };
+  for (int st = 0; st < NSTAGE; st++) {
+    init_pads(smem + st * STAGE_B, 0, tid);
+    init_pads(smem + st * STAGE_B + DOFF, 0, tid);
+  }
+  auto bar = [&]() { __builtin_amdgcn_s_barrier(); };
+  auto stage = [&](int i) -> char* { return smem + i * STAGE_B; };
+  issue(0, stage(0));
+  if (T > 1) issue(1, stage(1));
+  lds_dma_wait<0>();
+  __syncthreads();                                          // tiles 0 and 1 have landed, pads written
+  if (!wave_active) {                                       // DMA, waits and barriers only, in the group's rhythm
+    if (grp == 1) bar();
+    bar();
+    int in2 = 2;
+    for (int t = 0; t < T; t++) {
+      if (grp == 1 && t + 2 < T) issue(t + 2, stage(in2));  // group 1: start of its first V
+      bar();
+      if (grp == 0 && t + 2 < T) issue(t + 2, stage(in2));  // group 0: start of its first M
+      if (grp == 1) lds_dma_wait<0>();
+      bar();
+      if (grp == 0) lds_dma_wait<0>();
+      bar();
+      bar();
+      in2 = in2 == NSTAGE - 1 ? 0 : in2 + 1;
+    }
+    if (grp == 0) bar();
+    return;
+  }
+  f32x16 dk[3], dv[3];
+  zero3(dk);
+  zero3(dv);
+  const float c = p.scale_log2;
+  const unsigned lds0 = (unsigned)(uintptr_t)LDS_PTR(char, smem);
+  f32x16 s, dp;
+  bf16x8 pb[2], db[2], f[NF];
+  struct Bases { unsigned r0, r1, r40, r41, t0, t1; };
+  auto bases = [&](unsigned st) -> Bases { return Bases{st + (unsigned)fa.rb[0], st + (unsigned)fa.rb[1], st + (unsigned)r4[0], st + (unsigned)r4[1],
+                                                        st + (unsigned)fa.tb[0], st + (unsigned)fa.tb[1]}; };
+  auto rd_row = [&](auto subc, auto kc, bf16x8& d, const Bases& bs) {
+    constexpr int sub = decltype(subc)::value, k = decltype(kc)::value, ks = k >> 1, w = k & 1;
+    if constexpr (ks < KSTEPS - 1) lds_row_asm<w * DOFF + sub * 32 * ROWB + (ks >> 1) * 64>(d, (ks & 1) ? bs.r1 : bs.r0);
+    else lds_row_asm<w * DOFF>(d, sub ? bs.r41 : bs.r40);
+  };
+  auto rd_tr = [&](auto subc, auto kc, bf16x8& d, const Bases& bs) {
+    constexpr int sub = decltype(subc)::value, k = decltype(kc)::value, uu = k / 6, dt = (k % 6) >> 1, w = k & 1;
+    lds_tr_asm<(w ? 0 : DOFF) + (sub * 2 + uu) * 16 * ROWB + dt * 64>(d, bs.t0, bs.t1);
+  };
+  // phase M as ONE chain of 22 fragments: 12 transpose fragments of C(sub CSUB of the stage behind cb; 2 reads each), then 10 row fragments of A(sub ASUB
+  // of the stage behind ab; 1 read each).  Fragment i sits in f[i % NF]; the first D = NF - 1 are in flight on entry (issued by the V phase before);
+  // slot k = {wait for fragment k: the reads issued after it are those of fragments k+1 .. k+D-1; MFMA k; issue fragment k+D}.  Nothing in flight after.
+  auto frag_issue = [&](auto ic_, auto csubc, auto asubc, const Bases& cb, const Bases& ab) {
+    constexpr int i = decltype(ic_)::value;
+    if constexpr (i < 12) rd_tr(csubc, IntC<i>{}, f[i % NF], cb);
+    else if constexpr (i < 22) rd_row(asubc, IntC<i - 12>{}, f[i % NF], ab);
+  };
+  auto mChain = [&](auto csubc, auto asubc, const Bases& cb, const Bases& ab) {
+    static_for<22>([&](auto kc) {
+      constexpr int k = decltype(kc)::value;
+      constexpr int nafter = [] { int n = 0; for (int i = k + 1; i < k + DK && i < 22; i++) n += i < 12 ? 2 : 1; return n; }();
+      lds_wait<nafter>(f[k % NF]);
+      if constexpr (k < 12) {
+        constexpr int uu = k / 6, dt = (k % 6) >> 1;
+        if constexpr (k & 1) dk[dt] = mfma32(f[k % NF], db[uu], dk[dt]);
+        else dv[dt] = mfma32(f[k % NF], pb[uu], dv[dt]);
+      } else {
+        constexpr int j = k - 12;
+        if constexpr (j == 0) { f32x16 z; for (int g = 0; g < 16; g++) z[g] = 0.f; s = mfma32(f[k % NF], kf[0], z); }
+        else if constexpr (j == 1) { f32x16 z; for (int g = 0; g < 16; g++) z[g] = 0.f; dp = mfma32(f[k % NF], vf[0], z); }
+        else if constexpr (j & 1) dp = mfma32(f[k % NF], vf[j >> 1], dp);
+        else s = mfma32(f[k % NF], kf[j >> 1], s);
+      }
+      frag_issue(IntC<k + DK>{}, csubc, asubc, cb, ab);
+      __builtin_amdgcn_sched_barrier(0);
+    });
+  };
+  // A alone (prologue): row fragments only, cold
+  auto mA0 = [&](const Bases& ab) {
+    static_for<DK>([&](auto ic_) { rd_row(IntC<0>{}, ic_, f[decltype(ic_)::value % NF], ab); });
+    __builtin_amdgcn_sched_barrier(0);
+    static_for<10>([&](auto kc) {
+      constexpr int k = decltype(kc)::value;
+      constexpr int nafter = (k + DK - 1 < 10 ? DK - 1 : 9 - k);
+      lds_wait<nafter>(f[k % NF]);
+      if constexpr (k == 0) { f32x16 z; for (int g = 0; g < 16; g++) z[g] = 0.f; s = mfma32(f[k % NF], kf[0], z); }
+      else if constexpr (k == 1) { f32x16 z; for (int g = 0; g < 16; g++) z[g] = 0.f; dp = mfma32(f[k % NF], vf[0], z); }
+      else if constexpr (k & 1) dp = mfma32(f[k % NF], vf[k >> 1], dp);
+      else s = mfma32(f[k % NF], kf[k >> 1], s);
+      if constexpr (k + DK < 10) rd_row(IntC<0>{}, IntC<k + DK>{}, f[(k + DK) % NF], ab);
+      __builtin_amdgcn_sched_barrier(0);
+    });
+  };
+  // phase V: B in place, then the first D fragments of the M phase that follows (C of sub CSUB of the stage behind cb)
+  auto vB = [&](auto csubc, const Bases& cb) {
+#pragma unroll
+    for (int g = 0; g < 16; g++) {
+      const float pr = __builtin_amdgcn_exp2f(s[g] * c);
+      s[g] = pr;
+      dp[g] = pr * dp[g];
+    }
+#pragma unroll
+    for (int uu = 0; uu < 2; uu++) { pb[uu] = pack8(s, 8 * uu); db[uu] = pack8(dp, 8 * uu); }
+    asm volatile("" : "+v"(pb[0]), "+v"(pb[1]), "+v"(db[0]), "+v"(db[1]));
+    __builtin_amdgcn_sched_barrier(0);
+    static_for<DK>([&](auto ic_) { rd_tr(csubc, ic_, f[decltype(ic_)::value % NF], cb); });
+    __builtin_amdgcn_sched_barrier(0);
+  };
+
+  if (grp == 1) bar();                                      // group 1 sits out the phase in which group 0 computes its A(0, 0)
+  mA0(bases(lds0));
+  bar();
+  int ic = 0;
+  for (int t = 0; t < T; t++) {
+    const int in = ic == NSTAGE - 1 ? 0 : ic + 1, in2 = in == NSTAGE - 1 ? 0 : in + 1;
+    unsigned cst = lds0 + ic * STAGE_B;
+    asm volatile("" : "+s"(cst));                           // per-stage lane addresses are rebuilt where they are used, not carried through the loop
+    // ---- V: B(2t)
+    if (grp == 1 && t + 2 < T) issue(t + 2, stage(in2));
+    vB(IntC<0>{}, bases(cst));
+    bar();
+    // ---- M: C(2t), A(2t+1)
+    if (grp == 0 && t + 2 < T) issue(t + 2, stage(in2));
+    {
+      const Bases cb = bases(cst);
+      mChain(IntC<0>{}, IntC<1>{}, cb, cb);
+    }
+    if (grp == 1) lds_dma_wait<0>();
+    bar();
+    // ---- V: B(2t+1)
+    asm volatile("" : "+s"(cst));
+    vB(IntC<1>{}, bases(cst));
+    if (grp == 0) lds_dma_wait<0>();
+    bar();
+    // ---- M: C(2t+1), A(2t+2) (the last tile re-reads its own first sub-tile: unused)
+    {
+      unsigned nst = lds0 + ((t + 1 < T) ? in : ic) * STAGE_B;
+      asm volatile("" : "+s"(cst), "+s"(nst));
+      const Bases cb = bases(cst), nb = bases(nst);
+      mChain(IntC<1>{}, IntC<0>{}, cb, nb);
+    }
+    bar();
+    ic = in;
+  }
+  if (grp == 0) bar();                                      // group 1's last phase
+  if (kvvalid) {
+    store_rows(p.dK + dkbase + (long)kv * p.dk_ts + (long)h * p.dk_hs, dk, p.scale, hi);
+    store_rows(p.dV + dvbase + (long)kv * p.dv_ts + (long)h * p.dv_hs, dv, 1.f, hi);
+  }
+  if (p.dk_colsum) colsum_rows(p.dk_colsum + (b % PXA_COLSUM_SLOTS) * p.colsum_stride + h * DH, dk, p.scale, kvvalid, hi, lane);
+  if (p.dv_colsum) colsum_rows(p.dv_colsum + (b % PXA_COLSUM_SLOTS) * p.colsum_stride + h * DH, dv, 1.f, kvvalid, hi, lane);
+}
+
 int fill(AttnParams& p, const pxa_attn_args* a) {
   PXA_CHECK(a, "attn: null args");
   PXA_CHECK(a->head_dim == DH, "attn: head_dim %d unsupported (PixArt XL/2 uses 72)", a->head_dim);
@@ -1513,10 +1743,11 @@ extern "C" int pxa_attn_bwd(const pxa_attn_args* a, hipStream_t stream) {
   }
   if (p.dK) {
     const int max_k = a->max_kv_len > 0 ? a->max_kv_len : p.Nk;
-    p.nx = (max_k + 127) / 128;
+    p.nx = dkv_mode == 3 ? (max_k + 255) / 256 : (max_k + 127) / 128;
     PXA_CHECK((long)p.nx * p.H * p.B < (1L << 31), "pxa_attn_bwd: grid too large");
     if (p.nx > 0) {
-      if (dkv_mode == 2) hipLaunchKernelGGL(attn_bwd_dkv2_kernel<1>, dim3(p.nx * p.H * p.B), dim3(256), 0, stream, p);
+      if (dkv_mode == 3) hipLaunchKernelGGL(attn_bwd_dkv3_kernel<2>, dim3(p.nx * p.H * p.B), dim3(512), 0, stream, p);   // prefetch distances 3 / 4 / 6 measured the same
+      else if (dkv_mode == 2) hipLaunchKernelGGL(attn_bwd_dkv2_kernel<1>, dim3(p.nx * p.H * p.B), dim3(256), 0, stream, p);
       else if (dkv_mode == 1) hipLaunchKernelGGL(attn_bwd_dkv2_kernel<0>, dim3(p.nx * p.H * p.B), dim3(256), 0, stream, p);
       else hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3(p.nx * p.H * p.B), dim3(256), 0, stream, p);
     }

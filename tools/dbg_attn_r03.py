@@ -25,14 +25,14 @@ if what == "grid":
     st = (s3, s3, s3, (N * C, C, 72))
     ops.attention_fwd(q, k, v, o, lse, B, H, N, N, st)
     outs = {}
-    for mode in ("0", "1", "2", "2"):
+    for mode in ("0", "2", "3", "3", "2"):
         os.environ["PXA_ATTN_DKV"] = mode
         os.environ["PXA_ATTN_DQ"] = "0" if mode == "0" else "1"
         d = torch.full_like(qkv, float("nan"))
         ops.attention_bwd(q, k, v, o, do, lse, delta, d[..., :C], d[..., C:2 * C], d[..., 2 * C:], B, H, N, N, st, (s3, s3, s3))
         torch.cuda.synchronize()
         outs.setdefault(mode, []).append(d)
-    print("mode 2 (+ dQ kernel 1) run-to-run identical:", torch.equal(outs["2"][0], outs["2"][1]), "| dQ kernel 0 vs 1 max abs diff:",
+    print("mode 3 run-to-run identical:", torch.equal(outs["3"][0], outs["3"][1]), "mode 2:", torch.equal(outs["2"][0], outs["2"][1]), "| dQ kernel 0 vs 1 max abs diff:",
           (outs["0"][0][..., :C].float() - outs["2"][0][..., :C].float()).abs().max().item())
     err = {m: torch.zeros(B, H, 3) for m in outs}
     for b in range(B):
