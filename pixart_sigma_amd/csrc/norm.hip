@@ -76,6 +76,45 @@ __global__ __launch_bounds__(256) void ln_mod_fwd_kernel(
 }
 
 constexpr int BWD_ROWS = 16;  // rows per half-wave in the reducing backward kernels
+#ifndef BWD_ROW_MAP
+#define BWD_ROW_MAP 1          // 1 = the block's 8 half-waves walk its 128 rows interleaved (row = first + h + 8 i: the block reads 8 consecutive rows =
+#endif                         //     37 KB at a time); 0 = 16 consecutive rows per half-wave (4096 concurrent streams 72 KB = 9 x 2^13 bytes apart)
+__device__ __forceinline__ int bwd_row(int blk_first, int h, int i) { return BWD_ROW_MAP ? blk_first + h + 8 * i : blk_first + h * BWD_ROWS + i; }
+
+// Block-level combine of two per-lane column-sum sets (a0 -> columns [0, D), a1 -> columns [D, 2 D)) held by the 8 half-waves of a 256-thread
+// block, WITHOUT LDS atomics (they retire at about one lane per clock per CU: 8 half-waves x 72 words x 32 lanes = 18 k cycles per block, a
+// quarter of the block's streaming time).  The two halves of a wave cover the same columns: one v_permlane32_swap per (a0, a1) pair adds them so that
+// the lower half owns a0 and the upper half a1 (9 ds_write_b128 per lane).  Waves 0/1 store into slots 0/1, waves 2/3 add into them:
+// red = [2 slots][2 D] floats, two barriers, plain LDS reads and writes only.
+__device__ __forceinline__ float half_swap_sum(float lo_owner, float hi_owner) {
+  // v_permlane32_swap: dst.upper <-> src.lower.  Afterwards dst = {lo_owner.lower, hi_owner.lower}, src = {lo_owner.upper, hi_owner.upper}: their
+  // sum is the wave total of lo_owner in the lower 32 lanes and of hi_owner in the upper 32 - one swap and one add per pair of values
+  auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(lo_owner), __float_as_uint(hi_owner), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+template <int NV>
+__device__ __forceinline__ void block_colsum_combine(float* red, float4 (&a0)[NV], float4 (&a1)[NV], int D) {
+  const int hl = threadIdx.x & 31, upper = (threadIdx.x >> 5) & 1, wave = threadIdx.x >> 6;
+  float* slot = red + (wave & 1) * 2 * D + upper * D;
+  float4 mine[NV];
+#pragma unroll
+  for (int j = 0; j < NV; j++)
+    mine[j] = make_float4(half_swap_sum(a0[j].x, a1[j].x), half_swap_sum(a0[j].y, a1[j].y), half_swap_sum(a0[j].z, a1[j].z), half_swap_sum(a0[j].w, a1[j].w));
+  if (wave < 2) {
+#pragma unroll
+    for (int j = 0; j < NV; j++) *reinterpret_cast<float4*>(slot + (hl + 32 * j) * 4) = mine[j];
+  }
+  __syncthreads();
+  if (wave >= 2) {
+#pragma unroll
+    for (int j = 0; j < NV; j++) {
+      float4* p = reinterpret_cast<float4*>(slot + (hl + 32 * j) * 4);
+      const float4 o = *p;
+      *p = make_float4(o.x + mine[j].x, o.y + mine[j].y, o.z + mine[j].z, o.w + mine[j].w);
+    }
+  }
+  __syncthreads();
+}
 #ifndef LNB_VARIANT
 #define LNB_VARIANT 1          // 1 = the row's dx_in loads are issued with its other loads (dx_out may alias dx_in, so a load placed behind the
 #endif                         //     previous chunk's store cannot be hoisted: 0 = that order, 312 us; 1: 250 us; 3 = all dx_in loads after the reduction: 407 us)
@@ -88,17 +127,12 @@ __global__ __launch_bounds__(256) void ln_mod_bwd_kernel(
   // Per-sample column sums (dshift / dscale): every 16-row chunk used to fire 72 global atomics per lane at the SAME 2 x D words
   // of its sample - ~1000 serialised read-modify-writes per cache line and call.  When the block's 128 rows belong to one sample
   // (always, unless a sample's token count is not a multiple of 128) the 8 half-waves first combine in LDS, then the block adds
-  // once: 8x fewer, fully coalesced atomics.
-  extern __shared__ float red[];                       // [2][D]
+  // once: 8x fewer, fully coalesced atomics (block_colsum_combine: no LDS atomics either).
+  extern __shared__ float red[];                       // [2 slots][2][D]
   const int hl = threadIdx.x & 31;
-  const int chunk = blockIdx.x * 8 + (threadIdx.x >> 5);
-  const int r_beg = chunk * BWD_ROWS, r_end = min(R, r_beg + BWD_ROWS);
   const int blk_first = blockIdx.x * 8 * BWD_ROWS, blk_last = min(R, blk_first + 8 * BWD_ROWS) - 1;
+  const int r_beg = bwd_row(blk_first, threadIdx.x >> 5, 0);
   const bool one_sample = (blk_first / rows_per_batch) == (blk_last / rows_per_batch);   // block-uniform
-  if (one_sample) {
-    for (int i = threadIdx.x; i < 2 * D; i += 256) red[i] = 0.f;
-    __syncthreads();
-  }
   float4 ash[NV], asc[NV];
 #pragma unroll
   for (int j = 0; j < NV; j++) { ash[j] = make_float4(0, 0, 0, 0); asc[j] = make_float4(0, 0, 0, 0); }
@@ -107,14 +141,16 @@ __global__ __launch_bounds__(256) void ln_mod_bwd_kernel(
 #pragma unroll
     for (int j = 0; j < NV; j++) {
       const int c = (hl + 32 * j) * 4;
-      float* ps = one_sample ? red + c : dshift + (size_t)b * dmod_stride + c;
-      float* pc = one_sample ? red + D + c : dscale + (size_t)b * dmod_stride + c;
+      float* ps = dshift + (size_t)b * dmod_stride + c;
+      float* pc = dscale + (size_t)b * dmod_stride + c;
       atomicAdd(ps + 0, ash[j].x); atomicAdd(ps + 1, ash[j].y); atomicAdd(ps + 2, ash[j].z); atomicAdd(ps + 3, ash[j].w);
       atomicAdd(pc + 0, asc[j].x); atomicAdd(pc + 1, asc[j].y); atomicAdd(pc + 2, asc[j].z); atomicAdd(pc + 3, asc[j].w);
       ash[j] = make_float4(0, 0, 0, 0); asc[j] = make_float4(0, 0, 0, 0);
     }
   };
-  for (int row = r_beg; row < r_end; row++) {
+  for (int i = 0; i < BWD_ROWS; i++) {
+    const int row = bwd_row(blk_first, threadIdx.x >> 5, i);
+    if (row >= R) break;
     const int b = row / rows_per_batch;
     if (b != cur_b) { flush(cur_b); cur_b = b; }
     const size_t base = (size_t)row * D;
@@ -169,14 +205,15 @@ __global__ __launch_bounds__(256) void ln_mod_bwd_kernel(
       if (dx_bf16) st_u2(dx_bf16 + base + c, pack_bf16x4(o.x, o.y, o.z, o.w));
     }
   }
-  if (r_beg < R) flush(cur_b);
   if (one_sample) {
-    __syncthreads();
+    block_colsum_combine<NV>(red, ash, asc, D);
     const int b = blk_first / rows_per_batch;
     for (int i = threadIdx.x; i < D; i += 256) {
-      atomicAdd(dshift + (size_t)b * dmod_stride + i, red[i]);
-      atomicAdd(dscale + (size_t)b * dmod_stride + i, red[D + i]);
+      atomicAdd(dshift + (size_t)b * dmod_stride + i, red[i] + red[2 * D + i]);
+      atomicAdd(dscale + (size_t)b * dmod_stride + i, red[D + i] + red[3 * D + i]);
     }
+  } else if (r_beg < R) {
+    flush(cur_b);
   }
 }
 
@@ -185,16 +222,11 @@ __global__ __launch_bounds__(256) void gate_bwd_kernel(
     const float* dx, const bf16_t* __restrict__ add, const bf16_t* __restrict__ u, const float* __restrict__ gate,
     int mod_stride, float* dx_out, bf16_t* __restrict__ du, float* __restrict__ dgate, int dmod_stride, float* __restrict__ dbias,
     long dbias_stride, int R, int D, int rows_per_batch) {
-  extern __shared__ float red[];                       // [2][D]: block-level combine of the column sums (see ln_mod_bwd_kernel)
+  extern __shared__ float red[];                       // [2 slots][2][D]: block-level combine of the column sums (block_colsum_combine)
   const int hl = threadIdx.x & 31;
-  const int chunk = blockIdx.x * 8 + (threadIdx.x >> 5);
-  const int r_beg = chunk * BWD_ROWS, r_end = min(R, r_beg + BWD_ROWS);
   const int blk_first = blockIdx.x * 8 * BWD_ROWS, blk_last = min(R, blk_first + 8 * BWD_ROWS) - 1;
+  const int r_beg = bwd_row(blk_first, threadIdx.x >> 5, 0);
   const bool one_sample = (blk_first / rows_per_batch) == (blk_last / rows_per_batch);   // block-uniform
-  if (one_sample) {
-    for (int i = threadIdx.x; i < 2 * D; i += 256) red[i] = 0.f;
-    __syncthreads();
-  }
   float4 ag[NV], ab[NV];
 #pragma unroll
   for (int j = 0; j < NV; j++) { ag[j] = make_float4(0, 0, 0, 0); ab[j] = make_float4(0, 0, 0, 0); }
@@ -203,7 +235,7 @@ __global__ __launch_bounds__(256) void gate_bwd_kernel(
     if (dgate) {
 #pragma unroll
       for (int j = 0; j < NV; j++) {
-        float* pg = one_sample ? red + (hl + 32 * j) * 4 : dgate + (size_t)b * dmod_stride + (hl + 32 * j) * 4;
+        float* pg = dgate + (size_t)b * dmod_stride + (hl + 32 * j) * 4;
         atomicAdd(pg + 0, ag[j].x); atomicAdd(pg + 1, ag[j].y); atomicAdd(pg + 2, ag[j].z); atomicAdd(pg + 3, ag[j].w);
         ag[j] = make_float4(0, 0, 0, 0);
       }
@@ -211,13 +243,15 @@ __global__ __launch_bounds__(256) void gate_bwd_kernel(
     if (dbias) {   // partial slot b % PXA_COLSUM_SLOTS: bounds same-address atomic contention exactly like the per-sample dgate
 #pragma unroll
       for (int j = 0; j < NV; j++) {
-        float* pb = one_sample ? red + D + (hl + 32 * j) * 4 : dbias + (size_t)(b % PXA_COLSUM_SLOTS) * dbias_stride + (hl + 32 * j) * 4;
+        float* pb = dbias + (size_t)(b % PXA_COLSUM_SLOTS) * dbias_stride + (hl + 32 * j) * 4;
         atomicAdd(pb + 0, ab[j].x); atomicAdd(pb + 1, ab[j].y); atomicAdd(pb + 2, ab[j].z); atomicAdd(pb + 3, ab[j].w);
         ab[j] = make_float4(0, 0, 0, 0);
       }
     }
   };
-  for (int row = r_beg; row < r_end; row++) {
+  for (int i = 0; i < BWD_ROWS; i++) {
+    const int row = bwd_row(blk_first, threadIdx.x >> 5, i);
+    if (row >= R) break;
     const int b = row / rows_per_batch;
     if (b != cur_b) { flush(cur_b); cur_b = b; }
     const size_t base = (size_t)row * D;
@@ -254,14 +288,15 @@ __global__ __launch_bounds__(256) void gate_bwd_kernel(
       ab[j].x += o.x; ab[j].y += o.y; ab[j].z += o.z; ab[j].w += o.w;
     }
   }
-  if (r_beg < R) flush(cur_b);
   if (one_sample) {
-    __syncthreads();
+    block_colsum_combine<NV>(red, ag, ab, D);
     const int b = blk_first / rows_per_batch;
     for (int i = threadIdx.x; i < D; i += 256) {
-      if (dgate) atomicAdd(dgate + (size_t)b * dmod_stride + i, red[i]);
-      if (dbias) atomicAdd(dbias + (size_t)(b % PXA_COLSUM_SLOTS) * dbias_stride + i, red[D + i]);
+      if (dgate) atomicAdd(dgate + (size_t)b * dmod_stride + i, red[i] + red[2 * D + i]);
+      if (dbias) atomicAdd(dbias + (size_t)(b % PXA_COLSUM_SLOTS) * dbias_stride + i, red[D + i] + red[3 * D + i]);
     }
+  } else if (r_beg < R) {
+    flush(cur_b);
   }
 }
 
@@ -459,7 +494,7 @@ extern "C" int pxa_ln_mod_bwd(const void* dy_bf16, const float* x, const float* 
   PXA_CHECK(dy_bf16 && x && mean && rstd && scale && dx_out && dshift && dscale, "pxa_ln_mod_bwd: null pointer");
   PXA_CHECK(R > 0 && D % 128 == 0 && rows_per_batch > 0, "pxa_ln_mod_bwd: bad shape");
   const int chunks = (R + BWD_ROWS - 1) / BWD_ROWS;
-  DISPATCH_NV(D, hipLaunchKernelGGL(ln_mod_bwd_kernel<NV>, dim3((chunks + 7) / 8), dim3(256), 2 * D * sizeof(float), stream, (const bf16_t*)dy_bf16, x, mean, rstd,
+  DISPATCH_NV(D, hipLaunchKernelGGL(ln_mod_bwd_kernel<NV>, dim3((chunks + 7) / 8), dim3(256), 4 * D * sizeof(float), stream, (const bf16_t*)dy_bf16, x, mean, rstd,
                                      scale, mod_stride, dx_in, dx_out, (bf16_t*)dx_bf16, dshift, dscale, dmod_stride, R, D, rows_per_batch));
   PXA_LAUNCH_CHECK();
   return 0;
@@ -471,7 +506,7 @@ extern "C" int pxa_gate_bwd(const float* dx, const void* add_bf16, const void* u
   PXA_CHECK(dx && R > 0 && D % 128 == 0 && rows_per_batch > 0, "pxa_gate_bwd: bad args");
   PXA_CHECK(!gate || (u_bf16 && dgate), "pxa_gate_bwd: gate needs u and dgate");
   const int chunks = (R + BWD_ROWS - 1) / BWD_ROWS;
-  DISPATCH_NV(D, hipLaunchKernelGGL(gate_bwd_kernel<NV>, dim3((chunks + 7) / 8), dim3(256), 2 * D * sizeof(float), stream, dx, (const bf16_t*)add_bf16,
+  DISPATCH_NV(D, hipLaunchKernelGGL(gate_bwd_kernel<NV>, dim3((chunks + 7) / 8), dim3(256), 4 * D * sizeof(float), stream, dx, (const bf16_t*)add_bf16,
                                      (const bf16_t*)u_bf16, gate, mod_stride, dx_out, (bf16_t*)du_bf16, dgate, dmod_stride, dbias, dbias_stride, R, D, rows_per_batch));
   PXA_LAUNCH_CHECK();
   return 0;
