@@ -545,6 +545,9 @@ __global__ __launch_bounds__(256) void attn_delta_rows_kernel(const bf16_t* __re
 // and a K/V tile pair fetched by LDS-DMA serves twice as many queries: the single-sub-tile kernel above moves 12.9 GB from L2 into
 // LDS per self-attention launch (8.6 TB/s - the same ballpark as the GEMM's DMA-only ceiling) and issues 1.9 LDS instructions per
 // MFMA.  Costs: 96 + 64 accumulator registers (two waves per SIMD instead of three).
+#ifndef FWD_ABL
+#define FWD_ABL 0       // ablation study of the forward loop (tools/build_variant.py): 1 = no exp2, 2 = no cvt / permlane, 3 = no softmax VALU at all, 4 = no MFMAs
+#endif
 __global__ __launch_bounds__(256, 2) void attn_fwd2_kernel(AttnParams p) {
   constexpr int QS = 2;
   __shared__ __attribute__((aligned(16))) char smem[4 * TILE_B];   // 2 stages x {K, V}
@@ -600,9 +603,16 @@ __global__ __launch_bounds__(256, 2) void attn_fwd2_kernel(AttnParams p) {
 #pragma unroll
       for (int ks = 0; ks < KSTEPS; ks++) {
         const bf16x8 kf = rowfrag(sK, fa, sub, ks);          // one LDS read, two MFMAs
+#if FWD_ABL == 4
+        asm volatile("" :: "v"(kf));
+#else
 #pragma unroll
         for (int s = 0; s < QS; s++) sc[s][sub] = mfma32(kf, qf[s][ks], sc[s][sub]);
+#endif
       }
+#if FWD_ABL == 3
+    // (ablation: no softmax at all - the score registers feed the pack as they are)
+#else
 #pragma unroll
     for (int s = 0; s < QS; s++) {
       if (TAIL) {
@@ -632,21 +642,41 @@ __global__ __launch_bounds__(256, 2) void attn_fwd2_kernel(AttnParams p) {
 #pragma unroll
       for (int sub = 0; sub < 2; sub++)
 #pragma unroll
-        for (int g = 0; g < 16; g++) sc[s][sub][g] = __builtin_amdgcn_exp2f(sc[s][sub][g] * c - mc);
+        for (int g = 0; g < 16; g++) {
+#if FWD_ABL == 1
+          sc[s][sub][g] = sc[s][sub][g] * c - mc;             // (ablation: no exp2)
+#else
+          sc[s][sub][g] = __builtin_amdgcn_exp2f(sc[s][sub][g] * c - mc);
+#endif
+        }
     }
+#endif
 #pragma unroll
     for (int sub = 0; sub < 2; sub++) {
       bf16x8 px[QS], py[QS];
 #pragma unroll
-      for (int s = 0; s < QS; s++) pack_xy(sc[s][sub], px[s], py[s]);
+      for (int s = 0; s < QS; s++) {
+#if FWD_ABL == 2 || FWD_ABL == 3
+        const f32x4 lo4 = {sc[s][sub][0], sc[s][sub][1], sc[s][sub][2], sc[s][sub][3]}, hi4 = {sc[s][sub][4], sc[s][sub][5], sc[s][sub][6], sc[s][sub][7]};
+        px[s] = __builtin_bit_cast(bf16x8, lo4);                // (ablation: no cvt / permlane)
+        py[s] = __builtin_bit_cast(bf16x8, hi4);
+        asm volatile("" : "+v"(px[s]), "+v"(py[s]));
+#else
+        pack_xy(sc[s][sub], px[s], py[s]);
+#endif
+      }
 #pragma unroll
       for (int t = 0; t < NT16; t++) {
         const bf16x8 vf = trfrag16(sV, ta, t, sub);          // one transposed fragment, four MFMAs
+#if FWD_ABL == 4
+        asm volatile("" :: "v"(vf), "v"(px[0]), "v"(py[0]), "v"(px[1]), "v"(py[1]));
+#else
 #pragma unroll
         for (int s = 0; s < QS; s++) {
           o[s].v[t][0] = mfma16(vf, px[s], o[s].v[t][0]);
           o[s].v[t][1] = mfma16(vf, py[s], o[s].v[t][1]);
         }
+#endif
       }
     }
   };
