@@ -507,7 +507,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_glds_kernel(GemmParams p) {
       }
     }
   }
-  if (EPI == 1) epilogue_staged<TM, TN>(p, acc, smem, wave, m0 + wm * (TM * 32), n0 + wn * (TN * 32), lane, hi);
+  if constexpr (EPI == 1) epilogue_staged<TM, TN>(p, acc, smem, wave, m0 + wm * (TM * 32), n0 + wn * (TN * 32), lane, hi);
   else epilogue_t<TM, TN>(p, acc, m0 + wm * (TM * 32), n0 + wn * (TN * 32), lane, hi, z_);
 }
 
