@@ -229,6 +229,9 @@ def came_tables(names, offset, shape, numel, tile_elems):
             inv_r += [1.0 / R] * (batch * Cc) + [0.0] * pad
             rows = batch * R
             per = max(4, tile_elems // Cc // 4 * 4)
+            if batch > 1 or Cc % 4 or Cc > 256 * 18:      # the kernel's scalar path (came.hip, MAXJ == 0): one wave walks its rows one after the other,
+                per = min(per, 64)                        # every row a chain of dependent loads and atomics - the patch-embed conv weight, viewed as
+                                                          # [4608][2][2], was ONE tile of 9,216 such rows = ~2 ms per pass, the whole launch waiting for it
             tiles += [(ti, r0, min(per, rows - r0)) for r0 in range(0, rows, per)]
             n_row, n_col, n_rm = n_row + rows, n_col + batch * Cc + pad, n_rm + batch
         else:
