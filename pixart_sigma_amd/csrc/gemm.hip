@@ -721,7 +721,8 @@ __device__ __forceinline__ bf16x8 frag16(const char* lds, int rbase, int lane, i
 
 // EPI (bf16 epilogue flavour, compiled separately so that none carries the others' registers - the epilogue runs with all
 // 128 accumulators live and spills at the slightest extra state): 0 = (+bias), 1 = act 3 (bias + GELU, GELU' as the second
-// output), 2 = act 4 (x aux) + bias-gradient column sums, 3 = everything decided at run time (acts 1 / 2 and odd mixes).
+// output), 2 = act 4 (x aux) + bias-gradient column sums, 3 = everything decided at run time (acts 1 / 2 and odd mixes), 7 = act 1 (bias + GELU,
+// one output: the fc1 of a forward whose backward never runs - inference, the discarded forward of a checkpointed step).
 // Dynamic item scheduler of the bf16 (NT / NN) instances.  A static "workgroup b takes items b, b + 256, ..." split makes the kernel
 // twice as long whenever another kernel (an RCCL all-reduce overlapping the backward) holds a few CUs: the workgroups that could not
 // start run their whole list after the others have finished.  Instead every XCD's contiguous item range has an atomic cursor; a
@@ -894,7 +895,7 @@ __global__ __launch_bounds__(512) void gemm_pers_kernel(GemmParams p) {
     const long k0 = (long)z_ * p.k_per_split;
     const bool vq = PAIR && vt, hq = HALF && vt;
     const int rla = vq ? 9 : 8, rlb = (vq || hq) ? 7 : 8;   // log2 of the A / B image row (column) counts
-    const int ln = opaque<LAYOUT == 1 || (EPI >= 2)>(lane);
+    const int ln = opaque<LAYOUT == 1 || (EPI >= 2 && EPI != 7)>(lane);
 #pragma unroll
     for (int i = 0; i < 5; i++) {
       const int id = wave + NW * i;                    // full tile: 16 A + 16 B pieces; paired: 32 A + 8 B
@@ -1138,7 +1139,7 @@ __global__ __launch_bounds__(512) void gemm_pers_kernel(GemmParams p) {
       }
     }
     PXA_TR(4);
-    const int le = opaque<LAYOUT == 1 || (EPI >= 2)>(lane);          // NN: epilogue-only lane constants are rebuilt per item (see opaque())
+    const int le = opaque<LAYOUT == 1 || (EPI >= 2 && EPI != 7)>(lane);          // NN: epilogue-only lane constants are rebuilt per item (see opaque())
     const int srow = le & 31;
     if constexpr (LAYOUT == 2) {
       // fp32 weight-gradient tile: each 32 x 32 accumulator tile is parked in the wave's staging slice (128-byte rows, 16-byte
@@ -1185,7 +1186,7 @@ __global__ __launch_bounds__(512) void gemm_pers_kernel(GemmParams p) {
       if (!more) break;
       continue;
     }
-    const int act = (EPI == 0 || EPI == 5) ? 0 : EPI == 1 ? 3 : EPI == 2 ? 4 : (EPI == 4 || EPI == 6) ? 5 : p.act;   // EPI 4 / 6: + aux (residual connection)
+    const int act = (EPI == 0 || EPI == 5) ? 0 : EPI == 1 ? 3 : EPI == 2 ? 4 : (EPI == 4 || EPI == 6) ? 5 : EPI == 7 ? 1 : p.act;   // EPI 4 / 6: + aux (residual connection)
     constexpr bool want_st = (EPI == 5 || EPI == 6);   // + GroupNorm statistics of the output (implicit convolutions of the VAE)
     const bool dual = EPI == 1 || (EPI == 3 && ((p.act == 1 && p.out2 != nullptr) || p.act == 3));
     const bool want_cs = EPI == 2 || (EPI == 3 && p.colsum != nullptr);
@@ -1446,6 +1447,7 @@ int launch_glds(GemmParams p, int split, hipStream_t s) {
     if (p.act == 0 && !p.colsum) return hc ? launch_pers<LY, 0, 2>(p, 1, s) : launch_pers<LY, 0, 0>(p, 1, s);
     if (p.act == 3 && !p.colsum) return launch_pers<LY, 1, 0>(p, 1, s);      // fc1 forward: N = 4608, no remainder column
     if (p.act == 4 && p.colsum) return hc ? launch_pers<LY, 2, 2>(p, 1, s) : launch_pers<LY, 2, 0>(p, 1, s);
+    if constexpr (LY == 0) { if (p.act == 1 && !p.out2 && !p.colsum && !hc) return launch_pers<0, 7, 0>(p, 1, s); }
     return launch_pers<LY, 3, 0>(p, 1, s);
   }
   // fp32 weight gradients (TN, split-K slabs / single-slice read-modify-write / plain store): the same persistent kernel

@@ -279,8 +279,12 @@ class Engine:
         u2 = self._lin(cr, p + "cross_attn.proj")
         r = ops.ln_mod_fwd(x1, sl, scl, st, u=u2, x_out=x1, rows_per_batch=N, want_stats=True)
         x2, xn2, mean2, rstd2 = r["x"], r["xn"], r["mean"], r["rstd"]
-        hpre = torch.empty((B * N, S.shape[p + "mlp.fc1.weight"][0]), dtype=BF16, device=qkv.device)
-        h = self._lin(xn2, p + "mlp.fc1", act=ops.ACT_GELU_SAVE_GRAD, out2=hpre)   # hpre holds GELU'(pre-activation), bf16
+        if ctx.get("need_grad_aux", True):
+            hpre = torch.empty((B * N, S.shape[p + "mlp.fc1.weight"][0]), dtype=BF16, device=qkv.device)
+            h = self._lin(xn2, p + "mlp.fc1", act=ops.ACT_GELU_SAVE_GRAD, out2=hpre)   # hpre holds GELU'(pre-activation), bf16
+        else:                                      # inference / the discarded forward of a checkpointed step: no backward reads GELU' - one output, half the
+            hpre = None                            # epilogue's transcendentals and stores
+            h = self._lin(xn2, p + "mlp.fc1", act=ops.ACT_GELU)
         u3 = self._lin(h, p + "mlp.fc2")
         saved = dict(x_in=x_in, mean1=mean1, rstd1=rstd1, xn1=xn1, qkv=qkv, a=a, lse=lse, u1=u1, x1b=x1b, qc=qc, kvc=kvc,
                      cr=cr, lse_c=lse_c, x2=x2, mean2=mean2, rstd2=rstd2, xn2=xn2, hpre=hpre, h=h, u3=u3, kc=kc, vc=vc, sr=sr, qkn=qkn)
@@ -388,7 +392,7 @@ class Engine:
             starts = np.concatenate([[0], np.cumsum(lens)[:-1]]).astype(np.int32)
             self._len_cache[lk] = (torch.tensor(lens, dtype=torch.int32, device=dev), torch.from_numpy(starts).to(dev))
         kv_len, kv_start = self._len_cache[lk]
-        ctx = dict(B=B, N=N, hw=(h, w), mod=mod, kv_len=kv_len, kv_start=kv_start, max_len=int(max(lens)))
+        ctx = dict(B=B, N=N, hw=(h, w), mod=mod, kv_len=kv_len, kv_start=kv_start, max_len=int(max(lens)), need_grad_aux=(save == "all"))
         L = y.shape[0] // B
         tkey = None
         if save or torch.is_grad_enabled():
@@ -437,6 +441,7 @@ class Engine:
         ops.ln_mod_bwd(dxn, saved["x3"], saved["meanf"], saved["rstdf"], saved["fin_mod"][:, 1], 2 * D, None, G, dfin[:, 0], dfin[:, 1], 2 * D, N)
         if self.grad_ready_hook:
             self.grad_ready_hook("final")
+        ctx["need_grad_aux"] = True                      # the recomputed forwards of a checkpointed step feed block_bwd
         for l in reversed(range(depth)):
             sv = saved["blocks"][l]
             if saved["mode"] == "ckpt":   # recompute this block's activations from its saved input (auto_grad_checkpoint semantics)

@@ -88,6 +88,8 @@ def test_gemm_persistent_kernel_epilogues(ops, M, N, K):
     assert rel_l2(out2.float(), x.grad) < BF16_TOL
     out = ops.gemm(a, w, ops.NT, bias=b, act=ops.ACT_GELU, out2=out2)                          # run-time generic flavour
     assert rel_l2(out.float(), F.gelu(pre, approximate="tanh")) < BF16_TOL and rel_l2(out2.float(), pre) < BF16_TOL
+    out = ops.gemm(a, w, ops.NT, bias=b, act=ops.ACT_GELU)                                     # single output (inference forward of fc1)
+    assert rel_l2(out.float(), F.gelu(pre, approximate="tanh")) < BF16_TOL
     wt = bf(rnd(K, N, scale=K ** -0.5, seed=4))                                                # NN: dX = dY W
     ref = a.float() @ wt.float()
     aux = bf(rnd(M, N, seed=5))
