@@ -54,6 +54,9 @@ CASES = {
     "train_d2_micro": (dict(depth=2, input_size=16, model_max_length=20, micro_condition=True), dict(B=2, Hl=16, Wl=16, L=20, lens=[20, 9])),
     # forward_with_cfg (PixArtMS.py:221-234): batch = [cond half ; uncond half] over one latent half, guidance on 3 channels
     "cfg_d2": (dict(depth=2, input_size=16, model_max_length=20), dict(B=4, Hl=16, Wl=16, L=20, lens=[20, 9, 20, 20])),
+    # scripts/inference.py:89-101 (--sampling_algo iddpm): IDDPM(str(steps)).p_sample_loop over forward_with_cfg, batch = [cond ; null] on a repeated
+    # latent, clip_denoised=False as the script passes it (and True as the method's default); 5 respaced steps keep the CPU run short
+    "iddpm_d2": (dict(depth=2, input_size=16, model_max_length=20), dict(B=4, Hl=16, Wl=16, L=20, lens=[20, 9, 20, 20])),
     # BASELINE.json configs[0]: XL/2 256px, batch 2, 2 DPM-Solver steps, CFG 4.5, random-init, CPU
     "cfg1_xl2_256": (dict(depth=28, input_size=32, model_max_length=300, pe_interpolation=0.5), dict(B=2, Hl=32, Wl=32, L=300, lens=[300, 77])),
     # ---- round 3: the model bench.py times, FULL DEPTH at the headline geometry (PixArtMS_XL_2, depth 28, PixArtMS.py:291-293; 1024px: N = 4096,
@@ -131,6 +134,16 @@ def gen_case(name):
             if g.numel() <= full_max:
                 grads[k]["full"] = g.clone()
         out["grads"] = grads
+    elif name.startswith("iddpm"):
+        from diffusion import IDDPM
+        z = torch.cat([inp["x"][:2], inp["x"][:2]], dim=0)          # inference.py:91: randn(n, ...).repeat(2, 1, 1, 1)
+        kw = dict(y=inp["y"], cfg_scale=4.5, data_info=data_info, mask=mask)
+        out.update(steps=5, cfg_scale=4.5, noise_seed=11)
+        with torch.no_grad():
+            for key, clip in (("sample", False), ("sample_clip", True)):
+                torch.manual_seed(11)                                # the per-step th.randn_like draws (gaussian_diffusion.py:438) come from here
+                out[key] = IDDPM(str(5)).p_sample_loop(m.forward_with_cfg, z.shape, z, clip_denoised=clip, model_kwargs=kw, progress=False,
+                                                       device="cpu").clone()
     elif name.startswith("dpms") or name.startswith("cfg1"):
         from diffusion import DPMS
         g = torch.Generator().manual_seed(7)

@@ -3,8 +3,9 @@ diffusion/model/gaussian_diffusion.py:145-256,280-373,711-855, respace.py:65-134
 
 Host-side elementwise math on (B,4,h,w) latents, kept in PyTorch ("caller of the hot path"), with the
 reference's per-call numpy->device table copies (`_extract_into_tensor`, gaussian_diffusion.py:1038) replaced by
-schedule tables cached on the device.  Supported configuration = what train_scripts/train.py builds:
-IDDPM(str(N), learn_sigma=True, pred_sigma=True, snr=False) -> EPSILON mean, LEARNED_RANGE variance, MSE loss.
+schedule tables cached on the device.  Supported configuration = what train_scripts/train.py and scripts/inference.py build:
+IDDPM(str(N), learn_sigma=True, pred_sigma=True, snr=False) -> EPSILON mean, LEARNED_RANGE variance, MSE loss; training_losses for the first,
+p_sample_loop (ancestral sampling, `--sampling_algo iddpm`, scripts/inference.py:89-101) for the second.
 """
 import os
 
@@ -135,6 +136,68 @@ class SpacedDiffusion:
         vb = torch.where(t == 0, nll, kl)
         mse = ((noise - eps) ** 2).flatten(1).mean(1)
         return {"loss": mse + vb, "mse": mse, "vb": vb}
+
+
+    # ------------------------------------------------------------------ ancestral sampling (scripts/inference.py --sampling_algo iddpm)
+    def p_mean_variance(self, model, x, t, clip_denoised=True, denoised_fn=None, model_kwargs=None):
+        """p(x_{t-1} | x_t) of the EPSILON / LEARNED_RANGE model (gaussian_diffusion.py:280-361 through respace.py:89-134): one denoiser call at
+        the ORIGINAL timestep of respaced step t, then elementwise math on the latent with the device-resident schedule tables."""
+        T = self._tab(x.device)
+        nd = x.dim()
+        B, C = x.shape[:2]
+        assert t.shape == (B,)
+        out = model(x, timestep=T["tmap"][t].to(t.dtype), **(model_kwargs or {}))
+        if isinstance(out, tuple):
+            out = out[0]
+        assert out.shape == (B, C * 2, *x.shape[2:])
+        eps, var_v = torch.split(out.float(), C, dim=1)
+        frac = (var_v + 1) / 2                                          # [-1, 1] -> [posterior variance, beta], in the log domain
+        log_variance = frac * self._ex(T["log_betas"], t, nd) + (1 - frac) * self._ex(T["post_logvar"], t, nd)
+        pred_xstart = self._ex(T["sqrt_recip_ac"], t, nd) * x - self._ex(T["sqrt_recipm1_ac"], t, nd) * eps
+        if denoised_fn is not None:
+            pred_xstart = denoised_fn(pred_xstart)
+        if clip_denoised:
+            pred_xstart = pred_xstart.clamp(-1, 1)
+        mean = self._ex(T["post_c1"], t, nd) * pred_xstart + self._ex(T["post_c2"], t, nd) * x
+        return {"mean": mean, "variance": torch.exp(log_variance), "log_variance": log_variance, "pred_xstart": pred_xstart, "extra": None}
+
+    def p_sample(self, model, x, t, clip_denoised=True, denoised_fn=None, cond_fn=None, model_kwargs=None, noise=None):
+        """x_{t-1} ~ p(. | x_t) (gaussian_diffusion.py:405-446).  `noise` (optional) replaces the fresh N(0, I) draw - the parity tests feed the
+        reference's own draws."""
+        if cond_fn is not None:
+            raise NotImplementedError("classifier guidance (cond_fn) has no call site in PixArt")
+        out = self.p_mean_variance(model, x, t, clip_denoised=clip_denoised, denoised_fn=denoised_fn, model_kwargs=model_kwargs)
+        if noise is None:
+            noise = torch.randn_like(x)
+        nonzero = (t != 0).float().reshape(-1, *([1] * (x.dim() - 1)))   # the last step returns the mean
+        return {"sample": out["mean"] + nonzero * torch.exp(0.5 * out["log_variance"]) * noise, "pred_xstart": out["pred_xstart"]}
+
+    def p_sample_loop_progressive(self, model, shape, noise=None, clip_denoised=True, denoised_fn=None, cond_fn=None, model_kwargs=None, device=None,
+                                  progress=False, step_noise=None):
+        """gaussian_diffusion.py:493-543.  step_noise: optional callable(x) -> noise for the step (default torch.randn_like)."""
+        if device is None:
+            device = next(model.parameters()).device if hasattr(model, "parameters") else (noise.device if noise is not None else "cuda")
+        img = noise if noise is not None else torch.randn(*shape, device=device)
+        indices = list(range(self.num_timesteps))[::-1]
+        if progress:
+            from tqdm.auto import tqdm
+            indices = tqdm(indices)
+        for i in indices:
+            t = torch.full((shape[0],), i, device=img.device, dtype=torch.long)
+            with torch.no_grad():
+                out = self.p_sample(model, img, t, clip_denoised=clip_denoised, denoised_fn=denoised_fn, cond_fn=cond_fn, model_kwargs=model_kwargs,
+                                    noise=None if step_noise is None else step_noise(img))
+            yield out
+            img = out["sample"]
+
+    def p_sample_loop(self, model, shape, noise=None, clip_denoised=True, denoised_fn=None, cond_fn=None, model_kwargs=None, device=None,
+                      progress=False, step_noise=None):
+        """gaussian_diffusion.py:448-491: the final sample of the chain above (num_timesteps denoiser calls)."""
+        final = None
+        for final in self.p_sample_loop_progressive(model, shape, noise=noise, clip_denoised=clip_denoised, denoised_fn=denoised_fn, cond_fn=cond_fn,
+                                                    model_kwargs=model_kwargs, device=device, progress=progress, step_noise=step_noise):
+            pass
+        return final["sample"]
 
 
 def _approx_standard_normal_cdf(x):

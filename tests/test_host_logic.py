@@ -180,3 +180,31 @@ def test_store_notices_parameters_moved_out_by_a_standalone_block(monkeypatch):
     m._prepare(torch.device("cpu"))                               # what the next forward does
     assert m._store is not st and m._store.owns_all(m._ordered_named_params())
     assert float(m._store.f("blocks.1.attn.proj.weight").mean()) == 0.25
+
+
+def test_iddpm_ancestral_sampler_host_math_matches_reference():
+    """pixart_sigma_amd.diffusion.iddpm.SpacedDiffusion.p_sample_loop is host-side elementwise math around the denoiser call: with the oracle's
+    forward_with_cfg standing in for the denoiser (CPU) it must reproduce the reference's 5-step chain of tests/golden/iddpm_d2.pt."""
+    import os
+    import torch
+    from oracle import pixart_oracle as po
+    from oracle.weights import make_inputs, make_state_dict
+    from pixart_sigma_amd.diffusion.iddpm import IDDPM
+    g = torch.load(os.path.join(os.path.dirname(__file__), "golden", "iddpm_d2.pt"), weights_only=False)
+    cfg = po.OracleCfg(**g["cfg"])
+    sd = make_state_dict(cfg, seed=g["weights_seed"])
+    inp = make_inputs(seed=g["inputs_seed"], **g["inputs"])
+    z = torch.cat([inp["x"][:2], inp["x"][:2]], dim=0)
+    diff = IDDPM(str(g["steps"]))
+    assert diff.timestep_map == [0, 250, 500, 749, 999] and diff.num_timesteps == 5
+    seen = []
+
+    def model(x, timestep, **kw):
+        seen.append(int(timestep[0]))
+        return po.forward_with_cfg(sd, cfg, x, timestep, inp["y"], g["cfg_scale"], inp["mask"])
+    for key, clip in (("sample", False), ("sample_clip", True)):
+        torch.manual_seed(g["noise_seed"])
+        with torch.no_grad():
+            out = diff.p_sample_loop(model, z.shape, z, clip_denoised=clip, device="cpu", step_noise=lambda x: torch.randn(x.shape))
+        assert ((out - g[key]).norm() / g[key].norm()).item() < 5e-5, key
+    assert seen[:5] == [999, 749, 500, 250, 0]          # the denoiser is called at the ORIGINAL timesteps (respace.py:128-134)

@@ -42,6 +42,28 @@ def test_forward_with_cfg_matches_reference(golden):
     assert torch.equal(y[:2, :3], y[2:, :3]) and not torch.equal(y[:2, 3:], y[2:, 3:])
 
 
+def _step_noises(seed, shape, n):
+    """The reference's per-step th.randn_like(x) draws (gaussian_diffusion.py:438) on the CPU generator, in loop order."""
+    torch.manual_seed(seed)
+    return [torch.randn(shape) for _ in range(n)]
+
+
+@pytest.mark.parametrize("key,clip", [("sample", False), ("sample_clip", True)])
+def test_iddpm_ancestral_sampling_matches_reference(golden, key, clip):
+    """IDDPM(str(5)).p_sample_loop over forward_with_cfg (scripts/inference.py:89-101): respaced schedule, original-timestep mapping, learned-range
+    variance, noise on every step but the last - the oracle's restatement against the reference's own 5-step chain."""
+    g = golden("iddpm_d2")
+    cfg, sd, inp, mask = _setup(g)
+    z = torch.cat([inp["x"][:2], inp["x"][:2]], dim=0)
+    samp = po.RespacedSamplerOracle(g["steps"])
+    assert samp.timestep_map == [0, 250, 500, 749, 999]
+    noises = _step_noises(g["noise_seed"], z.shape, g["steps"])
+    with torch.no_grad():
+        out = samp.p_sample_loop(lambda x, t: po.forward_with_cfg(sd, cfg, x, t, inp["y"], g["cfg_scale"], mask), z, noises, clip_denoised=clip)
+    assert rel_l2(out, g[key]) < 5e-5
+    assert rel_l2(g["sample"], g["sample_clip"]) > 1e-3          # the clamp is live on this input
+
+
 def test_micro_condition_changes_the_output(golden):
     """The size / aspect-ratio embeddings really enter t (PixArtMS.py:187-191): other data_info -> other output."""
     g = golden("fwd_d2_micro")

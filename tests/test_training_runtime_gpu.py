@@ -123,3 +123,19 @@ def test_train_entry_point_fp16_accumulation_schedule(tmp_path):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "train_scripts", "train.py"), str(bad), "--synthetic", "--max-steps", "1"], capture_output=True, text=True,
                        timeout=300, cwd=ROOT)
     assert r.returncode != 0 and "use_fancy_thing" in (r.stdout + r.stderr)
+
+
+@pytest.mark.parametrize("algo,steps", [("dpm-solver", 3), ("iddpm", 4)])
+def test_inference_entry_point_samplers(tmp_path, algo, steps):
+    """scripts/inference.py with the reference's CLI (reference scripts/inference.py:24-44, 86-118) on synthetic caption features: both built samplers run
+    the HIP denoiser end to end (256px, two prompts, batch 2 -> model batch 4 with CFG) and write finite latents of the right shape."""
+    txt = tmp_path / "prompts.txt"
+    txt.write_text("a red cube\na blue sphere\n")
+    env = {k: v for k, v in os.environ.items() if k not in ("PXA_OPERAND_DTYPE", "PXA_LIB_PATH")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "inference.py"), "--image_size", "256", "--txt_file", str(txt), "--bs", "2", "--synthetic",
+                        "--sampling_algo", algo, "--step", str(steps), "--save_name", f"pytest_{algo}", "--pipeline_load_from", str(tmp_path / "none")],
+                       capture_output=True, text=True, timeout=900, cwd=str(tmp_path), env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    assert f"in {steps} steps" in r.stdout
+    lat = torch.load(tmp_path / "output" / f"pytest_{algo}" / "latents_0.pt", map_location="cpu")
+    assert tuple(lat.shape) == (2, 4, 32, 32) and torch.isfinite(lat).all() and lat.std() > 0.1
