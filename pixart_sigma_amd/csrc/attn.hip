@@ -716,6 +716,141 @@ __global__ __launch_bounds__(256, 2) void attn_fwd2_kernel(AttnParams p) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------ forward, all keys resident (cross-attention)
+// Text keys are few (L <= 300): with one 256-query workgroup per launch unit, as above, a cross-attention forward is 4,096 workgroups that each
+// pay a query load, the pads, a first LDS-DMA and a barrier per 64-key tile for five tiles of work - 100 of its 165 us do not depend on L
+// (profiles/r03zd_cross_vs_len.txt).  Here ONE 512-thread workgroup loads ALL of a sample's K and V rows for its head once (<= KVRES_TILES tiles, both
+// operands: <= 120 KiB, one workgroup per CU, two waves per SIMD) and then walks `qpb` queries, 64 per wave and trip, with no DMA and no barrier in
+// the loop: the tile body is attn_fwd2_kernel's, reading the resident tiles.
+constexpr int KVRES_TILES = 5;                       // 320 keys
+__global__ __launch_bounds__(512, 1) void attn_fwd_kvres_kernel(AttnParams p, int qpb, int tiles_alloc) {
+  constexpr int QS = 2;
+  extern __shared__ __attribute__((aligned(16))) char smem_dyn[];
+  char* smem = smem_dyn;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), hi = lane >> 5;
+  int bx, h, b;
+  block_coords(p, bx, h, b);
+  long kbase, vbase, d0_, d1_; int kvlen;
+  kv_range(p, b, kbase, vbase, d0_, d1_, kvlen);
+  const bf16_t* Kp = p.K + kbase + (long)h * p.k_hs;
+  const bf16_t* Vp = p.V + vbase + (long)h * p.v_hs;
+  kvlen = min(kvlen, tiles_alloc * BKV);                       // (the host sized the LDS for max_kv_len: a longer sample would be a caller error)
+  const int Tfull = kvlen / BKV, rem = kvlen - Tfull * BKV, T = Tfull + (rem ? 1 : 0);
+  {   // waves 0-3 fetch the K tiles, waves 4-7 the V tiles (each group is the four-wave DMA team of the kernels above); pads once per tile
+    DmaPlan pl;
+    dma_plan(pl, wave & 3, lane);
+    const bool vside = wave >= 4;
+    for (int t = 0; t < T; t++) {
+      char* dst = smem + t * 2 * TILE_B + (vside ? TILE_B : 0);
+      init_pads(dst, vside ? 1 : 0, tid & 255);               // V: column 72 = 1 -> O^T row 72 accumulates sum_kv P = l
+      if (t < Tfull) dma_tile<true>(dst, vside ? Vp : Kp, vside ? (int)p.v_ts : (int)p.k_ts, t * BKV, kvlen, pl, wave & 3);
+      else dma_tile<false>(dst, vside ? Vp : Kp, vside ? (int)p.v_ts : (int)p.k_ts, t * BKV, kvlen, pl, wave & 3);
+    }
+  }
+  FragAddr fa;
+  frag_addr(fa, lane);
+  Tr16Addr ta;
+  tr16_addr(ta, lane);
+  const float c = p.scale_log2;
+  tile_sync();
+  for (int q0b = bx * qpb; q0b < min(p.Nq, (bx + 1) * qpb); q0b += 512) {
+    const int q0w = q0b + wave * 64;
+    if (q0w >= p.Nq) break;                                    // wave-uniform; nothing below synchronises the workgroup
+    int q[QS];
+    bool qvalid[QS];
+    bf16x8 qf[QS][KSTEPS];
+#pragma unroll
+    for (int s = 0; s < QS; s++) {
+      q[s] = q0w + s * 32 + (lane & 31);
+      qvalid[s] = q[s] < p.Nq;
+      load_row_frags(qf[s], p.Q + (long)b * p.q_bs + (long)q[s] * p.q_ts + (long)h * p.q_hs, qvalid[s], hi);
+    }
+    Acc16 o[QS];
+    float m[QS];
+#pragma unroll
+    for (int s = 0; s < QS; s++) {
+      zero16(o[s]);
+      m[s] = -INFINITY;
+    }
+    auto tile = [&](auto tailc, const char* sK, const char* sV, int kv0) {
+      constexpr bool TAIL = decltype(tailc)::value;
+      f32x16 sc[QS][2];
+#pragma unroll
+      for (int s = 0; s < QS; s++)
+#pragma unroll
+        for (int sub = 0; sub < 2; sub++)
+#pragma unroll
+          for (int g = 0; g < 16; g++) sc[s][sub][g] = 0.f;
+#pragma unroll
+      for (int sub = 0; sub < 2; sub++)
+#pragma unroll
+        for (int ks = 0; ks < KSTEPS; ks++) {
+          const bf16x8 kf = rowfrag(sK, fa, sub, ks);
+#pragma unroll
+          for (int s = 0; s < QS; s++) sc[s][sub] = mfma32(kf, qf[s][ks], sc[s][sub]);
+        }
+#pragma unroll
+      for (int s = 0; s < QS; s++) {
+        if (TAIL) {
+#pragma unroll
+          for (int sub = 0; sub < 2; sub++)
+#pragma unroll
+            for (int g = 0; g < 16; g++)
+              if (kv0 + sub * 32 + (g & 3) + 8 * (g >> 2) + 4 * hi >= kvlen) sc[s][sub][g] = -INFINITY;
+        }
+        float mt = sc[s][0][0];
+#pragma unroll
+        for (int sub = 0; sub < 2; sub++)
+#pragma unroll
+          for (int g = 0; g < 16; g++) mt = fmaxf(mt, sc[s][sub][g]);
+        mt = fmaxf(mt, __shfl_xor(mt, 32));
+        if (__builtin_amdgcn_readfirstlane(__any((mt - m[s]) * c > RESCALE_LOG2))) {   // deferred rescale, see attn_fwd_kernel
+          asm volatile("" ::: "memory");
+          const float mn = fmaxf(m[s], mt);
+          const float alpha = __builtin_amdgcn_exp2f((m[s] - mn) * c);
+          m[s] = mn;
+          const float ao = __shfl_xor(alpha, 16);
+          const float a0 = (lane & 16) ? ao : alpha, a1 = (lane & 16) ? alpha : ao;
+#pragma unroll
+          for (int t = 0; t < NT16; t++) { o[s].v[t][0] *= a0; o[s].v[t][1] *= a1; }
+        }
+        const float mc = m[s] * c;
+#pragma unroll
+        for (int sub = 0; sub < 2; sub++)
+#pragma unroll
+          for (int g = 0; g < 16; g++) sc[s][sub][g] = __builtin_amdgcn_exp2f(sc[s][sub][g] * c - mc);
+      }
+#pragma unroll
+      for (int sub = 0; sub < 2; sub++) {
+        bf16x8 px[QS], py[QS];
+#pragma unroll
+        for (int s = 0; s < QS; s++) pack_xy(sc[s][sub], px[s], py[s]);
+#pragma unroll
+        for (int t = 0; t < NT16; t++) {
+          const bf16x8 vf = trfrag16(sV, ta, t, sub);
+#pragma unroll
+          for (int s = 0; s < QS; s++) {
+            o[s].v[t][0] = mfma16(vf, px[s], o[s].v[t][0]);
+            o[s].v[t][1] = mfma16(vf, py[s], o[s].v[t][1]);
+          }
+        }
+      }
+    };
+    for (int t = 0; t < Tfull; t++) tile(BoolC<false>{}, smem + t * 2 * TILE_B, smem + t * 2 * TILE_B + TILE_B, t * BKV);
+    if (rem) tile(BoolC<true>{}, smem + Tfull * 2 * TILE_B, smem + Tfull * 2 * TILE_B + TILE_B, Tfull * BKV);
+#pragma unroll
+    for (int s = 0; s < QS; s++) {
+      const float la = __shfl(o[s].v[4][0][0], 32 + (lane & 15)), lb = __shfl(o[s].v[4][1][0], 32 + (lane & 15));
+      const float l = (lane & 16) ? lb : la;
+      const float inv = l > 0.f ? 1.f / l : 0.f, invo = __shfl_xor(inv, 16);
+      const int q0s = q0w + s * 32;
+      store_rows16(p.O + (long)b * p.o_bs + (long)q0s * p.o_ts + (long)h * p.o_hs, p.o_ts, o[s], (lane & 16) ? invo : inv, (lane & 16) ? inv : invo,
+                   q0s + (lane & 15) < p.Nq, q0s + 16 + (lane & 15) < p.Nq, lane);
+      if (qvalid[s] && hi == 0 && p.LSE) p.LSE[((long)b * p.H + h) * p.Nq + q[s]] = m[s] * c + log2f(l);
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ backward: dQ
 #ifndef ATTN_BWD_WAVES
 #define ATTN_BWD_WAVES 2
@@ -1721,6 +1856,22 @@ extern "C" int pxa_attn_fwd(const pxa_attn_args* a, hipStream_t stream) {
   if (int rc = fill(p, a)) return rc;
   PXA_CHECK(p.Q && p.K && p.V && p.O, "pxa_attn_fwd: null tensor");
   static const bool one_sub = getenv("PXA_ATTN_FWD1") != nullptr;   // A/B: the one-sub-tile kernel
+  static const bool no_kvres = getenv("PXA_ATTN_NO_KVRES") != nullptr;   // A/B: cross-attention on the streaming kernel
+  const int max_k = a->max_kv_len > 0 ? a->max_kv_len : p.Nk;
+  if (!no_kvres && !one_sub && max_k > 0 && max_k <= KVRES_TILES * BKV && p.Nq >= 512) {   // every key of a sample fits one workgroup's LDS: attn_fwd_kvres_kernel
+    const int tiles = (max_k + BKV - 1) / BKV, lds = tiles * 2 * TILE_B;
+    const int qpb = p.Nq >= 4096 ? 4096 : (p.Nq + 511) / 512 * 512;        // a whole head per workgroup up to 4,096 queries
+    static bool attr_set = false;
+    if (!attr_set) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_kvres_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, KVRES_TILES * 2 * TILE_B);
+      PXA_CHECK(e == hipSuccess, "pxa_attn_fwd: hipFuncSetAttribute: %s", hipGetErrorString(e));
+      attr_set = true;
+    }
+    p.nx = (p.Nq + qpb - 1) / qpb;
+    hipLaunchKernelGGL(attn_fwd_kvres_kernel, dim3(p.nx * p.H * p.B), dim3(512), lds, stream, p, qpb, tiles);
+    PXA_LAUNCH_CHECK();
+    return 0;
+  }
   const bool two = !one_sub && p.Nq >= 256;
   p.nx = two ? (p.Nq + 255) / 256 : (p.Nq + 127) / 128;
   PXA_CHECK((long)p.nx * p.H * p.B < (1L << 31), "pxa_attn_fwd: grid too large");

@@ -308,6 +308,36 @@ def test_attention_varlen_cross(ops):
     assert rel_l2(dkv.float().view(tot, 2, H, 72), kvr.grad) < 2 * BF16_TOL
 
 
+@pytest.mark.parametrize("N,lens", [(4133, [300, 7, 64, 129]), (1024, [320, 1, 65]), (600, [20, 300])])
+def test_attention_forward_keys_resident(ops, N, lens):
+    """Cross-attention forward with every key of a sample resident in LDS (attn_fwd_kvres_kernel: max_kv_len <= 320 and N_q >= 512): ragged text
+    lengths incl. 1 key, exact tile multiples and the 320-key maximum; query counts that are no multiple of the 64-query trip, the 512-query round or
+    the 4,096-query workgroup; O and the log-sum-exp the backward reads, against per-sample fp32 attention.  A spike key in the last tile forces the
+    online-softmax rescale inside the resident loop."""
+    B, H = len(lens), 16
+    C = H * 72
+    tot = sum(lens)
+    q = bf(rnd(B, N, C, seed=1))
+    kv = bf(rnd(tot, 2 * C, seed=2))
+    starts = [sum(lens[:i]) for i in range(B)]
+    kv[starts[0] + lens[0] - 1, :72] = q[0, 5, :72] * 6            # head 0 of sample 0: its last key dominates query 5
+    kv_start = torch.tensor(starts, dtype=torch.int32, device="cuda")
+    kv_len = torch.tensor(lens, dtype=torch.int32, device="cuda")
+    o = torch.full((B, N, C), float("nan"), dtype=ops.BF16, device="cuda")
+    lse = torch.full((B, H, N), float("nan"), device="cuda")
+    st = ((N * C, C, 72), (0, 2 * C, 72), (0, 2 * C, 72), (N * C, C, 72))
+    ops.attention_fwd(q, kv[:, :C], kv[:, C:], o, lse, B, H, N, max(lens), st, kv_start=kv_start, kv_len=kv_len, max_kv_len=max(lens))
+    qr = q.float().view(B, N, H, 72)
+    kvr = kv.float().view(tot, 2, H, 72)
+    for b, (s0, n) in enumerate(zip(starts, lens)):
+        oref = _attn_ref(qr[b:b + 1], kvr[s0:s0 + n, 0][None], kvr[s0:s0 + n, 1][None])
+        assert rel_l2(o[b].float().view(1, N, H, 72), oref) < BF16_TOL, (b, n)
+        sc = torch.einsum("nhd,khd->hnk", qr[b], kvr[s0:s0 + n, 0]) * 72 ** -0.5
+        lref = torch.logsumexp(sc, dim=-1) * 1.4426950408889634       # the kernels keep log2-domain statistics
+        assert (lse[b] - lref).abs().max() < 2e-2, (b, n)
+    assert torch.isfinite(o.float()).all() and torch.isfinite(lse).all()
+
+
 def test_attention_online_softmax_rescale(ops):
     """A key far above the running max arriving in a late tile forces the rescale branch (guide rule 26)."""
     B, H, N = 1, 1, 256
