@@ -1596,6 +1596,108 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq2_kernel(AttnParams p) {
 }
 
 
+// ------------------------------------------------------------------------------------------------ backward: dQ, all keys resident (cross-attention)
+// attn_fwd_kvres_kernel's organisation for the dQ product of a cross-attention backward (max_kv_len <= 320): one 512-thread workgroup keeps the K and V
+// rows of its (sample, head) in LDS and walks its queries, 32 per wave and trip - and because a wave holds the whole dO row of its query anyway, the
+// delta pre-pass (a separate kernel reading O and dO: 52 us per call) folds in: the wave loads the O row beside it, forms delta = rowsum(dO o O), writes
+// it (and, for the dK/dV kernel that runs afterwards, the lse / delta statistics rows) and carries it into the dP product through dO's pad slots
+// (ATTN_FOLD_DELTA).  The tile body is attn_bwd_dq2_kernel's compiler-scheduled tail form on the resident tiles: no DMA, no barrier in the loop.
+__global__ __launch_bounds__(512, 1) void attn_bwd_dq_kvres_kernel(AttnParams p, int qpb, int tiles_alloc, float* delta_out, bf16_t* stats_out, float inv_c) {
+  extern __shared__ __attribute__((aligned(16))) char smem_dyn[];
+  char* smem = smem_dyn;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), hi = lane >> 5;
+  int bx, h, b;
+  block_coords(p, bx, h, b);
+  long kbase, vbase, d0_, d1_; int kvlen;
+  kv_range(p, b, kbase, vbase, d0_, d1_, kvlen);
+  const bf16_t* Kp = p.K + kbase + (long)h * p.k_hs;
+  const bf16_t* Vp = p.V + vbase + (long)h * p.v_hs;
+  kvlen = min(kvlen, tiles_alloc * BKV);
+  const int Tfull = kvlen / BKV, rem = kvlen - Tfull * BKV, T = Tfull + (rem ? 1 : 0);
+  {
+    DmaPlan pl;
+    dma_plan(pl, wave & 3, lane);
+    const bool vside = wave >= 4;
+    for (int t = 0; t < T; t++) {
+      char* dst = smem + t * 2 * TILE_B + (vside ? TILE_B : 0);
+      init_pads(dst, vside ? 2 : 0, tid & 255);               // V: -1.0 in slots 72 .. 74 (delta rides in the dP product)
+      if (t < Tfull) dma_tile<true>(dst, vside ? Vp : Kp, vside ? (int)p.v_ts : (int)p.k_ts, t * BKV, kvlen, pl, wave & 3);
+      else dma_tile<false>(dst, vside ? Vp : Kp, vside ? (int)p.v_ts : (int)p.k_ts, t * BKV, kvlen, pl, wave & 3);
+    }
+  }
+  FragAddr fa;
+  frag_addr(fa, lane);
+  Tr16Addr ta;
+  tr16_addr(ta, lane);
+  const float c = p.scale_log2;
+  const long rows_total = (long)p.B * p.H * p.Nq64;
+  tile_sync();
+  for (int q0b = bx * qpb; q0b < min(p.Nq, (bx + 1) * qpb); q0b += 256) {
+    const int q0w = q0b + wave * 32;
+    if (q0w >= p.Nq) break;                                    // wave-uniform
+    const int q = q0w + (lane & 31);
+    const bool qvalid = q < p.Nq;
+    bf16x8 qf[KSTEPS], dof[KSTEPS], of[KSTEPS];
+    load_row_frags(qf, p.Q + (long)b * p.q_bs + (long)q * p.q_ts + (long)h * p.q_hs, qvalid, hi);
+    load_row_frags(dof, p.dO + (long)b * p.o_bs + (long)q * p.o_ts + (long)h * p.o_hs, qvalid, hi);
+    load_row_frags(of, p.O + (long)b * p.o_bs + (long)q * p.o_ts + (long)h * p.o_hs, qvalid, hi);
+    const long sidx = ((long)b * p.H + h) * p.Nq + q;
+    const float lse = qvalid ? p.LSE[sidx] : 0.f;
+    float part = 0.f;                                          // this lane's 40 of the row's 80 slots (slots 72 .. 79 are zero in both rows)
+#pragma unroll
+    for (int ks = 0; ks < KSTEPS; ks++)
+#pragma unroll
+      for (int j = 0; j < 8; j++) part += (float)dof[ks][j] * (float)of[ks][j];
+    const float delta = part + __shfl_xor(part, 32);
+    if (qvalid && hi == 0) {
+      delta_out[sidx] = delta;
+      write_stat_rows(stats_out, rows_total, ((long)b * p.H + h) * p.Nq64 + q, lse * inv_c, delta);
+    }
+    if (hi == 1) {                                            // slots 72 .. 74 of this lane's dO row: delta as three operand-type terms (split3)
+      typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+      u32x4 w = __builtin_bit_cast(u32x4, dof[KSTEPS - 1]);
+      const uint2 d3 = split3(delta);
+      w[0] = d3.x; w[1] = d3.y;
+      dof[KSTEPS - 1] = __builtin_bit_cast(bf16x8, w);
+    }
+    Acc16 dq;
+    zero16(dq);
+    auto tile = [&](auto tailc, const char* sK, const char* sV, int kv0) {
+      constexpr bool TAIL = decltype(tailc)::value;
+      f32x16 sv[2], dpv[2];
+#pragma unroll
+      for (int sub = 0; sub < 2; sub++) {
+#pragma unroll
+        for (int g = 0; g < 16; g++) { sv[sub][g] = 0.f; dpv[sub][g] = 0.f; }
+#pragma unroll
+        for (int ks = 0; ks < KSTEPS; ks++) {
+          sv[sub] = mfma32(rowfrag(sK, fa, sub, ks), qf[ks], sv[sub]);
+          dpv[sub] = mfma32(rowfrag(sV, fa, sub, ks), dof[ks], dpv[sub]);
+        }
+      }
+#pragma unroll
+      for (int sub = 0; sub < 2; sub++)
+#pragma unroll
+        for (int g = 0; g < 16; g++) {
+          float pr = __builtin_amdgcn_exp2f(sv[sub][g] * c - lse);
+          if (TAIL && kv0 + sub * 32 + (g & 3) + 8 * (g >> 2) + 4 * hi >= kvlen) pr = 0.f;
+          sv[sub][g] = pr * dpv[sub][g];
+        }
+#pragma unroll
+      for (int sub = 0; sub < 2; sub++) {
+        bf16x8 dx, dy;
+        pack_xy(sv[sub], dx, dy);
+        mma16(dq, sK, ta, sub, dx, dy);
+      }
+    };
+    for (int t = 0; t < Tfull; t++) tile(BoolC<false>{}, smem + t * 2 * TILE_B, smem + t * 2 * TILE_B + TILE_B, t * BKV);
+    if (rem) tile(BoolC<true>{}, smem + Tfull * 2 * TILE_B, smem + Tfull * 2 * TILE_B + TILE_B, Tfull * BKV);
+    const bool ok0 = q0w + (lane & 15) < p.Nq, ok1 = q0w + 16 + (lane & 15) < p.Nq;
+    store_rows16(p.dQ + (long)b * p.dq_bs + (long)q0w * p.dq_ts + (long)h * p.dq_hs, p.dq_ts, dq, p.scale, p.scale, ok0, ok1, lane);
+    if (p.dq_colsum) colsum_rows16(p.dq_colsum + (b % PXA_COLSUM_SLOTS) * p.colsum_stride + h * DH, dq, p.scale, ok0, ok1, lane);
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ backward: dK, dV as a phase ping-pong (round 3, second form)
 // What the hand-placed kernel above could not fix: its two waves per SIMD come from different workgroups, are in-order and uncoordinated - each blocks
 // on the matrix pipe while the partner's MFMA runs and cannot issue its softmax meanwhile (47 cycles per MFMA against a 32-cycle floor).  Here ONE
@@ -1903,7 +2005,11 @@ extern "C" int pxa_attn_bwd(const pxa_attn_args* a, hipStream_t stream) {
     hipLaunchKernelGGL(attn_stats_pad_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, stats, p.B * p.H, p.Nq, p.Nq64);
   }
   const bool no_prepass = getenv("PXA_ATTN_BWD_NO_PREPASS") != nullptr;   // measurement only (bench.py): delta / stats rows of the SAME inputs are still in the workspace
-  if (no_prepass) {
+  // cross-attention (every key of a sample fits one workgroup's LDS): the dQ kernel keeps them resident and takes over the delta / statistics pre-pass
+  static const bool no_kvres = getenv("PXA_ATTN_NO_KVRES") != nullptr;
+  const int max_kr = a->max_kv_len > 0 ? a->max_kv_len : p.Nk;
+  const bool dq_kvres = !no_kvres && ATTN_FOLD_DELTA && p.dQ && max_kr > 0 && max_kr <= KVRES_TILES * BKV && p.Nq >= 512;
+  if (no_prepass || dq_kvres) {
   } else if (p.o_hs == DH && p.o_ts == (long)p.H * DH && p.o_bs == (long)p.Nq * p.o_ts && p.H <= 16 && ((uintptr_t)p.O % 16) == 0 && ((uintptr_t)p.dO % 16) == 0) {
     const long tokens = (long)p.B * p.Nq;                  // token-contiguous rows: the coalesced form
     hipLaunchKernelGGL(attn_delta_rows_kernel, dim3((tokens + DELTA_TOK - 1) / DELTA_TOK), dim3(256), 0, stream, p.O, p.dO, a->delta, p.H, p.Nq, tokens,
@@ -1913,7 +2019,19 @@ extern "C" int pxa_attn_bwd(const pxa_attn_args* a, hipStream_t stream) {
                        p.o_bs, p.o_ts, p.o_hs, p.o_bs, p.o_ts, p.o_hs, p.B, p.H, p.Nq, p.LSE, stats, p.Nq64, inv_c);
   }
   PXA_LAUNCH_CHECK();
-  if (p.dQ) {
+  if (dq_kvres) {
+    const int tiles = (max_kr + BKV - 1) / BKV, lds = tiles * 2 * TILE_B;
+    const int qpb = p.Nq >= 4096 ? 4096 : (p.Nq + 255) / 256 * 256;
+    static bool attr_set = false;
+    if (!attr_set) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dq_kvres_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, KVRES_TILES * 2 * TILE_B);
+      PXA_CHECK(e == hipSuccess, "pxa_attn_bwd: hipFuncSetAttribute: %s", hipGetErrorString(e));
+      attr_set = true;
+    }
+    p.nx = (p.Nq + qpb - 1) / qpb;
+    hipLaunchKernelGGL(attn_bwd_dq_kvres_kernel, dim3(p.nx * p.H * p.B), dim3(512), lds, stream, p, qpb, tiles, a->delta, stats, inv_c);
+    PXA_LAUNCH_CHECK();
+  } else if (p.dQ) {
     p.nx = (p.Nq + 127) / 128;
     PXA_CHECK((long)p.nx * p.H * p.B < (1L << 31), "pxa_attn_bwd: grid too large");
     const char* dqe = getenv("PXA_ATTN_DQ");                // 0 = round-2 kernel (compiler-scheduled), 1 = hand-placed pipeline (needs the delta fold)

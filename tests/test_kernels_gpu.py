@@ -309,8 +309,8 @@ def test_attention_varlen_cross(ops):
 
 
 @pytest.mark.parametrize("N,lens", [(4133, [300, 7, 64, 129]), (1024, [320, 1, 65]), (600, [20, 300])])
-def test_attention_forward_keys_resident(ops, N, lens):
-    """Cross-attention forward with every key of a sample resident in LDS (attn_fwd_kvres_kernel: max_kv_len <= 320 and N_q >= 512): ragged text
+def test_attention_keys_resident(ops, N, lens):
+    """Cross-attention with every key of a sample resident in LDS (attn_fwd_kvres_kernel, attn_bwd_dq_kvres_kernel: max_kv_len <= 320 and N_q >= 512): ragged text
     lengths incl. 1 key, exact tile multiples and the 320-key maximum; query counts that are no multiple of the 64-query trip, the 512-query round or
     the 4,096-query workgroup; O and the log-sum-exp the backward reads, against per-sample fp32 attention.  A spike key in the last tile forces the
     online-softmax rescale inside the resident loop."""
@@ -336,6 +336,21 @@ def test_attention_forward_keys_resident(ops, N, lens):
         lref = torch.logsumexp(sc, dim=-1) * 1.4426950408889634       # the kernels keep log2-domain statistics
         assert (lse[b] - lref).abs().max() < 2e-2, (b, n)
     assert torch.isfinite(o.float()).all() and torch.isfinite(lse).all()
+    # backward on the same shapes: dQ by attn_bwd_dq_kvres_kernel, which also stands in for the delta pre-pass (delta array + the statistics rows the
+    # dK/dV kernel reads), then the streaming dK/dV kernel
+    do = bf(rnd(B, N, C, seed=3))
+    qg = q.float().view(B, N, H, 72).requires_grad_(True)
+    kvg = kv.float().view(tot, 2, H, 72).requires_grad_(True)
+    oref = torch.cat([_attn_ref(qg[b:b + 1], kvg[s0:s0 + n, 0][None], kvg[s0:s0 + n, 1][None]) for b, (s0, n) in enumerate(zip(starts, lens))], 0)
+    oref.backward(do.float().view(B, N, H, 72))
+    dq, dkv = torch.full_like(q, float("nan")), torch.zeros_like(kv)
+    delta = torch.full((B, H, N), float("nan"), device="cuda")
+    ops.attention_bwd(q, kv[:, :C], kv[:, C:], o, do, lse, delta, dq, dkv[:, :C], dkv[:, C:], B, H, N, max(lens), st,
+                      ((N * C, C, 72), (0, 2 * C, 72), (0, 2 * C, 72)), kv_start=kv_start, kv_len=kv_len, max_kv_len=max(lens))
+    dref = (do.float() * o.float()).view(B, N, H, 72).sum(-1).permute(0, 2, 1)
+    assert rel_l2(delta, dref) < 1e-5
+    assert rel_l2(dq.float().view_as(qg), qg.grad) < 2 * BF16_TOL
+    assert rel_l2(dkv.float().view(tot, 2, H, 72), kvg.grad) < 2 * BF16_TOL
 
 
 def test_attention_online_softmax_rescale(ops):
