@@ -1632,17 +1632,30 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_dq_kvres_kernel(AttnParams p,
   const float c = p.scale_log2;
   const long rows_total = (long)p.B * p.H * p.Nq64;
   tile_sync();
-  for (int q0b = bx * qpb; q0b < min(p.Nq, (bx + 1) * qpb); q0b += 256) {
+  // the rows of the NEXT trip are requested before this trip's tiles are worked on (two waves per SIMD do not hide a 2-3 us row load by themselves)
+  const int q_end = min(p.Nq, (bx + 1) * qpb);
+  bf16x8 nqf[KSTEPS], ndof[KSTEPS], nof[KSTEPS];
+  float nlse = 0.f;
+  auto load_trip = [&](int q0w) {
+    const int qq = q0w + (lane & 31);
+    const bool ok = q0w < q_end && qq < p.Nq;
+    load_row_frags(nqf, p.Q + (long)b * p.q_bs + (long)qq * p.q_ts + (long)h * p.q_hs, ok, hi);
+    load_row_frags(ndof, p.dO + (long)b * p.o_bs + (long)qq * p.o_ts + (long)h * p.o_hs, ok, hi);
+    load_row_frags(nof, p.O + (long)b * p.o_bs + (long)qq * p.o_ts + (long)h * p.o_hs, ok, hi);
+    nlse = ok ? p.LSE[((long)b * p.H + h) * p.Nq + qq] : 0.f;
+  };
+  load_trip(bx * qpb + wave * 32);
+  for (int q0b = bx * qpb; q0b < q_end; q0b += 256) {
     const int q0w = q0b + wave * 32;
     if (q0w >= p.Nq) break;                                    // wave-uniform
     const int q = q0w + (lane & 31);
     const bool qvalid = q < p.Nq;
     bf16x8 qf[KSTEPS], dof[KSTEPS], of[KSTEPS];
-    load_row_frags(qf, p.Q + (long)b * p.q_bs + (long)q * p.q_ts + (long)h * p.q_hs, qvalid, hi);
-    load_row_frags(dof, p.dO + (long)b * p.o_bs + (long)q * p.o_ts + (long)h * p.o_hs, qvalid, hi);
-    load_row_frags(of, p.O + (long)b * p.o_bs + (long)q * p.o_ts + (long)h * p.o_hs, qvalid, hi);
+#pragma unroll
+    for (int ks = 0; ks < KSTEPS; ks++) { qf[ks] = nqf[ks]; dof[ks] = ndof[ks]; of[ks] = nof[ks]; }
+    const float lse = nlse;
+    load_trip(q0w + 256);
     const long sidx = ((long)b * p.H + h) * p.Nq + q;
-    const float lse = qvalid ? p.LSE[sidx] : 0.f;
     float part = 0.f;                                          // this lane's 40 of the row's 80 slots (slots 72 .. 79 are zero in both rows)
 #pragma unroll
     for (int ks = 0; ks < KSTEPS; ks++)
