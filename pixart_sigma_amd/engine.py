@@ -326,7 +326,8 @@ class Engine:
                           B, H, N, ctx["max_len"], sc_str, ((N * D, D, 72), (0, 2 * D, 72), (0, 2 * D, 72)),
                           kv_start=ctx["kv_start"], kv_len=ctx["kv_len"], max_kv_len=ctx["max_len"])
         gq = self._lin_bwd(dqc, sv["x1b"], p + "cross_attn.q_linear")
-        self._lin_bwd(dkvc, ctx["ye"], p + "cross_attn.kv_linear", dx_kw=dict(out_f32=ctx["dye"], accumulate=True))
+        # 4,800 text rows fill 95 of 256 CUs with 256 x 256 tiles: split_k = 0 lets the library's (tile, split) model choose (128 x 128 here: 72 -> 47 us)
+        self._lin_bwd(dkvc, ctx["ye"], p + "cross_attn.kv_linear", dx_kw=dict(out_f32=ctx["dye"], accumulate=True, split_k=0))
         # ---- self attention: x1 = x_in + gate_msa * u1 ; G1 = G + gq
         ops.gate_bwd(G, add=gq, u=sv["u1"], gate=mod[:, 2], mod_stride=st, dx_out=G, du=du, dgate=dmod[:, 2], dmod_stride=st, rows_per_batch=N,
                      dbias=pb("attn.proj.bias"))
