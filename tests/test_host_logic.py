@@ -158,6 +158,26 @@ def test_came_tables_cover_every_parameter_exactly_once():
     assert tb["n_nf"] == 300 + 70000 and tb["col_inv_r"][T[0]["col_off"]] == 1.0 / 300
 
 
+def test_came_tables_keep_scalar_path_tiles_short():
+    """Tensors the CAME kernel walks on its scalar path (csrc/came.hip, MAXJ == 0: batched matrices, row lengths that are no multiple of 4 or longer than
+    4,608) get tiles of at most 64 rows: a wave takes those rows one after the other, each a chain of dependent loads and atomics, and the patch-embed
+    weight - [4608][2][2] as the package views it - used to be ONE tile of 9,216 rows that every pass of the step waited ~2 ms for
+    (profiles/r03u_came_kernel_stats.csv: 9.7 -> 4.7 ms per step).  Vector-path tensors keep their large tiles."""
+    from pixart_sigma_amd.dp import came_tables
+    shapes = {"x_embedder.proj.weight": (1152, 4, 2, 2), "fc1": (4608, 1152), "odd": (4000, 7), "wide": (8, 4612)}
+    names, offset, numel, off = list(shapes), {}, {}, 0
+    for n, sh in shapes.items():
+        numel[n] = int(torch.tensor(sh).prod())
+        offset[n] = off
+        off += numel[n]
+    tb = came_tables(names, offset, shapes, numel, tile_elems=262144)
+    rows_of = {i: [c for ti, _, c in tb["tiles"] if ti == i] for i in range(len(names))}
+    assert max(rows_of[0]) <= 64 and sum(rows_of[0]) == 4608 * 2 and len(rows_of[0]) == 144        # conv weight: 144 tiles instead of 1
+    assert max(rows_of[1]) == 224 and sum(rows_of[1]) == 4608                                         # C = 1152: 262,144 // 1152 rounded down to a multiple of 4
+    assert max(rows_of[2]) <= 64 and sum(rows_of[2]) == 4000                                          # C % 4 != 0
+    assert max(rows_of[3]) <= 64 and sum(rows_of[3]) == 8                                             # C > 4,608
+
+
 def test_store_notices_parameters_moved_out_by_a_standalone_block(monkeypatch):
     """a block used stand-alone re-points ITS parameters into a private flat store; the model's store must notice (every
     parameter is checked, not just the first) and rebuild from the current values instead of training stale copies."""
