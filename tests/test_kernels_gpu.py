@@ -20,6 +20,8 @@ def ops():
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")
     from pixart_sigma_amd import ops as o
+    if o.BF16 != torch.bfloat16:     # this file builds bf16 tensors by hand; the fp16-operand build is covered by tests/test_f16_parity_gpu.py (model suite re-run)
+        pytest.skip("per-kernel tests are written for the bf16-operand library (unset PXA_OPERAND_DTYPE)")
     return o
 
 
