@@ -57,6 +57,9 @@ CASES = {
     # scripts/inference.py:89-101 (--sampling_algo iddpm): IDDPM(str(steps)).p_sample_loop over forward_with_cfg, batch = [cond ; null] on a repeated
     # latent, clip_denoised=False as the script passes it (and True as the method's default); 5 respaced steps keep the CPU run short
     "iddpm_d2": (dict(depth=2, input_size=16, model_max_length=20), dict(B=4, Hl=16, Wl=16, L=20, lens=[20, 9, 20, 20])),
+    # scripts/inference.py:119-133 (--sampling_algo sa-solver): SASolverSampler(...).sample(S, eta=1, CFG 4.5) - stochastic Adams predictor-corrector,
+    # PEC, orders 2 / 2; 6 steps keep the CPU run short and still cover a deterministic (t > 0.8), three stochastic and a low-t deterministic step
+    "sasolver_d2": (dict(depth=2, input_size=16, model_max_length=20), dict(B=2, Hl=16, Wl=16, L=20, lens=[20, 11])),
     # BASELINE.json configs[0]: XL/2 256px, batch 2, 2 DPM-Solver steps, CFG 4.5, random-init, CPU
     "cfg1_xl2_256": (dict(depth=28, input_size=32, model_max_length=300, pe_interpolation=0.5), dict(B=2, Hl=32, Wl=32, L=300, lens=[300, 77])),
     # ---- round 3: the model bench.py times, FULL DEPTH at the headline geometry (PixArtMS_XL_2, depth 28, PixArtMS.py:291-293; 1024px: N = 4096,
@@ -144,6 +147,31 @@ def gen_case(name):
                 torch.manual_seed(11)                                # the per-step th.randn_like draws (gaussian_diffusion.py:438) come from here
                 out[key] = IDDPM(str(5)).p_sample_loop(m.forward_with_cfg, z.shape, z, clip_denoised=clip, model_kwargs=kw, progress=False,
                                                        device="cpu").clone()
+    elif name.startswith("sasolver"):
+        from diffusion import SASolverSampler
+
+        class _CpuSampler(SASolverSampler):          # the reference's register_buffer insists on torch.device("cuda") (sa_sampler.py:26-30): placement only
+            def register_buffer(self, name_, attr):
+                setattr(self, name_, attr)
+        g = torch.Generator().manual_seed(7)
+        null_y = torch.randn(1, 1, ikw["L"], 4096, generator=g).repeat(inp["x"].shape[0], 1, 1, 1)
+        draws, real_randn_like = [], torch.randn_like
+
+        def recording_randn_like(t, *a, **k):        # the solver's own Gaussian draws, in order (sa_solver.py:786, 813, 853): the GPU tests replay them
+            d = real_randn_like(t, *a, **k)
+            draws.append(d.clone())
+            return d
+        out.update(steps=6, eta=1, cfg_scale=4.5, null_seed=7, noise_seed=13)
+        with torch.no_grad():
+            torch.manual_seed(13)
+            torch.randn_like = recording_randn_like
+            try:
+                s_, _ = _CpuSampler(m.forward_with_dpmsolver, device="cpu").sample(
+                    S=6, batch_size=inp["x"].shape[0], shape=tuple(inp["x"].shape[1:]), eta=1, conditioning=inp["y"], unconditional_conditioning=null_y,
+                    unconditional_guidance_scale=4.5, model_kwargs=dict(data_info=data_info, mask=mask), x_T=inp["x"].clone())
+            finally:
+                torch.randn_like = real_randn_like
+        out["sample"], out["draws"] = s_.clone(), draws
     elif name.startswith("dpms") or name.startswith("cfg1"):
         from diffusion import DPMS
         g = torch.Generator().manual_seed(7)

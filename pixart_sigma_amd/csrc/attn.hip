@@ -1940,6 +1940,388 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv3_kernel(AttnParams p) {
   if (p.dv_colsum) colsum_rows(p.dv_colsum + (b % PXA_COLSUM_SLOTS) * p.colsum_stride + h * DH, dv, 1.f, kvvalid, hi, lane);
 }
 
+// ------------------------------------------------------------------------------------------------ forward, ONE wave per SIMD (round 4)
+// The organisation of cdna_hip_programming.md "4-wave, one-wave-per-SIMD, persistent structure", for head_dim 72: a workgroup = 4 waves = 256 queries,
+// each wave 64 queries (two 32-query blocks s) and the WHOLE 512-register file of its SIMD (__launch_bounds__(256, 1)); nothing is hidden by a
+// second wave, everything by software pipelining inside the wave.  Per 64-key tile j two matrix phases, every other instruction placed in their gaps:
+//   phase A(j): S'(j+1) = K(j+1) Q^T   (20 v_mfma_f32_32x32x16; K fragments resident in accumulator registers)  || the tile's LDS-DMA (K(j+5), V(j+3));
+//               finish-softmax(j): P = exp2(S'(j)), cvt_pk, v_permlane16_swap -> the B operands of PV(j); the first V(j) transpose reads
+//   phase B(j): O^T += V(j)^T P(j)^T    (40 v_mfma_f32_16x16x32; V fragments stream through FWD4_NVQ quads)       || start-softmax(j+1): running row maxima of
+//               S'(j+1) (v_max3), the K(j+2) row reads into the K registers
+// S is double-buffered (2 x 64 registers); ONE s_barrier per tile hands the rings over.  K and V tiles live in two 4-slot rings (96 KiB) and are fetched
+// THREE tiles ahead of their first LDS read, behind a counted vmcnt(12): with one workgroup per CU nothing else covers the L2 / HBM latency of a tile (first
+// version, 2-slot rings, fetch one tile ahead: 1.42 ms, 1.10 ms with the DMA ablated - profiles/r4_01_fwd4_time.txt).
+// Vector work per score: v_max3 (half), exp2, cvt_pk (half) + in the bf16 build the fma that applies scale and running maximum.  In the fp16 build
+// (FWD4_FOLD) that fma rides in the first product: Q~ = c Q (c = scale log2 e) is formed once per workgroup, and the zero padding of head_dim 72 -> 80
+// holds -m c in slot 72 of the query operand against 1.0 in column 72 of every K tile (the pad column that gives the V tiles their row sums), so the MFMA
+// returns S' = c S - m c.  m c is rounded to the operand type when it enters the slot; the SAME rounded value is used for alpha and for
+// lse = m c + log2 l, so that rounding cancels exactly (a uniform factor per query row, and l is summed from the very P that multiply V).  What does not
+// cancel is the second rounding of the query operand (Q~ = op(c op(q))): +24 % on the forward error of the fp16 build (2.9e-4 -> 3.6e-4 rel-L2 at the
+// headline shape), but +30 % with bf16 operands ON TOP of an 8 x coarser grid (2.3e-3 -> 2.9e-3, lse 1e-3 -> 4e-3: the backward's recomputed P follows
+// lse) - so the bf16 build keeps the fma.  (Folding c into the q rows of the qkv projection's shadow weights would remove that rounding for both: next.)
+// m is the *deferred* maximum: it moves only when some query of the wave sees S' > 6 (P <= 64; checked per tile, wave-uniform branch into a slow path
+// that rescales O, shifts the pending S' and rewrites the slot) - on the first tile always.
+// Full key tiles only (Nk % 64 == 0, dense keys): self-attention at every bucket resolution and the KV-compressed layers; everything else runs
+// attn_fwd2_kernel / the keys-resident kernel.  PXA_ATTN_FWD4=0 switches it off (A/B).
+#ifndef PXA_ATTN_FWD4_DEFAULT
+#define PXA_ATTN_FWD4_DEFAULT 1
+#endif
+constexpr float FWD4_THRESH = 6.0f;
+#ifndef FWD4_FOLD
+#define FWD4_FOLD PXA_OPERAND_DTYPE_ID      // scale + running maximum inside the first product (fp16 build only, see above)
+#endif
+#ifndef FWD4_NVQ
+#define FWD4_NVQ 5          // register quads the V^T fragments rotate through: a fragment is read FWD4_NVQ - 1 groups (of 4 MFMAs) ahead of its use
+#endif
+#ifndef FWD4_DMA_GAP
+#define FWD4_DMA_GAP 0      // first of the three consecutive phase-A gaps that carry the tile's LDS-DMA regions
+#endif
+#ifndef FWD4_ABL
+#define FWD4_ABL 0          // ablation builds (wrong results, timing only; tools/build_variant.py): 1 no LDS-DMA, 2 no running maxima, 4 no exp2, 8 no first-product MFMAs, 16 no second-product MFMAs, 32 no cvt / lane swaps
+#endif
+// Register ownership.  With 512 registers per wave the compiler's own split between the two halves of the file is hopeless (first build of this kernel:
+// 177 spills, ~440 v_accvgpr moves per tile), so every value that only the matrix pipe touches is pinned to the accumulator half through asm
+// constraints: O ("+a", 80 registers), Q ("a", 40), the K fragments (ds_read_b128 straight into "=a", 40); S / P / the V fragments stay in the arch
+// half where the VALU can reach them.  The MFMAs are therefore inline asm - and the compiler neither knows their latency nor pads their hazards: a VALU
+// or v_accvgpr read of an MFMA result must sit >= 12 issue states behind it.  In the loop that holds by construction (S'(j+1) is first read half a
+// tile after its last MFMA; O is read only in the slow path and the epilogue, both behind mfma_drain()).
+#ifdef PXA_OPERAND_F16
+#define PXA_MFMA32_ASM "v_mfma_f32_32x32x16_f16"
+#define PXA_MFMA16_ASM "v_mfma_f32_16x16x32_f16"
+#else
+#define PXA_MFMA32_ASM "v_mfma_f32_32x32x16_bf16"
+#define PXA_MFMA16_ASM "v_mfma_f32_16x16x32_bf16"
+#endif
+__device__ __forceinline__ void mfma32_aa_first(f32x16& d, const bf16x8& a, const bf16x8& b) {   // d = A B        (A, B in AGPRs, d in VGPRs)
+  asm volatile(PXA_MFMA32_ASM " %0, %1, %2, 0" : "=&v"(d) : "a"(a), "a"(b));
+}
+__device__ __forceinline__ void mfma32_aa(f32x16& d, const bf16x8& a, const bf16x8& b) {         // d += A B
+  asm volatile(PXA_MFMA32_ASM " %0, %1, %2, %0" : "+v"(d) : "a"(a), "a"(b));
+}
+__device__ __forceinline__ void mfma16_acc(f32x4& d, const bf16x8& a, const bf16x8& b) {         // d += A B       (A, B in VGPRs, d in AGPRs)
+  asm volatile(PXA_MFMA16_ASM " %0, %1, %2, %0" : "+a"(d) : "v"(a), "v"(b));
+}
+__device__ __forceinline__ void mfma_drain() { asm volatile("s_nop 15\n\ts_nop 15" ::: "memory"); __builtin_amdgcn_sched_barrier(0); }
+template <class T> __device__ __forceinline__ void to_agpr(T& v) { asm volatile("" : "+a"(v)); }
+template <int OFF> __device__ __forceinline__ void lds_row_asm_a(bf16x8& d, unsigned addr) {
+  asm volatile("ds_read_b128 %0, %1 offset:%2" : "=a"(d) : "v"(addr), "n"(OFF) : "memory");
+}
+template <int N> __device__ __forceinline__ void lds_wait_all(bf16x8 (&d)[10]) {
+  asm volatile("s_waitcnt lgkmcnt(%10)" : "+a"(d[0]), "+a"(d[1]), "+a"(d[2]), "+a"(d[3]), "+a"(d[4]), "+a"(d[5]), "+a"(d[6]), "+a"(d[7]), "+a"(d[8]), "+a"(d[9]) : "n"(N));
+}
+// both halves of a wave exchange: x <- {x.lo, x.lo}, y <- {x.hi, x.hi} (asm: with two copies of one value as operands the builtin's second result is
+// folded away by the compiler - the first version of this kernel lost the upper half's keys from its running maximum that way)
+__device__ __forceinline__ void bcast_halves(float x_in, float& lo, float& hi) {
+  float t;
+  asm volatile("v_mov_b32 %0, %1\n\ts_nop 1\n\tv_permlane32_swap_b32 %1, %0" : "=&v"(t), "+v"(x_in));
+  lo = x_in; hi = t;
+}
+// number of LDS reads that may stay in flight in front of the first MFMA of PV group g (issue order: V fragments 0 .. NVQ-2 at the end of phase A; then
+// per group g: [this wait] K row read g, V fragment g + NVQ - 1): everything issued behind V fragment g
+constexpr int fwd4_nwait(int g, int nvq, bool kreads) {
+  int n = 0;
+  for (int f = g + 1; f <= (g + nvq - 2 < 9 ? g + nvq - 2 : 9); f++) n += 2;
+  if (kreads) n += g >= nvq - 1 ? nvq - 2 : g;
+  return n;
+}
+// one exec region, two LDS-DMA pieces (K and V piece i share their lane mask): saddr form - wave-uniform 64-bit base + per-lane 32-bit byte offset
+template <int OFFK, int OFFV>
+__device__ __forceinline__ void dma_pair(unsigned long long mask, unsigned wbase, unsigned voffk, const void* kb, unsigned voffv, const void* vb) {
+  unsigned long long sv;
+  asm volatile("s_and_saveexec_b64 %0, %1\n\ts_add_u32 m0, %2, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %4, %5\n\ts_add_u32 m0, %2, %6\n\ts_nop 0\n\t"
+               "global_load_lds_dwordx4 %7, %8\n\ts_mov_b64 exec, %0"
+               : "=&s"(sv) : "s"(mask), "s"(wbase), "n"(OFFK), "v"(voffk), "s"(kb), "n"(OFFV), "v"(voffv), "s"(vb) : "memory", "scc");
+}
+template <int OFF>
+__device__ __forceinline__ void dma_one(unsigned long long mask, unsigned wbase, unsigned voff, const void* base) {
+  unsigned long long sv;
+  asm volatile("s_and_saveexec_b64 %0, %1\n\ts_add_u32 m0, %2, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %4, %5\n\ts_mov_b64 exec, %0"
+               : "=&s"(sv) : "s"(mask), "s"(wbase), "n"(OFF), "v"(voff), "s"(base) : "memory", "scc");
+}
+__global__ __launch_bounds__(256, 1) void attn_fwd4_kernel(AttnParams p) {
+  constexpr int QS = 2, NVQ = FWD4_NVQ;
+  constexpr bool FOLD = FWD4_FOLD;
+  constexpr int RING = 4, KOFF = 0, VOFF = RING * TILE_B;         // LDS: K ring [4 tiles] | V ring [4 tiles]
+  constexpr int LEAD = 3;                                          // tiles between a tile's DMA and its first LDS read (vmcnt(6 (LEAD - 1)) at the barrier)
+  __shared__ __attribute__((aligned(16))) char smem[2 * RING * TILE_B];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), hi = lane >> 5;
+  int bx, h, b;
+  block_coords(p, bx, h, b);
+  const bf16_t* Kp = p.K + (long)b * p.k_bs + (long)h * p.k_hs;
+  const bf16_t* Vp = p.V + (long)b * p.v_bs + (long)h * p.v_hs;
+  const int kts = (int)p.k_ts, vts = (int)p.v_ts;
+  const int T = p.Nk / BKV;                                       // >= 1, full tiles (checked by the launcher)
+  const float c = p.scale_log2;
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+  // query operands (FOLD: prescaled, Q~ = c Q in the operand type; slot 72 = k-step 4, upper half, element 0 carries -m c, initially 0)
+  int q[QS];
+  bool qvalid[QS];
+  bf16x8 qf[QS][KSTEPS];
+#pragma unroll
+  for (int s = 0; s < QS; s++) {
+    q[s] = bx * 256 + wave * 64 + s * 32 + (lane & 31);
+    qvalid[s] = q[s] < p.Nq;
+    load_row_frags(qf[s], p.Q + (long)b * p.q_bs + (long)q[s] * p.q_ts + (long)h * p.q_hs, qvalid[s], hi);
+    settle(qf[s]);
+    if constexpr (FOLD) {
+#pragma unroll
+      for (int ks = 0; ks < KSTEPS; ks++)
+#pragma unroll
+        for (int e = 0; e < 8; e++) qf[s][ks][e] = (bf16_t)((float)qf[s][ks][e] * c);
+    }
+#pragma unroll
+    for (int ks = 0; ks < KSTEPS; ks++) to_agpr(qf[s][ks]);
+  }
+  for (int st = 0; st < 2 * RING; st++) init_pads(smem + st * TILE_B, 1, tid);   // column 72 = 1.0 in K tiles (x slot 72 of Q~) and V tiles (row sums)
+
+  // LDS-DMA plan: per-lane byte offsets inside a tile's rows (saddr form), one lane mask per piece index
+  DmaPlan pl;
+  dma_plan(pl, wave, lane);
+  unsigned offK[NDMA], offV[NDMA];
+  unsigned long long dmask[NDMA];
+#pragma unroll
+  for (int i = 0; i < NDMA; i++) {
+    offK[i] = (unsigned)(pl.row[i] * kts + pl.coff[i]) * 2u;
+    offV[i] = (unsigned)(pl.row[i] * vts + pl.coff[i]) * 2u;
+    dmask[i] = __builtin_amdgcn_ballot_w64(pl.coff[i] >= 0);
+  }
+  const unsigned lds0 = (unsigned)(uintptr_t)LDS_PTR(char, smem);
+  const unsigned wbase = __builtin_amdgcn_readfirstlane(lds0 + wave * 1024);
+  const long kstep = (long)BKV * kts, vstep = (long)BKV * vts;     // elements per tile
+  auto ktile = [&](int t) { return Kp + (long)min(t, T - 1) * kstep; };   // past the last tile: a harmless re-fetch of it into a slot nobody reads
+  auto vtile = [&](int t) { return Vp + (long)min(t, T - 1) * vstep; };
+  auto dma_k = [&](auto slotc, const bf16_t* kb) {
+    constexpr int S = decltype(slotc)::value;
+    dma_one<KOFF + S * TILE_B>(dmask[0], wbase, offK[0], kb);
+    dma_one<KOFF + S * TILE_B + 4096>(dmask[1], wbase, offK[1], kb);
+    dma_one<KOFF + S * TILE_B + 8192>(dmask[2], wbase, offK[2], kb);
+  };
+  auto dma_kv = [&](auto kslotc, auto vslotc, const bf16_t* kb, const bf16_t* vb) {
+    constexpr int SK = decltype(kslotc)::value, SV = decltype(vslotc)::value;
+    dma_pair<KOFF + SK * TILE_B, VOFF + SV * TILE_B>(dmask[0], wbase, offK[0], kb, offV[0], vb);
+    dma_pair<KOFF + SK * TILE_B + 4096, VOFF + SV * TILE_B + 4096>(dmask[1], wbase, offK[1], kb, offV[1], vb);
+    dma_pair<KOFF + SK * TILE_B + 8192, VOFF + SV * TILE_B + 8192>(dmask[2], wbase, offK[2], kb, offV[2], vb);
+  };
+
+  // fragment addressing (LDS byte addresses; slot and fragment offsets are instruction immediates)
+  FragAddr fa;
+  frag_addr(fa, lane);
+  Tr16Addr ta;
+  tr16_addr(ta, lane);
+  const unsigned kr0 = lds0 + (unsigned)fa.rb[0], kr1 = lds0 + (unsigned)fa.rb[1];
+  const unsigned vt00 = lds0 + VOFF + (unsigned)ta.tb[0][0], vt01 = lds0 + VOFF + (unsigned)ta.tb[0][1], vt10 = lds0 + VOFF + (unsigned)ta.tb[1][0],
+                 vt11 = lds0 + VOFF + (unsigned)ta.tb[1][1];        // (the V ring's base sits in the address registers: instruction offsets are 16 bits)
+  bf16x8 kf[10];                                                   // K(j+1) fragments: kf[sub * 5 + ks]
+  auto rd_k = [&](auto slotc, auto kc) {
+    constexpr int S = decltype(slotc)::value, k = decltype(kc)::value, sub = k / 5, ks = k % 5;
+    lds_row_asm_a<KOFF + S * TILE_B + sub * 32 * ROWB + (ks >> 1) * 64>(kf[k], (ks & 1) ? kr1 : kr0);
+  };
+  bf16x8 vfr[NVQ];                                                 // V(j) transposed fragments, fragment g = sub * 5 + t in vfr[g % NVQ]
+  auto rd_v = [&](auto slotc, auto gc) {
+    constexpr int S = decltype(slotc)::value, g = decltype(gc)::value, sub = g / 5, t = g % 5;
+    lds_tr_asm<S * TILE_B + sub * 32 * ROWB + (t >> 1) * 64>(vfr[g % NVQ], (t & 1) ? vt01 : vt00, (t & 1) ? vt11 : vt10);
+  };
+
+  Acc16 o[QS];
+  f32x16 sc[2][QS][2];                                             // [buffer][query block s][key half sub]
+  u32x4 pxu[QS][2], pyu[QS][2];                                    // P(j) packed: the two B operands (query columns 0-15 / 16-31) of each 32 x 32 block
+  float mc[QS];                                                    // m c of this lane's query (lane & 31) of block s, log2 domain - FOLD: exactly the value in the slot
+  float mcsel = 0.f;                                               // hi ? mc[1] : mc[0]
+  float mrel = 0.f;                                                // after a tile's maxima: lower half lanes: max S' of block 0's query, upper half: block 1's
+#pragma unroll
+  for (int s = 0; s < QS; s++) {
+    zero16(o[s]); mc[s] = 0.f;
+#pragma unroll
+    for (int t = 0; t < NT16; t++) { to_agpr(o[s].v[t][0]); to_agpr(o[s].v[t][1]); }
+  }
+
+  // the slow path: the deferred maximum of some query moves (always on the first tile).  `nxt` = the pending S' buffer (computed with the old slot value).
+  auto rescale = [&](auto nxtc, auto firstc) {
+    constexpr int NXT = decltype(nxtc)::value;
+    constexpr bool first = decltype(firstc)::value;              // first tile: O is still zero (and alpha may overflow), the maximum may move DOWN from 0
+    mfma_drain();                                                 // the last PV MFMAs' results (asm MFMAs: no compiler-inserted hazard padding)
+    float mx[QS];
+    bcast_halves(mrel, mx[0], mx[1]);
+#pragma unroll
+    for (int s = 0; s < QS; s++) {
+      const float dmax = first ? mx[s] : fmaxf(mx[s], 0.f);
+      float mnew = mc[s] + dmax;
+      bf16_t nb = (bf16_t)0.f;
+      if constexpr (FOLD) { nb = (bf16_t)(-mnew); mnew = -(float)nb; }   // what the slot will hold, rounded to the operand type
+      const float delta = mnew - mc[s];
+      mc[s] = mnew;
+      if constexpr (FOLD) {
+#pragma unroll
+        for (int sub = 0; sub < 2; sub++)
+#pragma unroll
+          for (int g = 0; g < 16; g++) sc[NXT][s][sub][g] -= delta;
+        u32x4 w = __builtin_bit_cast(u32x4, qf[s][KSTEPS - 1]);
+        bf16x2 sl; sl[0] = nb; sl[1] = (bf16_t)0.f;
+        w[0] = hi ? __builtin_bit_cast(unsigned, sl) : w[0];
+        qf[s][KSTEPS - 1] = __builtin_bit_cast(bf16x8, w);
+        to_agpr(qf[s][KSTEPS - 1]);
+      }
+      if constexpr (!first) {
+        const float alpha = __builtin_amdgcn_exp2f(-delta);
+        const float ao = __shfl_xor(alpha, 16);
+        const float a0 = (lane & 16) ? ao : alpha, a1 = (lane & 16) ? alpha : ao;
+#pragma unroll
+        for (int t = 0; t < NT16; t++) { o[s].v[t][0] *= a0; o[s].v[t][1] *= a1; }
+#pragma unroll
+        for (int t = 0; t < NT16; t++) { to_agpr(o[s].v[t][0]); to_agpr(o[s].v[t][1]); }
+      }
+    }
+    mcsel = hi ? mc[1] : mc[0];
+    asm volatile("s_nop 3" ::: "memory");                          // v_accvgpr_write -> MFMA operand
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  // running maxima of a pending S' buffer -> mrel (halves exchanged: 1 swap + 1 max for both query blocks); FOLD: S' is already relative to m c
+  auto finish_max = [&](float m0, float m1) {              // lower half lanes <- max over both halves of m0, upper half lanes <- of m1
+    // (asm: hipcc 7.2 folds fmaxf over the two results of __builtin_amdgcn_permlane32_swap to its first result - /tmp reproducer in DESIGN.md - which is
+    // how the first version of this kernel lost the upper half's keys from its running maximum)
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\tv_max_f32 %0, %0, %1" : "+v"(m0), "+v"(m1));
+    mrel = FOLD ? m0 : fmaf(m0, c, -mcsel);
+  };
+
+  // ---- prologue.  DMA issue order = retirement order (vmcnt counts it): K(0) K(1) | K(2) V(0) | K(3) V(1) | - K(0) into registers, barrier - K(4) V(2)
+  dma_k(IntC<0>{}, ktile(0));
+  dma_k(IntC<1>{}, ktile(1));
+  dma_kv(IntC<2>{}, IntC<0>{}, ktile(2), vtile(0));
+  dma_kv(IntC<3>{}, IntC<1>{}, ktile(3), vtile(1));
+  lds_dma_wait<12>();                                              // K(0), K(1) landed (this wave's pieces)
+  __syncthreads();                                                 // ... everybody's, and the pads are written
+  static_for<10>([&](auto kc) { rd_k(IntC<0>{}, kc); });
+  lds_wait_all<0>(kf);
+  __syncthreads();                                                 // every wave holds K(0): its slot is free
+  dma_kv(IntC<0>{}, IntC<2>{}, ktile(4), vtile(2));
+  const bf16_t* kdma = ktile(5);                                   // tile body j fetches K(j+5) and V(j+3)
+  const bf16_t* vdma = vtile(3);
+#pragma unroll
+  for (int s = 0; s < QS; s++)
+#pragma unroll
+    for (int sub = 0; sub < 2; sub++) {
+      mfma32_aa_first(sc[0][s][sub], kf[sub * 5], qf[s][0]);
+#pragma unroll
+      for (int ks = 1; ks < KSTEPS; ks++) mfma32_aa(sc[0][s][sub], kf[sub * 5 + ks], qf[s][ks]);
+    }
+  static_for<10>([&](auto kc) { rd_k(IntC<1>{}, kc); });           // K(1): waited for in front of the first tile's barrier
+  mfma_drain();
+  {
+    float m0 = sc[0][0][0][0], m1 = sc[0][1][0][0];
+#pragma unroll
+    for (int sub = 0; sub < 2; sub++)
+#pragma unroll
+      for (int g = 0; g < 16; g++) { m0 = fmaxf(m0, sc[0][0][sub][g]); m1 = fmaxf(m1, sc[0][1][sub][g]); }
+    finish_max(m0, m1);
+  }
+  rescale(IntC<0>{}, BoolC<true>{});
+
+  // ---- one tile j, J = j & 3 (ring slots), CUR = j & 1 (S buffers).  ONE form for every tile: past the last tile the DMA sources are clamped to it and
+  // the last tile's phase A / maxima work on a tile that does not exist (the K registers still hold K(T-1): finite scores, never used; a rescale they may
+  // trigger scales O, l and m consistently) - 0.8 % extra matrix work at 64 tiles, against specialised copies of this body whose merges cost spills and
+  // register copies in the first version.
+  auto body = [&](auto jc) {
+    constexpr int J = decltype(jc)::value, CUR = J & 1, NXT = CUR ^ 1;
+    constexpr int KRD = (J + 2) % RING, VRD = J, KWR = (J + 2 + LEAD) % RING, VWR = (J + LEAD) % RING;
+    lds_wait_all<0>(kf);                                           // this wave's K(j+1) row reads are complete: their slot is refilled behind a later barrier
+    lds_dma_wait<6 * (LEAD - 1)>();                                // this wave's pieces of K(j+2), V(j) have landed; the two younger tiles stay in flight
+    __syncthreads();                                               // ... every wave's; and every wave is past phase B(j-1)
+    __builtin_amdgcn_sched_barrier(0);
+    // -------- phase A
+    static_for<20>([&](auto ac) {
+      constexpr int a = decltype(ac)::value, sub = a / 10, ks = (a % 10) / 2, s = a % 2;
+      if constexpr (!(FWD4_ABL & 8)) {
+        if constexpr (ks == 0) mfma32_aa_first(sc[NXT][s][sub], kf[sub * 5], qf[s][0]);
+        else mfma32_aa(sc[NXT][s][sub], kf[sub * 5 + ks], qf[s][ks]);
+      }
+      if constexpr (a >= FWD4_DMA_GAP && a < FWD4_DMA_GAP + 3 && !(FWD4_ABL & 1)) {
+        constexpr int i = a - FWD4_DMA_GAP;
+        dma_pair<KOFF + KWR * TILE_B + i * 4096, VOFF + VWR * TILE_B + i * 4096>(dmask[i], wbase, offK[i], kdma, offV[i], vdma);
+      }
+      // finish-softmax(j), block blk = a / 5 -> (s, sub) = (blk & 1, blk >> 1), slice a % 5
+      // 28 issues over 5 gaps (6 6 6 5 5): 16 exp2; 8 cvt_pk (ua: rows {0-3, 16-19} + 4 hi, ub: rows {8-11, 24-27} + 4 hi, see pack_xy); 4 v_permlane16_swap
+      constexpr int blk = a / 5, bs = blk & 1, bsub = blk >> 1, sl = a % 5;
+      f32x16& v = sc[CUR][bs][bsub];
+      u32x4& ux = pxu[bs][bsub]; u32x4& uy = pyu[bs][bsub];
+      const float mcb = mc[bs];
+      auto ex = [&](auto g0c, auto nc) {
+        static_for<decltype(nc)::value>([&](auto gc) {
+          constexpr int g = decltype(g0c)::value + decltype(gc)::value;
+          if (!(FWD4_ABL & 4)) v[g] = __builtin_amdgcn_exp2f(FOLD ? v[g] : fmaf(v[g], c, -mcb));
+          asm volatile("" : "+v"(v[g]));
+        });
+      };
+      auto cv = [&](auto wc) {                                      // ux[w] <- a-part, uy[w] <- b-part (swapped in place later)
+        constexpr int w = decltype(wc)::value, ga = (w & 1) * 2 + (w >> 1) * 8, gb = ga + 4;
+        if (FWD4_ABL & 32) { ux[w] = __builtin_bit_cast(unsigned, v[ga]); uy[w] = __builtin_bit_cast(unsigned, v[gb]); }
+        else { ux[w] = pack_bf16x2(v[ga], v[ga + 1]); uy[w] = pack_bf16x2(v[gb], v[gb + 1]); }
+        asm volatile("" : "+v"(ux[w]), "+v"(uy[w]));
+      };
+      auto sw = [&](auto wc) {
+        constexpr int w = decltype(wc)::value;
+        if (!(FWD4_ABL & 32)) { const auto r = __builtin_amdgcn_permlane16_swap(ux[w], uy[w], false, false); ux[w] = r[0]; uy[w] = r[1]; }
+        asm volatile("" : "+v"(ux[w]), "+v"(uy[w]));
+      };
+      if constexpr (sl == 0) ex(IntC<0>{}, IntC<6>{});
+      if constexpr (sl == 1) ex(IntC<6>{}, IntC<6>{});
+      if constexpr (sl == 2) { ex(IntC<12>{}, IntC<4>{}); cv(IntC<0>{}); }
+      if constexpr (sl == 3) { cv(IntC<1>{}); sw(IntC<0>{}); cv(IntC<2>{}); }
+      if constexpr (sl == 4) { cv(IntC<3>{}); sw(IntC<1>{}); sw(IntC<2>{}); sw(IntC<3>{}); }
+      if constexpr (a >= 20 - (NVQ - 1)) rd_v(IntC<VRD>{}, IntC<a - (20 - (NVQ - 1))>{});   // V fragments 0 .. NVQ-2
+      __builtin_amdgcn_sched_barrier(0);
+    });
+    // -------- phase B
+    float m0 = 0.f, m1 = 0.f;
+    static_for<40>([&](auto bc) {
+      constexpr int bb = decltype(bc)::value, g = bb / 4, i = bb % 4, sub = g / 5, t = g % 5, s = i / 2, half = i % 2;
+      if constexpr (i == 0) lds_wait<fwd4_nwait(g, NVQ, true)>(vfr[g % NVQ]);
+      if constexpr (!(FWD4_ABL & 16)) mfma16_acc(o[s].v[t][half], vfr[g % NVQ], __builtin_bit_cast(bf16x8, half ? pyu[s][sub] : pxu[s][sub]));
+      else asm volatile("" :: "v"(vfr[g % NVQ]), "v"(half ? pyu[s][sub] : pxu[s][sub]));
+      if constexpr (i == 0) rd_k(IntC<KRD>{}, IntC<g>{});
+      if constexpr (i == 1 && g + NVQ - 1 < 10) rd_v(IntC<VRD>{}, IntC<(g + NVQ - 1 < 10 ? g + NVQ - 1 : 0)>{});
+      if constexpr (bb < 32 && !(FWD4_ABL & 2)) {                   // start-softmax(j+1): running maxima, two scores per slot and query block
+        constexpr int ms = bb & 1, part = bb >> 1, msub = part >> 3, e = (part & 7) * 2;
+        float& m = ms ? m1 : m0;
+        const f32x16& v = sc[NXT][ms][msub];
+        if constexpr (part == 0) m = fmaxf(v[0], v[1]); else m = fmaxf(fmaxf(m, v[e]), v[e + 1]);
+        asm volatile("" : "+v"(m));
+      }
+      if constexpr (bb == 33 && !(FWD4_ABL & 2)) { finish_max(m0, m1); asm volatile("" : "+v"(mrel)); }
+      __builtin_amdgcn_sched_barrier(0);
+    });
+    if (__builtin_amdgcn_ballot_w64(mrel > FWD4_THRESH) != 0) rescale(IntC<NXT>{}, BoolC<false>{});
+  };
+
+  for (int j = 0; j < T; j += 4) {
+    body(IntC<0>{});
+    kdma += j + 6 < T ? kstep : 0;  vdma += j + 4 < T ? vstep : 0;
+    if (j + 1 >= T) break;
+    body(IntC<1>{});
+    kdma += j + 7 < T ? kstep : 0;  vdma += j + 5 < T ? vstep : 0;
+    if (j + 2 >= T) break;
+    body(IntC<2>{});
+    kdma += j + 8 < T ? kstep : 0;  vdma += j + 6 < T ? vstep : 0;
+    if (j + 3 >= T) break;
+    body(IntC<3>{});
+    kdma += j + 9 < T ? kstep : 0;  vdma += j + 7 < T ? vstep : 0;
+  }
+  lds_wait_all<0>(kf);
+  lds_dma_wait<0>();                                               // the clamped re-fetches must not land in a later workgroup's LDS
+
+  mfma_drain();
+#pragma unroll
+  for (int s = 0; s < QS; s++) {
+    const float la = __shfl(o[s].v[4][0][0], 32 + (lane & 15)), lb = __shfl(o[s].v[4][1][0], 32 + (lane & 15));
+    const float l = (lane & 16) ? lb : la;             // row 72 of O^T = sum over keys of the P actually multiplied into O, of query l & 31
+    const float inv = l > 0.f ? 1.f / l : 0.f, invo = __shfl_xor(inv, 16);
+    const int q0w = bx * 256 + wave * 64 + s * 32;
+    store_rows16(p.O + (long)b * p.o_bs + (long)q0w * p.o_ts + (long)h * p.o_hs, p.o_ts, o[s], (lane & 16) ? invo : inv, (lane & 16) ? inv : invo,
+                 q0w + (lane & 15) < p.Nq, q0w + 16 + (lane & 15) < p.Nq, lane);
+    if (qvalid[s] && hi == 0 && p.LSE) p.LSE[((long)b * p.H + h) * p.Nq + q[s]] = mc[s] + log2f(l);
+  }
+}
+
 int fill(AttnParams& p, const pxa_attn_args* a) {
   PXA_CHECK(a, "attn: null args");
   PXA_CHECK(a->head_dim == DH, "attn: head_dim %d unsupported (PixArt XL/2 uses 72)", a->head_dim);
@@ -1990,6 +2372,12 @@ extern "C" int pxa_attn_fwd(const pxa_attn_args* a, hipStream_t stream) {
   const bool two = !one_sub && p.Nq >= 256;
   p.nx = two ? (p.Nq + 255) / 256 : (p.Nq + 127) / 128;
   PXA_CHECK((long)p.nx * p.H * p.B < (1L << 31), "pxa_attn_fwd: grid too large");
+  const char* f4 = getenv("PXA_ATTN_FWD4");               // 1 = one-wave-per-SIMD kernel where it applies (dense keys, full 64-key tiles), 0 = never
+  if (two && (f4 ? atoi(f4) : PXA_ATTN_FWD4_DEFAULT) && !p.kv_start && p.Nk >= BKV && p.Nk % BKV == 0) {
+    hipLaunchKernelGGL(attn_fwd4_kernel, dim3(p.nx * p.H * p.B), dim3(256), 0, stream, p);
+    PXA_LAUNCH_CHECK();
+    return 0;
+  }
   if (two) hipLaunchKernelGGL(attn_fwd2_kernel, dim3(p.nx * p.H * p.B), dim3(256), 0, stream, p);
   else hipLaunchKernelGGL(attn_fwd_kernel, dim3(p.nx * p.H * p.B), dim3(256), 0, stream, p);
   PXA_LAUNCH_CHECK();

@@ -12,9 +12,10 @@ import torch
 
 
 class NoiseScheduleVP:
-    def __init__(self, schedule="discrete", betas=None, dtype=torch.float32):
-        assert schedule == "discrete" and betas is not None
-        log_alphas = 0.5 * torch.log(1 - betas).cumsum(dim=0)
+    def __init__(self, schedule="discrete", betas=None, alphas_cumprod=None, dtype=torch.float32):
+        assert schedule == "discrete" and (betas is not None or alphas_cumprod is not None)
+        # from betas as model/dpm_solver.py:27-28 does; from a float32 cumulative product as model/sa_solver.py:83-87 (SASolverSampler) does
+        log_alphas = 0.5 * torch.log(1 - betas).cumsum(dim=0) if betas is not None else 0.5 * torch.log(alphas_cumprod)
         self.T = 1.0
         self.log_alpha_array = log_alphas.to(dtype)                       # no clipping needed for the linear schedule (:71-81)
         self.total_N = self.log_alpha_array.shape[0]

@@ -174,6 +174,7 @@ class FusedAdamW:
         else:
             ops.adamw_step(self.store.master, self.store.grad, self.m, self.v, self.store.shadow, self.lr, self.betas[0], self.betas[1],
                            self.eps, self.wd, self.t, gscale=self.coef)
+        self.store.generation += 1           # the kernel rewrote the shadow weights: anything cached from them (Engine._text_cache) is stale
 
     def _clip(self, inv_world):
         """sumsq -> device-side clip coefficient (x 1/world, x 1/loss-scale) in self.coef = [multiplier, total_norm]."""
@@ -302,6 +303,7 @@ class FusedCAME(FusedAdamW):
         a.gscale = ptr(self.coef)
         a.scaler = ptr(self.scaler.state) if self.scaler is not None else None
         call("pxa_came_step", a)                        # refreshes the bf16 shadow itself (no parameter version is bumped)
+        self.store.generation += 1
 
     def state_dict(self):
         return {k: getattr(self, k) for k in ("m", "sq_row", "sq_col", "res_row", "res_col", "nf_sq")} | {"t": self.t, "lr": self.lr, "layout": self._layout()}

@@ -82,6 +82,7 @@ class ParamStore:
         self.shadow = torch.zeros(off, dtype=BF16, device=device)
         self.params = dict(named_params)
         self._versions = None
+        self.generation = 0        # bumped whenever the shadow weights change (re-cast here, fused optimizer steps): keys everything cached from them
         for name, p in named_params:
             v = self.view(self.master, name)
             v.copy_(p.data)
@@ -135,6 +136,7 @@ class ParamStore:
         if force or vers != self._versions:
             ops.cast_bf16(self.master, self.shadow)
             self._versions = vers
+            self.generation += 1
 
     def attach_grads(self):
         """Make every p.grad the view of the flat buffer; returns True if the buffer had to be (re)zeroed."""
@@ -401,7 +403,7 @@ class Engine:
         elif _capturing() or os.environ.get("PXA_TEXT_CACHE", "1") == "0":
             pass                                  # a captured graph must own every buffer it reads: no cache inside sample_graphed's capture
         else:
-            tkey = (y.data_ptr(), y._version, tuple(y.shape), lk, None if drop is None else (drop.data_ptr(), drop._version),
+            tkey = (S.generation, y.data_ptr(), y._version, tuple(y.shape), lk, None if drop is None else (drop.data_ptr(), drop._version),
                     None if y_null is None else (y_null.data_ptr(), y_null._version), row_idx.data_ptr())
         if tkey is not None and self._text_cache is not None and self._text_cache["key"] == tkey:
             ye, cap_saved = self._text_cache["ye"], None

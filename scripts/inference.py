@@ -25,7 +25,7 @@ _dt = _early.parse_known_args(sys.argv[1:])[0].dtype
 if _dt not in ("fp16", "bf16"):
     raise SystemExit(f"--dtype must be fp16 or bf16, got {_dt!r}")
 os.environ["PXA_OPERAND_DTYPE"] = "f16" if _dt == "fp16" else "bf16"
-from pixart_sigma_amd import DPMS, IDDPM, PixArtMS_XL_2  # noqa: E402
+from pixart_sigma_amd import DPMS, IDDPM, PixArtMS_XL_2, SASolverSampler  # noqa: E402
 
 
 def get_args():
@@ -40,7 +40,7 @@ def get_args():
     p.add_argument("--random_vae", action="store_true")
     p.add_argument("--bs", default=1, type=int)
     p.add_argument("--cfg_scale", default=4.5, type=float)
-    p.add_argument("--sampling_algo", default="dpm-solver", type=str, choices=["iddpm", "dpm-solver"])   # (reference also: sa-solver - not built)
+    p.add_argument("--sampling_algo", default="dpm-solver", type=str, choices=["iddpm", "dpm-solver", "sa-solver"])
     p.add_argument("--seed", default=0, type=int)
     p.add_argument("--dataset", default="custom", type=str)
     p.add_argument("--step", default=-1, type=int)
@@ -75,7 +75,7 @@ def main():
     torch.manual_seed(args.seed)
     latent = args.image_size // 8
     L = {"alpha": 120, "sigma": 300}[args.version]
-    steps = args.step if args.step > 0 else {"iddpm": 100, "dpm-solver": 20}[args.sampling_algo]           # reference inference.py:159-160
+    steps = args.step if args.step > 0 else {"iddpm": 100, "dpm-solver": 20, "sa-solver": 25}[args.sampling_algo]           # reference inference.py:159-160
     kvc = None
     if args.kv_compress:
         lo, hi = (int(v) for v in args.kv_compress_layers.split("-"))
@@ -107,6 +107,10 @@ def main():
             kw = dict(y=torch.cat([y, null_y.repeat(n, 1, 1, 1)]), cfg_scale=args.cfg_scale, data_info={"img_hw": hw, "aspect_ratio": ar}, mask=mask)
             samples = IDDPM(str(steps)).p_sample_loop(model.forward_with_cfg, z2.shape, z2, clip_denoised=False, model_kwargs=kw, device=dev)
             samples, _ = samples.chunk(2, dim=0)
+        elif args.sampling_algo == "sa-solver":                      # reference inference.py:119-133: 25 steps, eta = 1
+            sa = SASolverSampler(model.forward_with_dpmsolver, device=dev)
+            samples = sa.sample(S=steps, batch_size=n, shape=(4, latent, latent), eta=1, conditioning=y, unconditional_conditioning=null_y.repeat(n, 1, 1, 1),
+                                unconditional_guidance_scale=args.cfg_scale, model_kwargs=dict(data_info={"img_hw": hw, "aspect_ratio": ar}, mask=mask), x_T=z)[0]
         else:
             dpms = DPMS(model.forward_with_dpmsolver, condition=y, uncondition=null_y.repeat(n, 1, 1, 1), cfg_scale=args.cfg_scale,
                         model_kwargs=dict(data_info={"img_hw": hw, "aspect_ratio": ar}, mask=mask))

@@ -39,6 +39,19 @@ def test_f16_operand_build_model_suite():
     assert r.returncode == 0, r.stdout[-4000:] + r.stderr[-2000:]
 
 
+@pytest.mark.gpu
+def test_f16_operand_build_kernel_suite():
+    """tests/test_kernels_gpu.py re-run against libpixart_hip_f16.so - the library bench.py times: every GEMM epilogue, the row kernels, the dK/dV /
+    dQ kernel mode matrix and the full-grid B = 16 attention test, with the fp16 bounds of that file (one fp16 rounding: 5e-4; gradients 1e-3)."""
+    env = dict(os.environ, PXA_OPERAND_DTYPE="f16")
+    env.pop("PXA_LIB_PATH", None)
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_kernels_gpu.py"), "-q", "-m", "gpu", "-s",
+                        "-p", "no:cacheprovider"], capture_output=True, text=True, env=env, timeout=2400, cwd=ROOT)
+    tail = "\n".join(l for l in r.stdout.splitlines() if ("rel-L2" in l or "passed" in l or "failed" in l or "FAILED" in l or "Error" in l))
+    print("\n[f16 build] " + tail.replace("\n", "\n[f16 build] "))
+    assert r.returncode == 0, r.stdout[-6000:] + r.stderr[-2000:]
+
+
 F16_VAE_TOL = 4e-3        # measured 1.5e-3 ... 2.0e-3 (bf16 build: 1.2e-2 ... 1.7e-2); the reference runs this network in fp16
 
 

@@ -43,6 +43,38 @@ def test_dpm_solver_host_code_matches_reference(golden):
     assert rel_l2(s, g["sample"]) < 5e-5
 
 
+def test_sa_solver_host_code_matches_reference(golden):
+    """`--sampling_algo sa-solver` (scripts/inference.py:119-133): pixart_sigma_amd.diffusion.sa_solver around the oracle's denoiser (CPU) reproduces the
+    reference's 6-step SASolverSampler chain of tests/golden/sasolver_d2.pt when fed the reference's own Gaussian draws - host-side predictor /
+    corrector coefficients, the tau window, warm-up and final-step orders."""
+    from pixart_sigma_amd.diffusion import SASolverSampler
+    g = golden("sasolver_d2")
+    cfg, sd, inp, mask = _setup(g)
+    gen = torch.Generator().manual_seed(g["null_seed"])
+    null_y = torch.randn(1, 1, g["inputs"]["L"], 4096, generator=gen).repeat(inp["x"].shape[0], 1, 1, 1)
+    model = lambda x, t, y, mask=None, **kw: po.forward_with_dpmsolver(sd, cfg, x, t, y, mask)
+    assert len(g["draws"]) == g["steps"] + 1                     # one unused draw in front of the first evaluation + one per step
+    s, _ = SASolverSampler(model, device="cpu").sample(S=g["steps"], batch_size=inp["x"].shape[0], shape=tuple(inp["x"].shape[1:]), eta=g["eta"],
+                                                       conditioning=inp["y"], unconditional_conditioning=null_y, unconditional_guidance_scale=g["cfg_scale"],
+                                                       model_kwargs=dict(mask=mask), x_T=inp["x"].clone(), normals_sequence=g["draws"])
+    e = rel_l2(s, g["sample"])
+    assert e < 5e-5, e
+    # the draws matter (three of the six steps are stochastic): zero noise gives a different sample
+    z, _ = SASolverSampler(model, device="cpu").sample(S=g["steps"], batch_size=inp["x"].shape[0], shape=tuple(inp["x"].shape[1:]), eta=g["eta"],
+                                                       conditioning=inp["y"], unconditional_conditioning=null_y, unconditional_guidance_scale=g["cfg_scale"],
+                                                       model_kwargs=dict(mask=mask), x_T=inp["x"].clone(), normals_sequence=[torch.zeros_like(d) for d in g["draws"]])
+    assert rel_l2(z, g["sample"]) > 1e-2
+
+
+def test_sa_solver_25_steps_runs_and_is_finite():
+    from pixart_sigma_amd.diffusion import SASolverSampler
+    model = lambda x, t, y, **kw: 0.1 * x + 0.01 * y.mean()
+    torch.manual_seed(0)
+    s, _ = SASolverSampler(model, device="cpu").sample(S=25, batch_size=2, shape=(4, 8, 8), eta=1, conditioning=torch.ones(2, 1),
+                                                       unconditional_conditioning=torch.zeros(2, 1), unconditional_guidance_scale=4.5)
+    assert s.shape == (2, 4, 8, 8) and torch.isfinite(s).all()
+
+
 def test_dpm_solver_20_steps_runs_and_is_finite():
     from pixart_sigma_amd.diffusion import DPMS
     model = lambda x, t, y, **kw: 0.1 * x + 0.01 * y.mean()

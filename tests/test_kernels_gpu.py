@@ -12,7 +12,15 @@ pytestmark = pytest.mark.gpu
 
 from conftest import rel_l2  # noqa: E402
 
-BF16_TOL = 4e-3
+F16_BUILD = os.environ.get("PXA_OPERAND_DTYPE", "bf16").lower() in ("f16", "fp16", "float16", "half")
+# one rounding of a 16-bit output: bf16 ~1.6e-3 rel-L2 RMS -> 4e-3; IEEE fp16 (3 more mantissa bits) ~2e-4 -> 5e-4
+BF16_TOL = 5e-4 if F16_BUILD else 4e-3
+
+
+def _opd():
+    """the 16-bit operand dtype of the loaded library (ops.BF16: _opd(), or torch.float16 under PXA_OPERAND_DTYPE=f16)"""
+    from pixart_sigma_amd import ops as o
+    return o.BF16
 
 
 @pytest.fixture(scope="module")
@@ -20,8 +28,7 @@ def ops():
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")
     from pixart_sigma_amd import ops as o
-    if o.BF16 != torch.bfloat16:     # this file builds bf16 tensors by hand; the fp16-operand build is covered by tests/test_f16_parity_gpu.py (model suite re-run)
-        pytest.skip("per-kernel tests are written for the bf16-operand library (unset PXA_OPERAND_DTYPE)")
+    assert (o.BF16 == torch.float16) == F16_BUILD, "PXA_OPERAND_DTYPE and the loaded library disagree"
     return o
 
 
@@ -31,7 +38,7 @@ def rnd(*shape, scale=1.0, seed=0, dtype=torch.float32):
 
 
 def bf(x):
-    return x.to(torch.bfloat16)
+    return x.to(_opd())
 
 
 # ------------------------------------------------------------------------------------------------ GEMM
@@ -49,7 +56,7 @@ def test_gemm_gelu_dual_output(ops):
     M, N, K = 520, 4608, 1152
     a, w, b = bf(rnd(M, K, seed=1)), bf(rnd(N, K, scale=K ** -0.5, seed=2)), rnd(N, seed=3)
     pre = a.float() @ w.float().t() + b
-    out2 = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
+    out2 = torch.empty(M, N, dtype=_opd(), device="cuda")
     out = ops.gemm(a, w, ops.NT, bias=b, act=ops.ACT_GELU, out2=out2)
     assert rel_l2(out2.float(), pre) < BF16_TOL
     assert rel_l2(out.float(), F.gelu(pre, approximate="tanh")) < BF16_TOL
@@ -72,7 +79,7 @@ def test_gemm_nn_gelu_grad(ops):
     assert rel_l2(cs, 1 + (ref * x.grad).sum(0)) < 1e-4          # fused bias-gradient column sums (staged epilogue)
     part.zero_()
     ops.gemm(dy[:, :72], w[:72], ops.NN, colsum=part)                # K=72: register-staged fallback kernel + separate column-sum pass
-    assert rel_l2(part.sum(0)[:N], (dy[:, :72].float() @ w[:72].float()).to(torch.bfloat16).float().sum(0)) < 1e-4
+    assert rel_l2(part.sum(0)[:N], (dy[:, :72].float() @ w[:72].float()).to(_opd()).float().sum(0)) < 1e-4
 
 
 @pytest.mark.parametrize("M,N,K", [(1100, 1152, 256), (2048, 1280, 128), (1024, 4608, 64), (2300, 1096, 192), (4096, 1152, 96)])
@@ -84,7 +91,7 @@ def test_gemm_persistent_kernel_epilogues(ops, M, N, K):
     x = pre.clone().requires_grad_(True)
     F.gelu(x, approximate="tanh").backward(torch.ones_like(x))
     assert rel_l2(ops.gemm(a, w, ops.NT, bias=b).float(), pre) < BF16_TOL                      # bias only
-    out2 = torch.empty(M, N, dtype=torch.bfloat16, device="cuda")
+    out2 = torch.empty(M, N, dtype=_opd(), device="cuda")
     out = ops.gemm(a, w, ops.NT, bias=b, act=ops.ACT_GELU_SAVE_GRAD, out2=out2)                # training forward of fc1
     assert rel_l2(out.float(), F.gelu(pre, approximate="tanh")) < BF16_TOL
     assert rel_l2(out2.float(), x.grad) < BF16_TOL
@@ -191,7 +198,7 @@ def test_ln_affine_fwd_bwd(ops):
     xs, mean, rstd = ops.ln_affine_fwd(buf[:, D:2 * D], w, b)
     assert rel_l2(buf[:, D:2 * D].float(), y.detach()) < BF16_TOL and torch.equal(xs, keep[:, D:2 * D])
     assert torch.equal(buf[:, :D], keep[:, :D]) and torch.equal(buf[:, 2 * D:], keep[:, 2 * D:])     # neighbours untouched
-    dbuf = torch.zeros(R, 3 * D, dtype=torch.bfloat16, device="cuda")
+    dbuf = torch.zeros(R, 3 * D, dtype=_opd(), device="cuda")
     dbuf[:, D:2 * D] = dy
     dw, db = torch.ones(D, device="cuda"), torch.ones(D, device="cuda")
     ops.ln_affine_bwd(dbuf[:, D:2 * D], xs, mean, rstd, w, dw, db)
@@ -207,14 +214,14 @@ def test_gate_bwd_and_colsum(ops, B, N):
     gate = mod[:, 2]
     g = dx + add.float()
     dgate = torch.zeros(B, 6, D, device="cuda")
-    dxo, du = torch.empty_like(dx), torch.empty(R, D, dtype=torch.bfloat16, device="cuda")
+    dxo, du = torch.empty_like(dx), torch.empty(R, D, dtype=_opd(), device="cuda")
     dbias = torch.zeros(ops.COLSUM_SLOTS, D, device="cuda")
     ops.gate_bwd(dx, add=add, u=u, gate=gate, mod_stride=6 * D, dx_out=dxo, du=du, dgate=dgate[:, 2], dmod_stride=6 * D, rows_per_batch=N, dbias=dbias)
     assert rel_l2(dxo, g) < 1e-6
     assert rel_l2(dbias.sum(0), (g * gate.repeat_interleave(N, 0)).sum(0)) < 1e-5
     assert rel_l2(du.float(), g * gate.repeat_interleave(N, 0)) < BF16_TOL
     assert rel_l2(dgate[:, 2], (g * u.float()).view(B, N, D).sum(1)) < 1e-5
-    du2 = torch.empty(R, D, dtype=torch.bfloat16, device="cuda")
+    du2 = torch.empty(R, D, dtype=_opd(), device="cuda")
     ops.gate_bwd(dx, du=du2, rows_per_batch=N)  # plain cast
     assert rel_l2(du2.float(), dx) < BF16_TOL
     dy = bf(rnd(777, 3456, seed=5))
@@ -235,7 +242,7 @@ def test_attention_fwd_bwd_dense(ops, B, H, Nq, Nk):
     C = H * 72
     q, k, v = (bf(rnd(B, n, C, seed=s)) for n, s in ((Nq, 1), (Nk, 2), (Nk, 3)))
     do = bf(rnd(B, Nq, C, seed=4))
-    o = torch.empty(B, Nq, C, dtype=torch.bfloat16, device="cuda")
+    o = torch.empty(B, Nq, C, dtype=_opd(), device="cuda")
     lse = torch.empty(B, H, Nq, device="cuda")
     st = ((Nq * C, C, 72), (Nk * C, C, 72), (Nk * C, C, 72), (Nq * C, C, 72))
     ops.attention_fwd(q, k, v, o, lse, B, H, Nq, Nk, st)
@@ -264,7 +271,7 @@ def test_attention_qkv_packed_layout(ops):
     C = H * 72
     qkv = bf(rnd(B, N, 3 * C, seed=1))
     q, k, v = qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:]
-    o = torch.empty(B, N, C, dtype=torch.bfloat16, device="cuda")
+    o = torch.empty(B, N, C, dtype=_opd(), device="cuda")
     lse = torch.empty(B, H, N, device="cuda")
     s3 = (N * 3 * C, 3 * C, 72)
     st = (s3, s3, s3, (N * C, C, 72))
@@ -292,7 +299,7 @@ def test_attention_varlen_cross(ops):
     starts = [0, lens[0], lens[0] + lens[1]]
     kv_start = torch.tensor(starts, dtype=torch.int32, device="cuda")
     kv_len = torch.tensor(lens, dtype=torch.int32, device="cuda")
-    o = torch.empty(B, N, C, dtype=torch.bfloat16, device="cuda")
+    o = torch.empty(B, N, C, dtype=_opd(), device="cuda")
     lse = torch.empty(B, H, N, device="cuda")
     st = ((N * C, C, 72), (0, 2 * C, 72), (0, 2 * C, 72), (N * C, C, 72))
     ops.attention_fwd(q, kv[:, :C], kv[:, C:], o, lse, B, H, N, max(lens), st, kv_start=kv_start, kv_len=kv_len, max_kv_len=max(lens))
@@ -393,7 +400,7 @@ def test_unpatchify_and_inverse(ops):
     ref = torch.einsum("nhwpqc->nchpwq", lin.view(B, h, w, 2, 2, Co)).reshape(B, Co, 2 * h, 2 * w)
     assert torch.equal(img, ref)
     back = ops.patchify_bwd(img, h, w)
-    assert torch.equal(back, lin.to(torch.bfloat16))
+    assert torch.equal(back, lin.to(_opd()))
 
 
 def test_gather_rows(ops):
@@ -405,7 +412,7 @@ def test_gather_rows(ops):
     drop = torch.tensor([0, 1, 0], dtype=torch.int32, device="cuda")
     out = ops.gather_rows_bf16(y, idx, L, alt=alt, drop=drop)
     ref = torch.where(drop.bool()[:, None, None], alt[None], y.view(B, L, Cw)).reshape(B * L, Cw)[idx.long()]
-    assert torch.equal(out, ref.to(torch.bfloat16))
+    assert torch.equal(out, ref.to(_opd()))
 
 
 def test_kv_compress_fwd(ops):
@@ -441,13 +448,13 @@ def test_kv_compress_bwd_and_pick(ops):
         assert rel_l2(got, ref) < 1e-4, nm
     assert dqkv[:, :C].abs().max() == 0 and dqkv[:, 2 * C:].abs().max() == 0
     # token pick ('uniform' / 'ave') forward + scatter backward
-    kc = torch.empty(B, Nk, C, dtype=torch.bfloat16, device="cuda")
+    kc = torch.empty(B, Nk, C, dtype=_opd(), device="cuda")
     ops.kv_pick(k, kc, N * 3 * C, 3 * C, B, H, W, C, sr)
     ref = k.reshape(B, H, W, C)[:, ::sr, ::sr].reshape(B, Nk, C)
     assert torch.equal(kc, ref)
     back = torch.zeros_like(qkv)
     ops.kv_pick(kc, back[:, C:2 * C], N * 3 * C, 3 * C, B, H, W, C, sr, backward=True)
-    refb = torch.zeros(B, H, W, C, dtype=torch.bfloat16, device="cuda")
+    refb = torch.zeros(B, H, W, C, dtype=_opd(), device="cuda")
     refb[:, ::sr, ::sr] = ref.reshape(B, H // sr, W // sr, C)
     assert torch.equal(back[:, C:2 * C].reshape(B, H, W, C), refb)
 
@@ -459,13 +466,13 @@ def test_adamw_matches_torch(ops):
     pr = p0.clone().requires_grad_(True)
     opt = torch.optim.AdamW([pr], lr=2e-5, weight_decay=3e-2, eps=1e-10)
     p, m, v = p0.clone(), torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
-    pb = torch.empty(n, dtype=torch.bfloat16, device="cuda")
+    pb = torch.empty(n, dtype=_opd(), device="cuda")
     for step, g in enumerate((g1, g2), 1):
         pr.grad = g.clone()
         opt.step()
         ops.adamw_step(p, g, m, v, pb, 2e-5, 0.9, 0.999, 1e-10, 3e-2, step)
     assert rel_l2(p, pr.detach()) < 1e-6
-    assert torch.equal(pb, p.to(torch.bfloat16))
+    assert torch.equal(pb, p.to(_opd()))
 
 
 def test_grad_norm_and_clip(ops):
@@ -505,7 +512,7 @@ def test_gemm_nt_headline_shapes(ops, N, K, flavour):
         aux = bf(_gpu_rnd(M_TOK, N, seed=5))
         e = rel_l2(ops.gemm(a, w, ops.NT, bias=b, act=ops.ACT_ADD_AUX, aux=aux).float(), pre + aux.float())
     else:
-        out2 = torch.empty(M_TOK, N, dtype=torch.bfloat16, device="cuda")
+        out2 = torch.empty(M_TOK, N, dtype=_opd(), device="cuda")
         out = ops.gemm(a, w, ops.NT, bias=b, act=ops.ACT_GELU_SAVE_GRAD, out2=out2)
         x = pre.clone().requires_grad_(True)
         F.gelu(x, approximate="tanh").backward(torch.ones_like(x))
@@ -571,7 +578,7 @@ def test_attention_headline_shapes(ops, B, H, Nq, Nk):
     kernels) and the 2K KV-compressed layers (N_q = 16384 against N_kv = 4096), forward + backward, vs fp32 attention per head."""
     C = H * 72
     q, k, v, do = bf(_gpu_rnd(B, Nq, C, seed=1)), bf(_gpu_rnd(B, Nk, C, seed=2)), bf(_gpu_rnd(B, Nk, C, seed=3)), bf(_gpu_rnd(B, Nq, C, seed=4))
-    o = torch.empty(B, Nq, C, dtype=torch.bfloat16, device="cuda")
+    o = torch.empty(B, Nq, C, dtype=_opd(), device="cuda")
     lse = torch.empty(B, H, Nq, device="cuda")
     sq, sk = (Nq * C, C, 72), (Nk * C, C, 72)
     ops.attention_fwd(q, k, v, o, lse, B, H, Nq, Nk, (sq, sk, sk, sq))
@@ -598,7 +605,7 @@ def test_attention_dkv_kernel_modes(ops, monkeypatch, mode, dqm, B, H, Nq, Nk, l
     monkeypatch.setenv("PXA_ATTN_DQ", dqm)
     C = H * 72
     q, do = bf(_gpu_rnd(B, Nq, C, seed=1)), bf(_gpu_rnd(B, Nq, C, seed=4))
-    o = torch.empty(B, Nq, C, dtype=torch.bfloat16, device="cuda")
+    o = torch.empty(B, Nq, C, dtype=_opd(), device="cuda")
     lse = torch.empty(B, H, Nq, device="cuda")
     delta = torch.empty(B, H, Nq, device="cuda")
     dq = torch.empty_like(q)
@@ -643,7 +650,7 @@ def test_attention_full_grid_b16(ops):
     qkv = bf(_gpu_rnd(B, N, 3 * C, seed=1))
     do = bf(_gpu_rnd(B, N, C, seed=2))
     q, k, v = qkv[..., :C], qkv[..., C:2 * C], qkv[..., 2 * C:]
-    o = torch.full((B, N, C), float("nan"), dtype=torch.bfloat16, device="cuda")
+    o = torch.full((B, N, C), float("nan"), dtype=_opd(), device="cuda")
     lse, delta = torch.empty(B, H, N, device="cuda"), torch.empty(B, H, N, device="cuda")
     s3 = (N * 3 * C, 3 * C, 72)
     st = (s3, s3, s3, (N * C, C, 72))

@@ -235,6 +235,22 @@ def test_grad_checkpointing_matches_saved_activations(golden):
     assert rel_l2(grads[1], grads[0]) < 1e-4
 
 
+def test_sa_solver_sampling_matches_reference(golden):
+    """`--sampling_algo sa-solver` on the HIP denoiser against the reference's 6-step chain (tests/golden/sasolver_d2.pt), replaying the reference's
+    Gaussian draws (the device generator's stream differs from the CPU's)."""
+    from pixart_sigma_amd import SASolverSampler
+    g = golden("sasolver_d2")
+    cfg, sd, inp, mask, m = _build(g)
+    gen = torch.Generator().manual_seed(g["null_seed"])
+    null_y = torch.randn(1, 1, g["inputs"]["L"], 4096, generator=gen).repeat(inp["x"].shape[0], 1, 1, 1).cuda()
+    s, _ = SASolverSampler(m.forward_with_dpmsolver, device="cuda").sample(
+        S=g["steps"], batch_size=inp["x"].shape[0], shape=tuple(inp["x"].shape[1:]), eta=g["eta"], conditioning=inp["y"].cuda(), unconditional_conditioning=null_y,
+        unconditional_guidance_scale=g["cfg_scale"], model_kwargs=dict(data_info=None, mask=mask.cuda()), x_T=inp["x"].cuda(), normals_sequence=g["draws"])
+    e = rel_l2(s.cpu(), g["sample"])
+    print(f"\n6-step SA-Solver sample rel-L2 vs reference {e:.2e}")
+    assert e < (SAMPLE_TOL if F16 else FWD_F32_TOL)
+
+
 def test_dpm_solver_sampling_matches_reference(golden):
     from pixart_sigma_amd import DPMS
     g = golden("dpms_d2")
@@ -251,7 +267,7 @@ def test_dpm_solver_sampling_matches_reference(golden):
 def test_inference_text_cache_is_exact_and_invalidated(golden, monkeypatch):
     """engine.Engine._text_cache (round 3): the caption MLP and the 28 cross-attention kv_linear outputs depend on the text alone, so a sampler's
     steps reuse them.  Same sample bit for bit with the cache off; a different caption tensor, an in-place edit of the same one, and a training
-    forward in between (weights may have changed) all miss."""
+    forward in between all miss - and so does a change of the WEIGHTS under the same caption (the key carries ParamStore.generation)."""
     from pixart_sigma_amd import DPMS
     g = golden("dpms_d2")
     cfg, sd, inp, mask, m = _build(g)
@@ -272,6 +288,16 @@ def test_inference_text_cache_is_exact_and_invalidated(golden, monkeypatch):
         y.mul_(0.5)                                           # in-place edit of the caption tensor: version bump -> miss -> different sample
         c = solver.sample(x, **kw)
         assert m._engine._text_cache["key"] != key0 and not torch.equal(c, a)
+        # weights change under the same caption tensor: load_state_dict of another checkpoint between two no-grad samples must miss the cache
+        key1 = m._engine._text_cache["key"]
+        sd2 = {k_: (v_ * 1.25 if k_.endswith("cross_attn.kv_linear.weight") else v_) for k_, v_ in m.state_dict().items()}
+        m.load_state_dict(sd2)
+        d = solver.sample(x, **kw)
+        assert m._engine._text_cache["key"] != key1 and not torch.equal(d, c)
+        monkeypatch.setenv("PXA_TEXT_CACHE", "0")
+        e = solver.sample(x, **kw)
+        monkeypatch.delenv("PXA_TEXT_CACHE")
+        assert torch.equal(d, e)                              # ... and what it recomputes is what a cache-less run computes
     m.train()
     from pixart_sigma_amd import IDDPM
     IDDPM(str(1000)).training_losses(m, x, inp["t"].cuda(), model_kwargs=dict(y=y, mask=mask.cuda()), noise=inp["noise"].cuda())["loss"].mean().backward()

@@ -125,9 +125,9 @@ def test_train_entry_point_fp16_accumulation_schedule(tmp_path):
     assert r.returncode != 0 and "use_fancy_thing" in (r.stdout + r.stderr)
 
 
-@pytest.mark.parametrize("algo,steps", [("dpm-solver", 3), ("iddpm", 4)])
+@pytest.mark.parametrize("algo,steps", [("dpm-solver", 3), ("iddpm", 4), ("sa-solver", 5)])
 def test_inference_entry_point_samplers(tmp_path, algo, steps):
-    """scripts/inference.py with the reference's CLI (reference scripts/inference.py:24-44, 86-118) on synthetic caption features: both built samplers run
+    """scripts/inference.py with the reference's CLI (reference scripts/inference.py:24-44, 86-133) on synthetic caption features: all three samplers run
     the HIP denoiser end to end (256px, two prompts, batch 2 -> model batch 4 with CFG) and write finite latents of the right shape."""
     txt = tmp_path / "prompts.txt"
     txt.write_text("a red cube\na blue sphere\n")

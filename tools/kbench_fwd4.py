@@ -1,0 +1,105 @@
+"""attn_fwd4_kernel (one wave per SIMD, csrc/attn.hip) against attn_fwd2_kernel and fp32 attention: parity on ragged / tiny / rescale-heavy shapes, the
+full B16 grid per head, and time at the headline shape.  The launcher reads PXA_ATTN_FWD4 per call, so both kernels run in one process.
+Usage (GPU box): python tools/kbench_fwd4.py [check|time|all]"""
+import math
+import os
+import sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from pixart_sigma_amd import ops
+
+dev = "cuda"
+OPD = ops.BF16
+
+
+def rel(a, b):
+    a, b = a.double(), b.double()
+    return ((a - b).norm() / b.norm().clamp_min(1e-30)).item()
+
+
+def run_fwd(q, k, v, B, H, Nq, Nk, mode):
+    os.environ["PXA_ATTN_FWD4"] = mode
+    C = H * 72
+    o = torch.full((B, Nq, C), float("nan"), dtype=OPD, device=dev)
+    lse = torch.full((B, H, Nq), float("nan"), device=dev)
+    ops.attention_fwd(q, k, v, o, lse, B, H, Nq, Nk, ((Nq * C, C, 72), (Nk * C, C, 72), (Nk * C, C, 72), (Nq * C, C, 72)))
+    torch.cuda.synchronize()
+    return o, lse
+
+
+def ref(q, k, v, B, H, Nq, Nk):
+    qf, kf, vf = (t.float().view(B, -1, H, 72).transpose(1, 2) for t in (q, k, v))
+    s = (qf @ kf.transpose(-1, -2)) * 72 ** -0.5
+    return (s.softmax(-1) @ vf).transpose(1, 2).reshape(B, Nq, H * 72), torch.logsumexp(s, -1) / math.log(2)
+
+
+def check():
+    bad = 0
+    tol = 5e-4 if OPD == torch.float16 else 4e-3
+    g = torch.Generator(device=dev).manual_seed(0)
+    cases = [(2, 3, 256, 64, 1.0), (2, 3, 256, 128, 1.0), (1, 2, 300, 192, 1.0), (2, 2, 520, 256, 1.0), (1, 4, 1024, 320, 1.0), (2, 16, 1024, 1024, 1.0),
+             (1, 2, 512, 1024, 6.0), (1, 2, 512, 4096, 3.0), (1, 16, 4096, 1024, 1.0), (1, 2, 256, 512, 0.02)]
+    for B, H, Nq, Nk, sc in cases:
+        C = H * 72
+        q = (torch.randn(B, Nq, C, device=dev, generator=g) * sc).to(OPD)
+        k = (torch.randn(B, Nk, C, device=dev, generator=g) * sc).to(OPD)
+        v = torch.randn(B, Nk, C, device=dev, generator=g).to(OPD)
+        if sc == 6.0:            # a drifting score level: the running maximum keeps moving, rescale events on many tiles
+            k = (k.float() + torch.linspace(0, 3, Nk, device=dev)[None, :, None] * q.float().mean(1, keepdim=True).sign()).to(OPD)
+        o4, l4 = run_fwd(q, k, v, B, H, Nq, Nk, "1")
+        o2, l2 = run_fwd(q, k, v, B, H, Nq, Nk, "0")
+        ro, rl = ref(q, k, v, B, H, Nq, Nk)
+        e4, e2, el4, el2 = rel(o4.float(), ro), rel(o2.float(), ro), (l4 - rl).abs().max().item(), (l2 - rl).abs().max().item()
+        ok = e4 < tol and el4 < 2e-3 and torch.isfinite(o4.float()).all().item()
+        bad += not ok
+        print(f"B{B} H{H} Nq{Nq} Nk{Nk} x{sc}: fwd4 o {e4:.2e} lse {el4:.1e} | fwd2 o {e2:.2e} lse {el2:.1e} | fwd4 vs fwd2 {rel(o4.float(), o2.float()):.2e}  {'ok' if ok else 'FAIL'}", flush=True)
+    # full grid: every workgroup of the B16 launch, per head against the two-wave kernel, and run-to-run reproducibility
+    B, H, N = 16, 16, 4096
+    C = H * 72
+    q, k, v = (torch.randn(B, N, C, device=dev, generator=g).to(OPD) for _ in range(3))
+    o4, l4 = run_fwd(q, k, v, B, H, N, N, "1")
+    o4b, _ = run_fwd(q, k, v, B, H, N, N, "1")
+    o2, l2 = run_fwd(q, k, v, B, H, N, N, "0")
+    d = (o4.float() - o2.float()).view(B, N, H, 72).pow(2).sum((1, 3)).sqrt() / o2.float().view(B, N, H, 72).pow(2).sum((1, 3)).sqrt()
+    rep = torch.equal(o4, o4b)
+    ro, rl = ref(q[:1], k[:1], v[:1], 1, H, N, N)
+    e = rel(o4[:1].float(), ro)
+    ok = d.max().item() < tol and rep and e < tol and (l4 - l2).abs().max().item() < 2e-3
+    bad += not ok
+    print(f"full grid B16: worst head vs fwd2 {d.max().item():.2e}, lse diff {(l4 - l2).abs().max().item():.1e}, sample 0 vs fp32 {e:.2e} (fwd2 {rel(o2[:1].float(), ro):.2e}), "
+          f"bit-reproducible {rep}  {'ok' if ok else 'FAIL'}", flush=True)
+    return bad
+
+
+def timeit():
+    B, H, N, D = 16, 16, 4096, 1152
+    R = B * N
+    qkv = torch.randn(R, 3 * D, device=dev).to(OPD)
+    a = torch.empty(R, D, dtype=OPD, device=dev)
+    lse = torch.empty(B, H, N, device=dev)
+    s3 = (N * 3 * D, 3 * D, 72)
+    st = (s3, s3, s3, (N * D, D, 72))
+    fl = 4.0 * B * N * N * D
+    for mode in ("0", "1", "0", "1"):
+        os.environ["PXA_ATTN_FWD4"] = mode
+        fn = lambda: ops.attention_fwd(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], a, lse, B, H, N, N, st)
+        for _ in range(10):
+            fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(100):
+            fn()
+        e1.record()
+        e1.synchronize()
+        t = e0.elapsed_time(e1) / 100 * 1e-3
+        print(f"attn fwd self B16 H16 N4096 PXA_ATTN_FWD4={mode} lib={os.environ.get('PXA_LIB_PATH', 'default')}: {t * 1e3:7.3f} ms {fl / t / 1e12:7.1f} TF/s", flush=True)
+
+
+if __name__ == "__main__":
+    what = sys.argv[1] if len(sys.argv) > 1 else "all"
+    rc = 0
+    if what in ("check", "all"):
+        rc = check()
+    if what in ("time", "all"):
+        timeit()
+    sys.exit(1 if rc else 0)

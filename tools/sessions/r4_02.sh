@@ -1,0 +1,17 @@
+#!/bin/bash
+# round 4, session 2: attn_fwd4_kernel v2 (4-slot rings, 3 tiles of DMA lead, asm maxima exchange) - parity both builds, time, variants, model suite under f16
+cd "$GRAFT_REPO_ROOT" || exit 1
+O=gpurun_out
+mkdir -p $O
+export PYTHONUNBUFFERED=1
+timeout 300 python tools/kbench_fwd4.py check > $O/r4_02_fwd4_check_bf16.txt 2>&1; echo "check bf16 rc=$?" >> $O/r4_02_fwd4_check_bf16.txt
+PXA_OPERAND_DTYPE=f16 timeout 300 python tools/kbench_fwd4.py all > $O/r4_02_fwd4_check_f16.txt 2>&1; echo "check f16 rc=$?" >> $O/r4_02_fwd4_check_f16.txt
+timeout 120 python tools/kbench_fwd4.py time > $O/r4_02_fwd4_time.txt 2>&1
+for v in fold nvq3 nvq4 nvq7 gap5 abl1 abl2 abl4 abl32 abl24 abl39 abl24f abl39f; do
+  PXA_LIB_PATH=pixart_sigma_amd/variants/lib_f4_$v.so timeout 120 python tools/kbench_fwd4.py time 2>&1 | grep "FWD4=1" | tail -1 >> $O/r4_02_fwd4_time.txt
+done
+PXA_OPERAND_DTYPE=f16 timeout 900 python -m pytest tests/test_kernels_gpu.py -q -p no:cacheprovider > $O/r4_02_kernels_f16.txt 2>&1
+timeout 900 python -m pytest tests/test_kernels_gpu.py -q -p no:cacheprovider > $O/r4_02_kernels_bf16.txt 2>&1
+PXA_OPERAND_DTYPE=f16 timeout 1500 python -m pytest tests/test_model_gpu.py -q -s -p no:cacheprovider > $O/r4_02_model_f16.txt 2>&1
+tail -n 3 $O/r4_02_kernels_f16.txt $O/r4_02_kernels_bf16.txt $O/r4_02_model_f16.txt
+cat $O/r4_02_fwd4_check_bf16.txt $O/r4_02_fwd4_check_f16.txt $O/r4_02_fwd4_time.txt | grep -v amdgpu.ids
