@@ -1963,21 +1963,31 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv3_kernel(AttnParams p) {
 // that rescales O, shifts the pending S' and rewrites the slot) - on the first tile always.
 // Full key tiles only (Nk % 64 == 0, dense keys): self-attention at every bucket resolution and the KV-compressed layers; everything else runs
 // attn_fwd2_kernel / the keys-resident kernel.  PXA_ATTN_FWD4=0 switches it off (A/B).
-#ifndef PXA_ATTN_FWD4_DEFAULT
-#define PXA_ATTN_FWD4_DEFAULT 1
-#endif
-constexpr float FWD4_THRESH = 6.0f;
 #ifndef FWD4_FOLD
 #define FWD4_FOLD PXA_OPERAND_DTYPE_ID      // scale + running maximum inside the first product (fp16 build only, see above)
 #endif
+#ifndef PXA_ATTN_FWD4_DEFAULT
+#define PXA_ATTN_FWD4_DEFAULT FWD4_FOLD      // on where it wins: with the fold (fp16 build) 1.19-1.20 ms against 1.28-1.31; without it the two organisations tie (below)
+#endif
+constexpr float FWD4_THRESH = 6.0f;
 #ifndef FWD4_NVQ
 #define FWD4_NVQ 5          // register quads the V^T fragments rotate through: a fragment is read FWD4_NVQ - 1 groups (of 4 MFMAs) ahead of its use
 #endif
-#ifndef FWD4_DMA_GAP
-#define FWD4_DMA_GAP 0      // first of the three consecutive phase-A gaps that carry the tile's LDS-DMA regions
+#ifndef FWD4_KSPREAD
+#define FWD4_KSPREAD 0      // K row reads of the next tile: 0 = two per PV group in groups 0..4, 1 = one per group in all ten (A/B)
+#endif
+#ifndef FWD4_DMA_A
+#define FWD4_DMA_A 0        // the tile's three LDS-DMA regions: 0 = behind PV groups 5..7, 1 = in phase A gaps 14 / 16 / 18 (A/B)
 #endif
 #ifndef FWD4_ABL
 #define FWD4_ABL 0          // ablation builds (wrong results, timing only; tools/build_variant.py): 1 no LDS-DMA, 2 no running maxima, 4 no exp2, 8 no first-product MFMAs, 16 no second-product MFMAs, 32 no cvt / lane swaps
+#endif
+#ifndef FWD4_TRACE
+#define FWD4_TRACE 0        // diagnostics build: wave 0 of workgroup 0 sums s_memtime ticks (100 MHz) per tile section: [barrier wait, phase A, phase B, tiles]
+#endif
+#if FWD4_TRACE
+__device__ unsigned long long fwd4_trace_buf[8];
+__device__ __forceinline__ unsigned long long fwd4_now() { unsigned long long t; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)); return t; }
 #endif
 // Register ownership.  With 512 registers per wave the compiler's own split between the two halves of the file is hopeless (first build of this kernel:
 // 177 spills, ~440 v_accvgpr moves per tile), so every value that only the matrix pipe touches is pinned to the accumulator half through asm
@@ -2016,21 +2026,27 @@ __device__ __forceinline__ void bcast_halves(float x_in, float& lo, float& hi) {
   asm volatile("v_mov_b32 %0, %1\n\ts_nop 1\n\tv_permlane32_swap_b32 %1, %0" : "=&v"(t), "+v"(x_in));
   lo = x_in; hi = t;
 }
-// number of LDS reads that may stay in flight in front of the first MFMA of PV group g (issue order: V fragments 0 .. NVQ-2 at the end of phase A; then
-// per group g: [this wait] K row read g, V fragment g + NVQ - 1): everything issued behind V fragment g
-constexpr int fwd4_nwait(int g, int nvq, bool kreads) {
+// number of LDS reads that may stay in flight in front of the first MFMA of PV group g = everything issued behind V fragment g.  Issue order: V fragments
+// 0 .. NVQ-2 at the end of phase A; then per group gg: [wait], K row read 2 gg, V fragment gg + NVQ - 1, K row read 2 gg + 1 (K reads in groups 0..4 only)
+constexpr int fwd4_nwait(int g, int nvq) {
   int n = 0;
-  for (int f = g + 1; f <= (g + nvq - 2 < 9 ? g + nvq - 2 : 9); f++) n += 2;
-  if (kreads) n += g >= nvq - 1 ? nvq - 2 : g;
+  bool seen = false;
+  for (int f = 0; f <= nvq - 2; f++) { if (seen) n += 2; if (f == g) seen = true; }
+  for (int gg = 0; gg < g; gg++) {
+    if ((FWD4_KSPREAD || gg < 5) && seen) n += 1;
+    if (gg + nvq - 1 < 10) { if (seen) n += 2; if (gg + nvq - 1 == g) seen = true; }
+    if (!FWD4_KSPREAD && gg < 5 && seen) n += 1;
+  }
   return n;
 }
 // one exec region, two LDS-DMA pieces (K and V piece i share their lane mask): saddr form - wave-uniform 64-bit base + per-lane 32-bit byte offset
 template <int OFFK, int OFFV>
 __device__ __forceinline__ void dma_pair(unsigned long long mask, unsigned wbase, unsigned voffk, const void* kb, unsigned voffv, const void* vb) {
-  unsigned long long sv;
-  asm volatile("s_and_saveexec_b64 %0, %1\n\ts_add_u32 m0, %2, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %4, %5\n\ts_add_u32 m0, %2, %6\n\ts_nop 0\n\t"
-               "global_load_lds_dwordx4 %7, %8\n\ts_mov_b64 exec, %0"
-               : "=&s"(sv) : "s"(mask), "s"(wbase), "n"(OFFK), "v"(voffk), "s"(kb), "n"(OFFV), "v"(voffv), "s"(vb) : "memory", "scc");
+  // (exec is all ones in this kernel - full waves, no divergence outside these statements - so it is set and reset, not saved; the exec write doubles as the
+  // wait state between the first M0 write and its LDS-DMA)
+  asm volatile("s_add_u32 m0, %1, %2\n\ts_mov_b64 exec, %0\n\tglobal_load_lds_dwordx4 %3, %4\n\ts_add_u32 m0, %1, %5\n\ts_nop 0\n\t"
+               "global_load_lds_dwordx4 %6, %7\n\ts_mov_b64 exec, -1"
+               :: "s"(mask), "s"(wbase), "n"(OFFK), "v"(voffk), "s"(kb), "n"(OFFV), "v"(voffv), "s"(vb) : "memory", "scc");
 }
 template <int OFF>
 __device__ __forceinline__ void dma_one(unsigned long long mask, unsigned wbase, unsigned voff, const void* base) {
@@ -2221,13 +2237,64 @@ __global__ __launch_bounds__(256, 1) void attn_fwd4_kernel(AttnParams p) {
   // the last tile's phase A / maxima work on a tile that does not exist (the K registers still hold K(T-1): finite scores, never used; a rescale they may
   // trigger scales O, l and m consistently) - 0.8 % extra matrix work at 64 tiles, against specialised copies of this body whose merges cost spills and
   // register copies in the first version.
+#if FWD4_TRACE
+  unsigned long long tr_wait = 0, tr_a = 0, tr_b = 0, tr_n = 0;
+#endif
   auto body = [&](auto jc) {
     constexpr int J = decltype(jc)::value, CUR = J & 1, NXT = CUR ^ 1;
     constexpr int KRD = (J + 2) % RING, VRD = J, KWR = (J + 2 + LEAD) % RING, VWR = (J + LEAD) % RING;
+#if FWD4_TRACE
+    const unsigned long long t0 = fwd4_now();
+#endif
     lds_wait_all<0>(kf);                                           // this wave's K(j+1) row reads are complete: their slot is refilled behind a later barrier
     lds_dma_wait<6 * (LEAD - 1)>();                                // this wave's pieces of K(j+2), V(j) have landed; the two younger tiles stay in flight
     __syncthreads();                                               // ... every wave's; and every wave is past phase B(j-1)
     __builtin_amdgcn_sched_barrier(0);
+#if FWD4_TRACE
+    const unsigned long long t1 = fwd4_now();
+#endif
+    // Issue budget (SQ counters of the first working version, profiles/r4_04_pmc_fwd4_sq.txt: ~5.4 cycles per issued instruction, exp2 and the 32-row MFMA
+    // two issue quads each; a wave is alone on its SIMD, so every instruction of the tile queues behind every other): the first product's 640 matrix
+    // cycles can carry ~120 quads of other work, the second product's 640 another ~120 - and the softmax alone is 64 exp2 (128 quads) + 48 cvt / swap.
+    // All of it sat in phase A at first (phase A 960 cycles for 640 of MFMA, phase B matrix-bound with idle issue slots); now the tile's four 32 x 32
+    // blocks of P are split: blocks 0, 1 (key half 0, needed by PV groups 0-4) in phase A, blocks 2, 3 (key half 1, needed from group 5 on) in the
+    // shadow of PV groups 0-4; the running maxima of S'(j+1) follow its first product half by half (key half 0 in the tail of phase A, key half 1 in
+    // PV groups 5-9, where the LDS-DMA sits too).
+    // micro-instruction k = 0..27 of softmax block blk -> (s, sub) = (blk & 1, blk >> 1): 8 exp2, 4 cvt_pk, 2 swaps - twice (pack_xy's a / b parts)
+    auto smx = [&](auto blkc, auto kc) {
+      constexpr int blk = decltype(blkc)::value, k = decltype(kc)::value, bs = blk & 1, bsub = blk >> 1;
+      if constexpr (k < 28) {
+        f32x16& v = sc[CUR][bs][bsub];
+        u32x4& ux = pxu[bs][bsub]; u32x4& uy = pyu[bs][bsub];
+        constexpr int hk = k % 14, hb = k / 14;                          // half hb covers scores 8 hb .. 8 hb + 7 -> words 2 hb, 2 hb + 1 of both operands
+        if constexpr (hk < 8) {
+          constexpr int g = 8 * hb + hk;
+          if (!(FWD4_ABL & 4)) v[g] = __builtin_amdgcn_exp2f(FOLD ? v[g] : fmaf(v[g], c, -mc[bs]));
+          asm volatile("" : "+v"(v[g]));
+        } else if constexpr (hk < 12) {
+          constexpr int w = 2 * hb + ((hk - 8) >> 1), isb = (hk - 8) & 1, g0 = (w & 1) * 2 + (w >> 1) * 8 + 4 * isb;
+          unsigned d;
+          if (FWD4_ABL & 32) d = __builtin_bit_cast(unsigned, v[g0]); else d = pack_bf16x2(v[g0], v[g0 + 1]);
+          asm volatile("" : "+v"(d));
+          if constexpr (isb) uy[w] = d; else ux[w] = d;
+        } else {
+          constexpr int w = 2 * hb + (hk - 12);
+          if (!(FWD4_ABL & 32)) { const auto r = __builtin_amdgcn_permlane16_swap(ux[w], uy[w], false, false); ux[w] = r[0]; uy[w] = r[1]; }
+          asm volatile("" : "+v"(ux[w]), "+v"(uy[w]));
+        }
+      }
+    };
+    // running maxima of S'(j+1): slice m = 0..15 of key half msub -> query block m & 1, scores 2 (m >> 1), + 1 (asm: no canonicalising v_max in front)
+    float m0 = 0.f, m1 = 0.f;
+    auto mxs = [&](auto msubc, auto mc_) {
+      constexpr int msub = decltype(msubc)::value, m = decltype(mc_)::value, ms = m & 1, e = (m >> 1) * 2;
+      if constexpr (!(FWD4_ABL & 2)) {
+        float& mm = ms ? m1 : m0;
+        const f32x16& v = sc[NXT][ms][msub];
+        if constexpr (msub == 0 && e == 0) asm volatile("v_max_f32 %0, %1, %2" : "=v"(mm) : "v"(v[0]), "v"(v[1]));
+        else asm volatile("v_max3_f32 %0, %0, %1, %2" : "+v"(mm) : "v"(v[e]), "v"(v[e + 1]));
+      }
+    };
     // -------- phase A
     static_for<20>([&](auto ac) {
       constexpr int a = decltype(ac)::value, sub = a / 10, ks = (a % 10) / 2, s = a % 2;
@@ -2235,59 +2302,33 @@ __global__ __launch_bounds__(256, 1) void attn_fwd4_kernel(AttnParams p) {
         if constexpr (ks == 0) mfma32_aa_first(sc[NXT][s][sub], kf[sub * 5], qf[s][0]);
         else mfma32_aa(sc[NXT][s][sub], kf[sub * 5 + ks], qf[s][ks]);
       }
-      if constexpr (a >= FWD4_DMA_GAP && a < FWD4_DMA_GAP + 3 && !(FWD4_ABL & 1)) {
-        constexpr int i = a - FWD4_DMA_GAP;
+      if constexpr (a < 14) static_for<4>([&](auto ic) { smx(IntC<a / 7>{}, IntC<4 * (a % 7) + decltype(ic)::value>{}); });
+      else {                                                             // 16 maxima slices of key half 0 over gaps 14..19: 3 3 3 3 2 2
+        constexpr int first = a < 18 ? 3 * (a - 14) : 12 + 2 * (a - 18), cnt = a < 18 ? 3 : 2;
+        static_for<cnt>([&](auto ic) { mxs(IntC<0>{}, IntC<first + decltype(ic)::value>{}); });
+      }
+      if constexpr (a >= 20 - (NVQ - 1)) rd_v(IntC<VRD>{}, IntC<a - (20 - (NVQ - 1))>{});   // V fragments 0 .. NVQ-2
+      if constexpr (FWD4_DMA_A && (a == 14 || a == 16 || a == 18) && !(FWD4_ABL & 1)) {
+        constexpr int i = (a - 14) / 2;
         dma_pair<KOFF + KWR * TILE_B + i * 4096, VOFF + VWR * TILE_B + i * 4096>(dmask[i], wbase, offK[i], kdma, offV[i], vdma);
       }
-      // finish-softmax(j), block blk = a / 5 -> (s, sub) = (blk & 1, blk >> 1), slice a % 5
-      // 28 issues over 5 gaps (6 6 6 5 5): 16 exp2; 8 cvt_pk (ua: rows {0-3, 16-19} + 4 hi, ub: rows {8-11, 24-27} + 4 hi, see pack_xy); 4 v_permlane16_swap
-      constexpr int blk = a / 5, bs = blk & 1, bsub = blk >> 1, sl = a % 5;
-      f32x16& v = sc[CUR][bs][bsub];
-      u32x4& ux = pxu[bs][bsub]; u32x4& uy = pyu[bs][bsub];
-      const float mcb = mc[bs];
-      auto ex = [&](auto g0c, auto nc) {
-        static_for<decltype(nc)::value>([&](auto gc) {
-          constexpr int g = decltype(g0c)::value + decltype(gc)::value;
-          if (!(FWD4_ABL & 4)) v[g] = __builtin_amdgcn_exp2f(FOLD ? v[g] : fmaf(v[g], c, -mcb));
-          asm volatile("" : "+v"(v[g]));
-        });
-      };
-      auto cv = [&](auto wc) {                                      // ux[w] <- a-part, uy[w] <- b-part (swapped in place later)
-        constexpr int w = decltype(wc)::value, ga = (w & 1) * 2 + (w >> 1) * 8, gb = ga + 4;
-        if (FWD4_ABL & 32) { ux[w] = __builtin_bit_cast(unsigned, v[ga]); uy[w] = __builtin_bit_cast(unsigned, v[gb]); }
-        else { ux[w] = pack_bf16x2(v[ga], v[ga + 1]); uy[w] = pack_bf16x2(v[gb], v[gb + 1]); }
-        asm volatile("" : "+v"(ux[w]), "+v"(uy[w]));
-      };
-      auto sw = [&](auto wc) {
-        constexpr int w = decltype(wc)::value;
-        if (!(FWD4_ABL & 32)) { const auto r = __builtin_amdgcn_permlane16_swap(ux[w], uy[w], false, false); ux[w] = r[0]; uy[w] = r[1]; }
-        asm volatile("" : "+v"(ux[w]), "+v"(uy[w]));
-      };
-      if constexpr (sl == 0) ex(IntC<0>{}, IntC<6>{});
-      if constexpr (sl == 1) ex(IntC<6>{}, IntC<6>{});
-      if constexpr (sl == 2) { ex(IntC<12>{}, IntC<4>{}); cv(IntC<0>{}); }
-      if constexpr (sl == 3) { cv(IntC<1>{}); sw(IntC<0>{}); cv(IntC<2>{}); }
-      if constexpr (sl == 4) { cv(IntC<3>{}); sw(IntC<1>{}); sw(IntC<2>{}); sw(IntC<3>{}); }
-      if constexpr (a >= 20 - (NVQ - 1)) rd_v(IntC<VRD>{}, IntC<a - (20 - (NVQ - 1))>{});   // V fragments 0 .. NVQ-2
       __builtin_amdgcn_sched_barrier(0);
     });
     // -------- phase B
-    float m0 = 0.f, m1 = 0.f;
     static_for<40>([&](auto bc) {
       constexpr int bb = decltype(bc)::value, g = bb / 4, i = bb % 4, sub = g / 5, t = g % 5, s = i / 2, half = i % 2;
-      if constexpr (i == 0) lds_wait<fwd4_nwait(g, NVQ, true)>(vfr[g % NVQ]);
+      if constexpr (i == 0) lds_wait<fwd4_nwait(g, NVQ)>(vfr[g % NVQ]);
       if constexpr (!(FWD4_ABL & 16)) mfma16_acc(o[s].v[t][half], vfr[g % NVQ], __builtin_bit_cast(bf16x8, half ? pyu[s][sub] : pxu[s][sub]));
       else asm volatile("" :: "v"(vfr[g % NVQ]), "v"(half ? pyu[s][sub] : pxu[s][sub]));
-      if constexpr (i == 0) rd_k(IntC<KRD>{}, IntC<g>{});
+      if constexpr (FWD4_KSPREAD && i == 0) rd_k(IntC<KRD>{}, IntC<g>{});
+      if constexpr (!FWD4_KSPREAD && g < 5 && i == 0) rd_k(IntC<KRD>{}, IntC<(g < 5 ? 2 * g : 0)>{});
       if constexpr (i == 1 && g + NVQ - 1 < 10) rd_v(IntC<VRD>{}, IntC<(g + NVQ - 1 < 10 ? g + NVQ - 1 : 0)>{});
-      if constexpr (bb < 32 && !(FWD4_ABL & 2)) {                   // start-softmax(j+1): running maxima, two scores per slot and query block
-        constexpr int ms = bb & 1, part = bb >> 1, msub = part >> 3, e = (part & 7) * 2;
-        float& m = ms ? m1 : m0;
-        const f32x16& v = sc[NXT][ms][msub];
-        if constexpr (part == 0) m = fmaxf(v[0], v[1]); else m = fmaxf(fmaxf(m, v[e]), v[e + 1]);
-        asm volatile("" : "+v"(m));
-      }
-      if constexpr (bb == 33 && !(FWD4_ABL & 2)) { finish_max(m0, m1); asm volatile("" : "+v"(mrel)); }
+      if constexpr (!FWD4_KSPREAD && g < 5 && i == 2) rd_k(IntC<KRD>{}, IntC<(g < 5 ? 2 * g + 1 : 0)>{});
+      if constexpr (bb < 20) static_for<3>([&](auto ic) { smx(IntC<2 + bb / 10>{}, IntC<3 * (bb % 10) + decltype(ic)::value>{}); });
+      else if constexpr (bb < 36) mxs(IntC<1>{}, IntC<bb - 20>{});
+      if constexpr (bb == 37 && !(FWD4_ABL & 2)) { finish_max(m0, m1); asm volatile("" : "+v"(mrel)); }
+      if constexpr (!FWD4_DMA_A && g >= 5 && g < 8 && i == 3 && !(FWD4_ABL & 1))
+        dma_pair<KOFF + KWR * TILE_B + (g - 5) * 4096, VOFF + VWR * TILE_B + (g - 5) * 4096>(dmask[g - 5], wbase, offK[g - 5], kdma, offV[g - 5], vdma);
       __builtin_amdgcn_sched_barrier(0);
     });
     if (__builtin_amdgcn_ballot_w64(mrel > FWD4_THRESH) != 0) rescale(IntC<NXT>{}, BoolC<false>{});
@@ -2308,6 +2349,9 @@ __global__ __launch_bounds__(256, 1) void attn_fwd4_kernel(AttnParams p) {
   }
   lds_wait_all<0>(kf);
   lds_dma_wait<0>();                                               // the clamped re-fetches must not land in a later workgroup's LDS
+#if FWD4_TRACE
+  if (blockIdx.x == 0 && tid == 0) { fwd4_trace_buf[0] = tr_wait; fwd4_trace_buf[1] = tr_a; fwd4_trace_buf[2] = tr_b; fwd4_trace_buf[3] = tr_n; }
+#endif
 
   mfma_drain();
 #pragma unroll
@@ -2372,8 +2416,12 @@ extern "C" int pxa_attn_fwd(const pxa_attn_args* a, hipStream_t stream) {
   const bool two = !one_sub && p.Nq >= 256;
   p.nx = two ? (p.Nq + 255) / 256 : (p.Nq + 127) / 128;
   PXA_CHECK((long)p.nx * p.H * p.B < (1L << 31), "pxa_attn_fwd: grid too large");
-  const char* f4 = getenv("PXA_ATTN_FWD4");               // 1 = one-wave-per-SIMD kernel where it applies (dense keys, full 64-key tiles), 0 = never
-  if (two && (f4 ? atoi(f4) : PXA_ATTN_FWD4_DEFAULT) && !p.kv_start && p.Nk >= BKV && p.Nk % BKV == 0) {
+  // one-wave-per-SIMD kernel: dense keys in full 64-key tiles.  PXA_ATTN_FWD4 = 1 forces it wherever it applies (tests), 0 never; by default the
+  // builds that fold scale and maximum into the first product use it from 8 key tiles on (its prologue fills a 4-deep ring and its last tile
+  // computes one first product too many: not worth it for the 256-token grids)
+  const char* f4 = getenv("PXA_ATTN_FWD4");
+  const bool f4_ok = two && !p.kv_start && p.Nk >= BKV && p.Nk % BKV == 0;
+  if (f4_ok && (f4 ? atoi(f4) != 0 : (PXA_ATTN_FWD4_DEFAULT && p.Nk >= 8 * BKV))) {
     hipLaunchKernelGGL(attn_fwd4_kernel, dim3(p.nx * p.H * p.B), dim3(256), 0, stream, p);
     PXA_LAUNCH_CHECK();
     return 0;
@@ -2384,6 +2432,9 @@ extern "C" int pxa_attn_fwd(const pxa_attn_args* a, hipStream_t stream) {
   return 0;
 }
 
+#if FWD4_TRACE
+extern "C" int pxa_attn_fwd4_trace(unsigned long long* out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(fwd4_trace_buf), sizeof(fwd4_trace_buf)) == hipSuccess ? 0 : -1; }
+#endif
 extern "C" long pxa_attn_bwd_stats_bytes(int B, int H, int Nq) { return 2L * B * H * ((Nq + BKV - 1) / BKV * BKV) * 16; }
 
 extern "C" int pxa_attn_bwd(const pxa_attn_args* a, hipStream_t stream) {

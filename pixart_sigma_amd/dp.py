@@ -35,7 +35,7 @@ class GradReducer:
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
         # PXA_DP_FORCE_COLLECTIVES=1: run the bucket collectives even in a one-rank group (a real RCCL all-reduce of every bucket from
-        # the engine's hooks on a single GPU - the only multi-GPU code path a one-GPU box can execute; tests/test_dp_nccl_gpu.py)
+        # the engine's hooks on a single GPU - the only multi-GPU code path a one-GPU box can execute; tests/test_training_runtime_gpu.py::test_bench_under_torchrun_forced_collectives)
         self.active = self.world > 1 or (dist.is_available() and dist.is_initialized() and os.environ.get("PXA_DP_FORCE_COLLECTIVES") == "1")
         self.bucket_dtype = bucket_dtype
         self.stage = torch.empty(store.total, dtype=bucket_dtype, device=store.device) if bucket_dtype not in (None, torch.float32) and self.active else None

@@ -1,0 +1,83 @@
+"""Static checks on the EMITTED gfx950 ISA of the hand-scheduled kernels (hipcc cross-compiles without a GPU; ~10 s):
+* hand-counted LDS waits (tools/check_lds_waits.py): every register an inline-asm ds_read fills is waited for before its first use;
+* the one-wave-per-SIMD forward kernel keeps its promises: no scratch, no v_accvgpr traffic on the tile loop's hot path (the compiler's own split of a
+  512-register kernel cost 177 spills and ~440 moves per tile before the accumulator half was pinned through asm constraints), one barrier per tile;
+* M0 (the LDS-DMA destination, written inside common.h lds_dma16 / attn.hip dma_pair without a clobber the compiler would honour) has no other user
+  in any kernel of attn.hip / gemm.hip (a compiler-generated M0 use between the statements would be corrupted silently)."""
+import os
+import re
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+
+@pytest.fixture(scope="module")
+def asm(tmp_path_factory):
+    from pixart_sigma_amd import build as B
+    out = {}
+    td = tmp_path_factory.mktemp("isa")
+    for src in ("attn.hip", "gemm.hip"):
+        for tag, extra in (("bf16", []), ("f16", ["-DPXA_OPERAND_F16"])):
+            if src == "gemm.hip" and tag == "f16":
+                continue
+            o = str(td / f"{src}.{tag}.s")
+            subprocess.run([B._hipcc(), *B.FLAGS, *B.PER_FILE_FLAGS.get(src, []), *extra, "-I", B.INCLUDE, "-S", "--cuda-device-only", os.path.join(B.CSRC, src), "-o", o],
+                           check=True, capture_output=True)
+            out[(src, tag)] = open(o).read()
+    return out
+
+
+@pytest.mark.parametrize("kernel,tag", [("attn_bwd_dkv2_kernelILi1E", "bf16"), ("attn_bwd_dq2_kernel", "bf16"), ("attn_fwd4_kernel", "bf16"), ("attn_fwd4_kernel", "f16")])
+def test_hand_counted_lds_waits(asm, kernel, tag):
+    import check_lds_waits as C
+    r = C.check(asm[("attn.hip", tag)], kernel, inflight_at_back_edge="fwd4" in kernel)
+    assert not r["errors"], r["errors"][:5]
+    assert r["reads"] > 0 and r["waits"] > 0 and r["mfma"] > 0
+
+
+def test_lds_wait_checker_catches_a_wrong_count(asm):
+    """mutation: relax one counted wait of the forward kernel's second-product loop by one - the replay must object"""
+    import check_lds_waits as C
+    text = asm[("attn.hip", "f16")]
+    i = text.index("attn_fwd4_kernel")
+    m = re.search(r"s_waitcnt lgkmcnt\(([3-9])\)", text[text.index("Loop Header", i):])
+    j = text.index("Loop Header", i) + m.start()
+    bad = text[:j] + f"s_waitcnt lgkmcnt({int(m.group(1)) + 3})" + text[j + len(m.group(0)):]
+    assert C.check(bad, "attn_fwd4_kernel", inflight_at_back_edge=True)["errors"]
+
+
+@pytest.mark.parametrize("tag", ["bf16", "f16"])
+def test_fwd4_register_ownership(asm, tag):
+    text = asm[("attn.hip", tag)]
+    name = re.search(r"^(_Z\w*attn_fwd4_kernel\w*):", text, re.M).group(1)
+    meta = text[text.index(".amdhsa_kernel " + name):]
+    meta = meta[:meta.index(".end_amdhsa_kernel")]
+    assert re.search(r"\.amdhsa_private_segment_fixed_size\s+0\b", meta), "scratch in attn_fwd4_kernel"
+    body = text[text.index("\n" + name + ":"):]
+    body = body[:body.index(".Lfunc_end")]
+    assert "scratch_" not in body
+    lines = body.split("\n")
+    h = max(i for i, l in enumerate(lines) if "Loop Header" in l)
+    # hot path of one tile body = from a body's barrier up to the branch that skips the slow path
+    bars = [i for i in range(h, len(lines)) if re.match(r"\s+s_barrier", lines[i])]
+    assert len(bars) == 4, "one barrier per tile body, four bodies (4-slot rings)"
+    for b0 in bars:
+        end = next(i for i in range(b0, len(lines)) if re.match(r"\s+s_cbranch_vccz", lines[i]))
+        hot = [l for l in lines[b0:end] if re.match(r"\s+[a-z]", l)]
+        ops = [l.split()[0] for l in hot]
+        assert not any("accvgpr" in o for o in ops), "register-file traffic on the hot path"
+        assert sum(o.startswith("v_mfma_f32_32x32x16") for o in ops) == 20 and sum(o.startswith("v_mfma_f32_16x16x32") for o in ops) == 40
+        assert sum(o.startswith("global_load_lds") for o in ops) == 6 and sum(o == "s_barrier" for o in ops) == 1
+
+
+def test_m0_has_no_other_user(asm):
+    for key, text in asm.items():
+        for l in text.split("\n"):
+            c = l.split(";")[0]
+            if re.search(r"\bm0\b", c):
+                assert re.match(r"\s+s_(mov_b32|add_u32) m0,", c), (key, l.strip())
+            assert not re.match(r"\s+(s_movrel|v_movrel|s_sendmsg|ds_gws|v_interp)", c), (key, l.strip())

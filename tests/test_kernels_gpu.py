@@ -10,7 +10,7 @@ import torch.nn.functional as F
 
 pytestmark = pytest.mark.gpu
 
-from conftest import rel_l2  # noqa: E402
+from conftest import record_parity, rel_l2  # noqa: E402
 
 F16_BUILD = os.environ.get("PXA_OPERAND_DTYPE", "bf16").lower() in ("f16", "fp16", "float16", "half")
 # one rounding of a 16-bit output: bf16 ~1.6e-3 rel-L2 RMS -> 4e-3; IEEE fp16 (3 more mantissa bits) ~2e-4 -> 5e-4
@@ -518,6 +518,7 @@ def test_gemm_nt_headline_shapes(ops, N, K, flavour):
         F.gelu(x, approximate="tanh").backward(torch.ones_like(x))
         e = max(rel_l2(out.float(), F.gelu(pre, approximate="tanh")), rel_l2(out2.float(), x.grad))
     print(f"\n[NT {M_TOK}x{N}x{K} {flavour}] rel-L2 {e:.2e} (bound {BF16_TOL:.0e})")
+    record_parity(f"gemm NT {M_TOK}x{N}x{K} {flavour} vs fp32", e, BF16_TOL)
     assert e < BF16_TOL
 
 
@@ -538,6 +539,7 @@ def test_gemm_nn_headline_shapes(ops, K, N, flavour):
         print(f"\n[NN colsum] rel-L2 vs column sums of the stored values {e_cs:.2e}")
         assert e_cs < 1e-4
     print(f"\n[NN {M_TOK}x{N}x{K} {flavour}] rel-L2 {e:.2e} (bound {BF16_TOL:.0e})")
+    record_parity(f"gemm NN {M_TOK}x{N}x{K} {flavour} vs fp32", e, BF16_TOL)
     assert e < BF16_TOL
 
 
@@ -588,6 +590,8 @@ def test_attention_headline_shapes(ops, B, H, Nq, Nk):
     ro, rdq, rdk, rdv = _attn_ref_heads(q.view(B, Nq, H, 72), k.view(B, Nk, H, 72), v.view(B, Nk, H, 72), do.view(B, Nq, H, 72))
     errs = {n: rel_l2(t.float().view_as(r), r) for n, t, r in (("o", o, ro), ("dq", dq, rdq), ("dk", dk, rdk), ("dv", dv, rdv))}
     print(f"\n[attention B{B} H{H} Nq{Nq} Nk{Nk}] rel-L2 " + " ".join(f"{n} {e:.2e}" for n, e in errs.items()) + f" (bounds {BF16_TOL:.0e} / {2 * BF16_TOL:.0e})")
+    for n, e in errs.items():
+        record_parity(f"attention B{B} H{H} Nq{Nq} Nk{Nk}: {n} vs fp32 attention", e, BF16_TOL if n == "o" else 2 * BF16_TOL)
     assert errs["o"] < BF16_TOL
     assert max(errs["dq"], errs["dk"], errs["dv"]) < 2 * BF16_TOL
 
@@ -639,6 +643,40 @@ def test_attention_dkv_kernel_modes(ops, monkeypatch, mode, dqm, B, H, Nq, Nk, l
     for i, ref in enumerate((rdk, rdv)):                        # fused bias-gradient column sums
         got, want = part.sum(0)[i * C:(i + 1) * C], ref.reshape(-1, C).sum(0)
         assert (got - want).norm() < 5e-3 * ref.norm() + 1e-6, (i, (got - want).norm().item(), ref.norm().item())
+
+
+@pytest.mark.parametrize("B,H,Nq,Nk,scale,drift", [(2, 3, 256, 64, 1.0, 0.0), (2, 3, 256, 128, 1.0, 0.0), (1, 2, 300, 192, 1.0, 0.0), (2, 16, 1024, 1024, 1.0, 0.0),
+                                                     (1, 2, 512, 1024, 6.0, 3.0), (1, 2, 512, 4096, 3.0, 0.0), (1, 16, 4096, 1024, 1.0, 0.0), (1, 2, 256, 512, 0.02, 0.0)])
+def test_attention_fwd4_one_wave_per_simd(ops, monkeypatch, B, H, Nq, Nk, scale, drift):
+    """attn_fwd4_kernel (round 4: one wave per SIMD, 4-slot K / V rings, deferred maximum in a slow path) forced on wherever it applies, against fp32
+    attention and against attn_fwd2_kernel: 1 .. 64 key tiles (ring prologue, clamped re-fetches past the last tile), ragged query blocks, tiny scores,
+    and scores whose level drifts upward along the keys so that the deferred maximum moves on most tiles (the rescale path: O, l, the pending S').
+    The fp16 build folds scale and maximum into the first product (one more rounding of the query operand: bounds 1.3 x the two-wave kernel's error)."""
+    C = H * 72
+    q, k, v = bf(_gpu_rnd(B, Nq, C, seed=1) * scale), _gpu_rnd(B, Nk, C, seed=2) * scale, bf(_gpu_rnd(B, Nk, C, seed=3))
+    if drift:
+        k = k + torch.linspace(0, drift, Nk, device="cuda")[None, :, None] * q.float().mean(1, keepdim=True).sign()
+    k = bf(k)
+    st = ((Nq * C, C, 72), (Nk * C, C, 72), (Nk * C, C, 72), (Nq * C, C, 72))
+    res = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("PXA_ATTN_FWD4", mode)
+        o = torch.full((B, Nq, C), float("nan"), dtype=_opd(), device="cuda")
+        lse = torch.full((B, H, Nq), float("nan"), device="cuda")
+        ops.attention_fwd(q, k, v, o, lse, B, H, Nq, Nk, st)
+        res[mode] = (o, lse)
+    qf, kf, vf = (t.float().view(B, -1, H, 72).transpose(1, 2) for t in (q, k, v))
+    sc = (qf @ kf.transpose(-1, -2)) * 72 ** -0.5
+    ro, rl = (sc.softmax(-1) @ vf).transpose(1, 2).reshape(B, Nq, C), torch.logsumexp(sc, -1) / math.log(2)
+    e4, e2 = rel_l2(res["1"][0].float(), ro), rel_l2(res["0"][0].float(), ro)
+    l4, l2 = (res["1"][1] - rl).abs().max().item(), (res["0"][1] - rl).abs().max().item()
+    print(f"\n[fwd4 B{B} H{H} Nq{Nq} Nk{Nk} x{scale} drift {drift}] o rel-L2 {e4:.2e} (two-wave kernel {e2:.2e}), lse max abs {l4:.1e} ({l2:.1e})")
+    record_parity(f"attn_fwd4 B{B} H{H} Nq{Nq} Nk{Nk} x{scale}: o vs fp32 attention", e4)
+    assert torch.isfinite(res["1"][0].float()).all() and torch.isfinite(res["1"][1]).all()
+    if F16_BUILD and scale > 1:       # folded scale: the second rounding of the query operand grows with the score level (|c S| up to ~400 here)
+        assert e4 < 2e-3 and l4 < 0.1
+    else:
+        assert e4 < max(BF16_TOL, 1.3 * e2) and l4 < max(2e-3, 1.5 * l2)
 
 
 def test_attention_full_grid_b16(ops):
