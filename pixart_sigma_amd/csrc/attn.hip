@@ -1969,7 +1969,20 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv3_kernel(AttnParams p) {
 #ifndef PXA_ATTN_FWD4_DEFAULT
 #define PXA_ATTN_FWD4_DEFAULT FWD4_FOLD      // on where it wins: with the fold (fp16 build) 1.19-1.20 ms against 1.28-1.31; without it the two organisations tie (below)
 #endif
-constexpr float FWD4_THRESH = 6.0f;
+// The deferred maximum.  The slow path is EXPENSIVE here (O lives in the accumulator half: 160 v_accvgpr moves, two MFMA drains, 64 S' updates - about
+// one tile's time), so the kernel's speed follows the score range through the number of events: with q, k ~ 2 N(0, 1) and the usual P <= 2^6 rule 1.48 ms
+// against 1.27 at N(0, 1) - the 12-17 % "in-step gap" of VERDICT r03 item 5 (the step's activations are not N(0, 1); the dQ / dK/dV kernels, which have
+// no such path, show no gap; a preceding GEMM, freshly written operands or an HBM write stream in front of the launch change nothing:
+// profiles/r4_09_instep_gap.txt, r4_10_fwd_vs_score_range.txt).  Two changes: the window is as wide as the operand type allows - S' <= 11, P <= 2048
+// (fp16 holds 65504; l and O accumulate in fp32) - and the first tile's maximum is entered with a MARGIN of 4 (P of the first tile's own maximum = 1/16:
+// fp16 keeps full precision down to 2^-14), so the maximum may grow by 15 in the log2 domain (3.3e4 x) over the keys before anything is rescaled.
+#ifndef FWD4_THRESH_LOG2
+#define FWD4_THRESH_LOG2 11.0f
+#endif
+#ifndef FWD4_MARGIN_LOG2
+#define FWD4_MARGIN_LOG2 4.0f
+#endif
+constexpr float FWD4_THRESH = FWD4_THRESH_LOG2, FWD4_MARGIN = FWD4_MARGIN_LOG2;
 #ifndef FWD4_NVQ
 #define FWD4_NVQ 5          // register quads the V^T fragments rotate through: a fragment is read FWD4_NVQ - 1 groups (of 4 MFMAs) ahead of its use
 #endif
@@ -2161,7 +2174,7 @@ __global__ __launch_bounds__(256, 1) void attn_fwd4_kernel(AttnParams p) {
     bcast_halves(mrel, mx[0], mx[1]);
 #pragma unroll
     for (int s = 0; s < QS; s++) {
-      const float dmax = first ? mx[s] : fmaxf(mx[s], 0.f);
+      const float dmax = first ? mx[s] + FWD4_MARGIN : fmaxf(mx[s], 0.f);
       float mnew = mc[s] + dmax;
       bf16_t nb = (bf16_t)0.f;
       if constexpr (FOLD) { nb = (bf16_t)(-mnew); mnew = -(float)nb; }   // what the slot will hold, rounded to the operand type

@@ -676,7 +676,7 @@ def test_attention_fwd4_one_wave_per_simd(ops, monkeypatch, B, H, Nq, Nk, scale,
     if F16_BUILD and scale > 1:       # folded scale: the second rounding of the query operand grows with the score level (|c S| up to ~400 here)
         assert e4 < 2e-3 and l4 < 0.1
     else:
-        assert e4 < max(BF16_TOL, 1.3 * e2) and l4 < max(2e-3, 1.5 * l2)
+        assert e4 < max(BF16_TOL, 1.3 * e2) and l4 < max(2e-3, 1.5 * l2, 2e-5 * rl.abs().max().item())     # lse itself reaches several hundred in the scaled cases
 
 
 def test_attention_full_grid_b16(ops):

@@ -74,7 +74,10 @@ def check():
 def timeit():
     B, H, N, D = 16, 16, 4096, 1152
     R = B * N
-    qkv = torch.randn(R, 3 * D, device=dev).to(OPD)
+    qs = float(os.environ.get("KBENCH_QK_SCALE", "1"))     # > 1: larger score range -> the deferred maximum moves more often (the in-step data is not N(0, 1))
+    qkv = torch.randn(R, 3 * D, device=dev)
+    qkv[:, :2 * D] *= qs
+    qkv = qkv.to(OPD)
     a = torch.empty(R, D, dtype=OPD, device=dev)
     lse = torch.empty(B, H, N, device=dev)
     s3 = (N * 3 * D, 3 * D, 72)
@@ -92,7 +95,7 @@ def timeit():
         e1.record()
         e1.synchronize()
         t = e0.elapsed_time(e1) / 100 * 1e-3
-        print(f"attn fwd self B16 H16 N4096 PXA_ATTN_FWD4={mode} lib={os.environ.get('PXA_LIB_PATH', 'default')}: {t * 1e3:7.3f} ms {fl / t / 1e12:7.1f} TF/s", flush=True)
+        print(f"attn fwd self B16 H16 N4096 PXA_ATTN_FWD4={mode} lib={os.environ.get('PXA_LIB_PATH', 'default')} qk_scale={qs:g}: {t * 1e3:7.3f} ms {fl / t / 1e12:7.1f} TF/s", flush=True)
 
 
 def trace():
@@ -117,8 +120,55 @@ def trace():
           f"barrier wait {buf[0] * 10 / n:7.1f}  phase A {buf[1] * 10 / n:7.1f}  phase B {buf[2] * 10 / n:7.1f}  tiles {buf[3]}", flush=True)
 
 
+def instep():
+    """the forward self-attention runs 12-17 % longer inside the training step than stand-alone.  Reproduce the step's neighbourhood:
+    qkv GEMM (writes the 453 MB the attention reads) -> attention, timed with events around the attention alone; variants: the GEMM writes ANOTHER
+    buffer (same power / clock history, no freshly written operands), a long idle gap before the attention, and an elementwise pass in between."""
+    B, H, N, D = 16, 16, 4096, 1152
+    R = B * N
+    x = torch.randn(R, D, device=dev).to(OPD)
+    w = (torch.randn(3 * D, D, device=dev) * D ** -0.5).to(OPD)
+    bias = torch.zeros(3 * D, device=dev)
+    qkv, other = torch.empty(R, 3 * D, dtype=OPD, device=dev), torch.empty(R, 3 * D, dtype=OPD, device=dev)
+    ops.gemm(x, w, ops.NT, bias=bias, out=qkv)
+    a = torch.empty(R, D, dtype=OPD, device=dev)
+    lse = torch.empty(B, H, N, device=dev)
+    s3 = (N * 3 * D, 3 * D, 72)
+    st = (s3, s3, s3, (N * D, D, 72))
+    attn = lambda: ops.attention_fwd(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], a, lse, B, H, N, N, st)
+    big = torch.empty(256 * 1024 * 1024 // 4, device=dev)
+
+    def run(pre, iters=40):
+        for _ in range(5):
+            pre(); attn()
+        tot = 0.0
+        evs = []
+        for _ in range(iters):
+            pre()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(); attn(); e1.record()
+            evs.append((e0, e1))
+        torch.cuda.synchronize()
+        return sum(e0.elapsed_time(e1) for e0, e1 in evs) / iters
+
+    for mode in ("1", "0"):
+        os.environ["PXA_ATTN_FWD4"] = mode
+        res = {
+            "alone (back to back)": run(lambda: None),
+            "after qkv GEMM -> qkv": run(lambda: ops.gemm(x, w, ops.NT, bias=bias, out=qkv)),
+            "after qkv GEMM -> other buffer": run(lambda: ops.gemm(x, w, ops.NT, bias=bias, out=other)),
+            "after 1 GB fill (HBM write stream)": run(lambda: big.fill_(1.0)),
+            "after GEMM -> qkv + 1 GB fill": run(lambda: (ops.gemm(x, w, ops.NT, bias=bias, out=qkv), big.fill_(1.0))),
+            "after host sync (idle GPU)": run(lambda: torch.cuda.synchronize()),
+        }
+        print(f"in-step neighbourhood, PXA_ATTN_FWD4={mode}: " + "; ".join(f"{k}: {v:.3f} ms" for k, v in res.items()), flush=True)
+
+
 if __name__ == "__main__":
     what = sys.argv[1] if len(sys.argv) > 1 else "all"
+    if what == "instep":
+        instep()
+        sys.exit(0)
     if what == "trace":
         trace()
         sys.exit(0)
