@@ -2379,6 +2379,347 @@ __global__ __launch_bounds__(256, 1) void attn_fwd4_kernel(AttnParams p) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------ backward: dK / dV, ONE wave per SIMD (round 4)
+// What the forward kernel above taught (profiles/r4_06_fwd4_ab.txt): on this part the ORGANISATION of a fixed instruction mix does not move the time - one
+// wave per SIMD placed by hand ties with two in-order waves - the instruction COUNT does.  attn_bwd_dkv2_kernel's count is dominated by operand
+// movement: its keys are stationary (32 per wave) and every MFMA consumes a fresh Q / dO fragment from LDS - 84 LDS reads for 44 MFMAs per tile and
+// wave, ~125 B/clk of LDS traffic per CU against a 128 B/clk port.  Here a wave owns 64 keys (two 32-key blocks kb) and the whole register file:
+// every fragment read from LDS feeds TWO MFMAs (34 read instructions for 44 MFMAs per 32-query sub-tile: 0.77 per MFMA instead of 1.9), half the waves
+// read the same Q / dO tile.  dK / dV accumulators (192 registers) and the V row operands live in the accumulator half ("a" constraints, asm MFMAs:
+// see "Register ownership" above); S / dP / P / dS and the fragment quads in the arch half.
+// Work of one 32-query sub-tile j (step), in issue order - 44 MFMAs, each fragment f feeding key blocks 0 and 1 back to back:
+//   S(j+1)  10 MFMAs   Q rows of the NEXT sub-tile x K^T       -> S'(j+1) = S - lse / c  (statistics rows ride in k-slots 72..74, see attn_bwd_dkv2_kernel)
+//   dP(j)   10 MFMAs   dO rows x V^T                           -> dP' = dP - delta
+//   dV(j)   12 MFMAs   dO^T (transpose reads) x P(j)
+//   dK(j)   12 MFMAs   Q^T  (transpose reads) x dS(j)
+// with the vector work of the step in their gaps, 4 per gap: E(j): P = exp2(c S'(j)) + the cvt_pk of P under S(j+1) / dP(j) (S is double-buffered, nothing
+// else is); M(j): dS = P dP' + its cvt_pk under dV(j); the gaps of dK(j) carry the tile hand-over.  Fragments rotate through four register quads, read
+// two fragments ahead (22 fragments per step: the rotation closes over the two steps of a tile), waits are hand-counted (tools/check_lds_waits.py).
+// Ring: {Q tile, L rows, dO tile, D rows} x 4 stages (104 KiB, one workgroup per CU), tile t+3 fetched behind the ONE barrier of tile t, which sits in
+// front of the first look-ahead read into tile t+1 (two fragments before the end of sub-tile 0) behind a counted vmcnt(7): tile t+2 stays in flight.
+// Every wave issues 7 LDS-DMA pieces per tile (waves 2 / 3 repeat the statistics pieces of waves 0 / 1: same bytes, uniform vmcnt accounting).
+// Dense keys, Nk % 256 == 0, Nq % 64 == 0 (every self-attention shape of the square buckets); everything else runs attn_bwd_dkv2_kernel.
+// (W >= 0: the counted wait for the fragment `a` rides in the MFMA's own statement - a separate wait statement with the fragment as its output draws a
+// compiler boundary s_nop in front of every consumer: 44 per tile in the first build of this kernel)
+#define PXA_WAIT_STR "s_waitcnt lgkmcnt(%3)\n\t"
+template <int W = -1> __device__ __forceinline__ void mfma32_va_first(f32x16& d, const bf16x8& a, const bf16x8& b) {
+  if constexpr (W >= 0) asm volatile(PXA_WAIT_STR PXA_MFMA32_ASM " %0, %1, %2, 0" : "=&v"(d) : "v"(a), "a"(b), "n"(W));
+  else asm volatile(PXA_MFMA32_ASM " %0, %1, %2, 0" : "=&v"(d) : "v"(a), "a"(b));
+}
+template <int W = -1> __device__ __forceinline__ void mfma32_va(f32x16& d, const bf16x8& a, const bf16x8& b) {
+  if constexpr (W >= 0) asm volatile(PXA_WAIT_STR PXA_MFMA32_ASM " %0, %1, %2, %0" : "+v"(d) : "v"(a), "a"(b), "n"(W));
+  else asm volatile(PXA_MFMA32_ASM " %0, %1, %2, %0" : "+v"(d) : "v"(a), "a"(b));
+}
+template <int W = -1> __device__ __forceinline__ void mfma32_vv_first(f32x16& d, const bf16x8& a, const bf16x8& b) {
+  if constexpr (W >= 0) asm volatile(PXA_WAIT_STR PXA_MFMA32_ASM " %0, %1, %2, 0" : "=&v"(d) : "v"(a), "v"(b), "n"(W));
+  else asm volatile(PXA_MFMA32_ASM " %0, %1, %2, 0" : "=&v"(d) : "v"(a), "v"(b));
+}
+template <int W = -1> __device__ __forceinline__ void mfma32_vv(f32x16& d, const bf16x8& a, const bf16x8& b) {
+  if constexpr (W >= 0) asm volatile(PXA_WAIT_STR PXA_MFMA32_ASM " %0, %1, %2, %0" : "+v"(d) : "v"(a), "v"(b), "n"(W));
+  else asm volatile(PXA_MFMA32_ASM " %0, %1, %2, %0" : "+v"(d) : "v"(a), "v"(b));
+}
+template <int W = -1> __device__ __forceinline__ void mfma32_acc(f32x16& d, const bf16x8& a, const bf16x8& b) {
+  if constexpr (W >= 0) asm volatile(PXA_WAIT_STR PXA_MFMA32_ASM " %0, %1, %2, %0" : "+a"(d) : "v"(a), "v"(b), "n"(W));
+  else asm volatile(PXA_MFMA32_ASM " %0, %1, %2, %0" : "+a"(d) : "v"(a), "v"(b));
+}
+#ifndef PXA_ATTN_DKV4_DEFAULT
+#define PXA_ATTN_DKV4_DEFAULT 1
+#endif
+constexpr int DKV4_STAGES = 4;
+constexpr int dkv4_nreads(int i) { const int k = ((i % 22) + 22) % 22; return k < 10 ? 1 : 2; }   // fragment i of a step: 10 row fragments, 12 transposed ones
+__global__ __launch_bounds__(256, 1) void attn_bwd_dkv4_kernel(AttnParams p) {
+  __shared__ __attribute__((aligned(16))) char smem[DKV4_STAGES * STAGE_B];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), hi = lane >> 5;
+  int bx, h, b;
+  block_coords(p, bx, h, b);
+  const long kbase = (long)b * p.k_bs, vbase = (long)b * p.v_bs, dkbase = (long)b * p.dk_bs, dvbase = (long)b * p.dv_bs;
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+  // stationary operands: K / V rows of this wave's 2 x 32 keys (B operands: lane = key), -1.0 in k-slots 72..74 against the statistics rows
+  int kv[2];
+  bf16x8 kf[2][KSTEPS], vf[2][KSTEPS];
+#pragma unroll
+  for (int kb = 0; kb < 2; kb++) {
+    kv[kb] = bx * 256 + wave * 64 + kb * 32 + (lane & 31);
+    load_row_frags(kf[kb], p.K + kbase + (long)kv[kb] * p.k_ts + (long)h * p.k_hs, true, hi);
+    load_row_frags(vf[kb], p.V + vbase + (long)kv[kb] * p.v_ts + (long)h * p.v_hs, true, hi);
+    settle(kf[kb]);
+    settle(vf[kb]);
+    if (hi == 1) {
+      u32x4 w = __builtin_bit_cast(u32x4, kf[kb][KSTEPS - 1]);
+      w[0] = PXA_OPERAND_MINUS_ONE_X2; w[1] = PXA_OPERAND_MINUS_ONE_X1;
+      kf[kb][KSTEPS - 1] = __builtin_bit_cast(bf16x8, w);
+      w = __builtin_bit_cast(u32x4, vf[kb][KSTEPS - 1]);
+      w[0] = PXA_OPERAND_MINUS_ONE_X2; w[1] = PXA_OPERAND_MINUS_ONE_X1;
+      vf[kb][KSTEPS - 1] = __builtin_bit_cast(bf16x8, w);
+    }
+#pragma unroll
+    for (int ks = 0; ks < KSTEPS; ks++) to_agpr(vf[kb][ks]);
+  }
+  const bf16_t* Qp = p.Q + (long)b * p.q_bs + (long)h * p.q_hs;
+  const bf16_t* Dp = p.dO + (long)b * p.o_bs + (long)h * p.o_hs;
+  const bf16_t* Ls = p.stats + ((long)b * p.H + h) * p.Nq64 * 8;
+  const bf16_t* Ds = Ls + (long)p.B * p.H * p.Nq64 * 8;
+  const int qts = (int)p.q_ts, ots = (int)p.o_ts;
+  const int T = p.Nq / BKV;                                        // full 64-query tiles (checked by the launcher)
+  const float c = p.scale_log2;
+
+  // LDS-DMA plan (saddr form: wave-uniform tile base + per-lane byte offset; Q and dO piece i share their lane mask)
+  DmaPlan pl;
+  dma_plan(pl, wave, lane);
+  unsigned offQ[NDMA], offD[NDMA];
+  unsigned long long dmask[NDMA];
+#pragma unroll
+  for (int i = 0; i < NDMA; i++) {
+    offQ[i] = (unsigned)(pl.row[i] * qts + pl.coff[i]) * 2u;
+    offD[i] = (unsigned)(pl.row[i] * ots + pl.coff[i]) * 2u;
+    dmask[i] = __builtin_amdgcn_ballot_w64(pl.coff[i] >= 0);
+  }
+  const unsigned lds0 = (unsigned)(uintptr_t)LDS_PTR(char, smem);
+  const unsigned wbase = __builtin_amdgcn_readfirstlane(wave * 1024);          // (stage addresses are added per fetch)
+  const long qstep = (long)BKV * qts, ostep = (long)BKV * ots;
+  const unsigned stat_off = (unsigned)lane * 16u;                  // statistics rows: 64 x 16 B per tile, one piece; waves 0 / 2 fetch L, waves 1 / 3 D
+  const bf16_t* statp = (wave & 1) ? Ds : Ls;
+  const unsigned stat_dst = __builtin_amdgcn_readfirstlane((wave & 1) ? 2 * TILE_B + STAT_B : TILE_B);
+  // tile fetch, in four parts (three {Q, dO} piece pairs + the statistics piece) so that the loop can spread them over MFMA gaps; the source pointers
+  // are running ones (qnext / dnext / snext: the next tile to fetch, clamped to the last one - past it a harmless re-fetch keeps every wave's piece
+  // count, and with it the counted vmcnt, uniform)
+  const bf16_t* qnext = Qp;
+  const bf16_t* dnext = Dp;
+  const bf16_t* snext = statp;
+  auto issue_part = [&](auto pc, unsigned sb) {                    // sb = LDS byte address of the stage
+    constexpr int P = decltype(pc)::value;
+    const unsigned wb = wbase + sb, so = stat_off, sd = stat_dst + sb;
+    const bf16_t* sn = snext;
+    if constexpr (P == 0) dma_pair<0, TILE_B + STAT_B>(dmask[0], wb, offQ[0], qnext, offD[0], dnext);
+    if constexpr (P == 1) dma_pair<4096, TILE_B + STAT_B + 4096>(dmask[1], wb, offQ[1], qnext, offD[1], dnext);
+    if constexpr (P == 2) dma_pair<8192, TILE_B + STAT_B + 8192>(dmask[2], wb, offQ[2], qnext, offD[2], dnext);
+    if constexpr (P == 3) asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" :: "s"(sd), "v"(so), "s"(sn) : "memory");
+  };
+  int tfetch = 0;                                                  // tile index behind qnext / dnext / snext
+  auto advance = [&]() {
+    const bool more = tfetch + 1 < T;
+    qnext += more ? qstep : 0; dnext += more ? ostep : 0; snext += more ? (long)BKV * 8 : 0;
+    tfetch++;
+  };
+  auto issue = [&](unsigned sb) { issue_part(IntC<0>{}, sb); issue_part(IntC<1>{}, sb); issue_part(IntC<2>{}, sb); issue_part(IntC<3>{}, sb); advance(); };
+
+  // fragment addressing inside a stage: per-lane bases + instruction immediates (see attn_bwd_dkv2_kernel); `cur` = stage of tile t, `nxt` = of tile t+1
+  FragAddr fa;
+  frag_addr(fa, lane);
+  int r4[2];
+#pragma unroll
+  for (int sub = 0; sub < 2; sub++) r4[sub] = hi ? TILE_B + (sub * 32 + (lane & 31)) * 16 : fa.rb[0] + 2 * 64 + sub * 32 * ROWB;
+  struct Bases { unsigned r0, r1, r40, r41, t0, t1; };
+  auto bases = [&](unsigned st) -> Bases { return Bases{st + (unsigned)fa.rb[0], st + (unsigned)fa.rb[1], st + (unsigned)r4[0], st + (unsigned)r4[1],
+                                                        st + (unsigned)fa.tb[0], st + (unsigned)fa.tb[1]}; };
+  constexpr int DOFF = TILE_B + STAT_B;
+
+  for (int st = 0; st < DKV4_STAGES; st++) {
+    init_pads(smem + st * STAGE_B, 0, tid);
+    init_pads(smem + st * STAGE_B + DOFF, 0, tid);
+  }
+  f32x16 dk[2][3], dv[2][3];
+#pragma unroll
+  for (int kb = 0; kb < 2; kb++) {
+    zero3(dk[kb]); zero3(dv[kb]);
+#pragma unroll
+    for (int dt = 0; dt < 3; dt++) { to_agpr(dk[kb][dt]); to_agpr(dv[kb][dt]); }
+  }
+  f32x16 S[2][2], dP[2];                                           // S[buffer][kb] (S'(j) in buffer j & 1; E(j) leaves P there), dP[kb]
+  bf16x8 pb[2][2], db[2][2];                                       // [kb][uu]: P / dS of 16 queries each, packed (B operands of the second products)
+  bf16x8 f[4];                                                     // fragment quads
+
+  // fragment i of step (SUB): 0..4 Q rows of the next sub-tile (k-step i), 5..9 dO rows, 10..15 dO^T (uu, dt), 16..21 Q^T (uu, dt); i >= 22: the next
+  // step's fragments (look-ahead).  cb = this tile's stage, nb = the next tile's.
+  auto rd_frag = [&](auto subc, auto ic, bf16x8& d, const Bases& cb, const Bases& nb) {
+    constexpr int SUB = decltype(subc)::value, I = decltype(ic)::value;
+    if constexpr (I >= 22) {                                       // next step: its fragments 0..3 are looked ahead (Q rows, k-steps 0..3)
+      constexpr int ks = I - 22;
+      static_assert(ks < KSTEPS - 1, "look-ahead reaches the statistics fragment");
+      // next step = (SUB ^ 1): its S block reads the sub-tile after it: SUB == 0 -> next step is sub 1 of this tile, reads (t+1, sub 0); SUB == 1 -> next
+      // step is sub 0 of tile t+1, reads (t+1, sub 1)
+      lds_row_asm<(SUB ? 32 * ROWB : 0) + (ks >> 1) * 64>(d, (ks & 1) ? nb.r1 : nb.r0);
+    } else if constexpr (I < 5) {
+      constexpr int ks = I;
+      if constexpr (SUB == 0) {                                    // (t, sub 1)
+        if constexpr (ks < KSTEPS - 1) lds_row_asm<32 * ROWB + (ks >> 1) * 64>(d, (ks & 1) ? cb.r1 : cb.r0);
+        else lds_row_asm<0>(d, cb.r41);
+      } else {                                                     // (t+1, sub 0)
+        if constexpr (ks < KSTEPS - 1) lds_row_asm<(ks >> 1) * 64>(d, (ks & 1) ? nb.r1 : nb.r0);
+        else lds_row_asm<0>(d, nb.r40);
+      }
+    } else if constexpr (I < 10) {
+      constexpr int ks = I - 5;
+      if constexpr (ks < KSTEPS - 1) lds_row_asm<DOFF + SUB * 32 * ROWB + (ks >> 1) * 64>(d, (ks & 1) ? cb.r1 : cb.r0);
+      else lds_row_asm<DOFF>(d, SUB ? cb.r41 : cb.r40);
+    } else {
+      constexpr int k = (I - 10) % 6, uu = k / 3, dt = k % 3, isq = I >= 16;
+      lds_tr_asm<(isq ? 0 : DOFF) + (SUB * 2 + uu) * 16 * ROWB + dt * 64>(d, cb.t0, cb.t1);
+    }
+  };
+
+  // ---- prologue: tiles 0, 1, 2 in flight; S'(0); look-ahead fragments 0, 1 of step 0
+  issue(lds0);
+  issue(lds0 + STAGE_B);
+  issue(lds0 + 2 * STAGE_B);
+  lds_dma_wait<14>();
+  __syncthreads();
+  {
+    const Bases cb = bases(lds0);
+    static_for<5>([&](auto kc) {
+      constexpr int ks = decltype(kc)::value;
+      if constexpr (ks < KSTEPS - 1) lds_row_asm<(ks >> 1) * 64>(f[ks & 3], (ks & 1) ? cb.r1 : cb.r0);
+      else lds_row_asm<0>(f[0], cb.r40);
+      if constexpr (ks == 3) { lds_wait<0>(f[0]); }                // (quad 0 is reused by k-step 4: settle k-step 0 first)
+      if constexpr (ks == 3) { mfma32_vv_first(S[0][0], f[0], kf[0][0]); mfma32_vv_first(S[0][1], f[0], kf[1][0]); }
+    });
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]));
+    mfma32_vv(S[0][0], f[1], kf[0][1]); mfma32_vv(S[0][1], f[1], kf[1][1]);
+    mfma32_vv(S[0][0], f[2], kf[0][2]); mfma32_vv(S[0][1], f[2], kf[1][2]);
+    mfma32_vv(S[0][0], f[3], kf[0][3]); mfma32_vv(S[0][1], f[3], kf[1][3]);
+    mfma32_vv(S[0][0], f[0], kf[0][4]); mfma32_vv(S[0][1], f[0], kf[1][4]);
+    mfma_drain();
+#pragma unroll
+    for (int kb = 0; kb < 2; kb++)
+#pragma unroll
+      for (int g = 0; g < 16; g++) S[0][kb][g] *= c;               // (inside the loop the next step's scores are scaled under the dK MFMAs)
+    static_for<4>([&](auto ic) { rd_frag(IntC<0>{}, ic, f[decltype(ic)::value], cb, cb); });   // step 0 (tile 0, sub 0): fragments 0..3 = Q rows of (0, sub 1)
+  }
+
+  // ---- one step = one 32-query sub-tile.  Quad of fragment i = (i + 2 SUB) & 3; fragments are consumed in pairs behind ONE counted wait (the next
+  // pair, already issued, may stay in flight) and re-read four fragments ahead, right behind the second MFMA of the quad's previous owner.
+  // Vector work per MFMA gap gi = 2 i + kb: E(j) (P = exp2(c S'), cvt_pk) in gaps 0..19, M(j) (dS = P dP', cvt_pk) in gaps 20..31; the cvt_pk of a pair
+  // lags one gap behind its second exp2 / multiply (a transcendental's consumer otherwise draws a wait state: 53 s_nop per tile in the first build).
+  int t = 0;
+  auto step = [&](auto subc, const Bases& cb, const Bases& nb, unsigned fst) {      // fst: LDS address of the stage tile t+3 is fetched into
+    constexpr int SUB = decltype(subc)::value, CUR = SUB, NXT = SUB ^ 1;
+    // Stages (a producer and its consumer are always at least one MFMA apart - an exp2's consumer, and the exp2 itself behind the multiply that feeds
+    // it, otherwise draw wait states: 53 / 100 s_nop per tile in the first two builds):
+    //   gaps  0..19  exp2 of S'(j) c (scaled one step earlier) -> P, in place;  cvt_pk of the P pairs completed two gaps before
+    //   gaps 20..31  dS = P dP', in place in dP;                                cvt_pk of the dS pairs completed two gaps before (.. gap 33)
+    //   gaps 32..43  S'(j+1) *= c  (its first product finished in gap 9)
+    auto pack_p = [&](auto gc) {
+      constexpr int g0 = decltype(gc)::value;
+      if constexpr (g0 >= 0 && g0 < 20) {
+        constexpr int p0 = (32 * g0) / 20, p1 = (32 * (g0 + 1)) / 20;
+        static_for<p1 - p0>([&](auto ec) {
+          constexpr int e = p0 + decltype(ec)::value, kb = e >> 4, g = e & 15;
+          if constexpr (g & 1) {
+            unsigned w = pack_bf16x2(S[CUR][kb][g - 1], S[CUR][kb][g]);
+            asm volatile("" : "+v"(w));
+            u32x4 ww = __builtin_bit_cast(u32x4, pb[kb][g >> 3]);
+            ww[(g & 7) >> 1] = w;
+            pb[kb][g >> 3] = __builtin_bit_cast(bf16x8, ww);
+          }
+        });
+      }
+    };
+    auto pack_ds = [&](auto gc) {
+      constexpr int g0 = decltype(gc)::value;
+      if constexpr (g0 >= 20 && g0 < 32) {
+        constexpr int p0 = (32 * (g0 - 20)) / 12, p1 = (32 * (g0 - 19)) / 12;
+        static_for<p1 - p0>([&](auto ec) {
+          constexpr int e = p0 + decltype(ec)::value, kb = e >> 4, g = e & 15;
+          if constexpr (g & 1) {
+            unsigned w = pack_bf16x2(dP[kb][g - 1], dP[kb][g]);
+            asm volatile("" : "+v"(w));
+            u32x4 ww = __builtin_bit_cast(u32x4, db[kb][g >> 3]);
+            ww[(g & 7) >> 1] = w;
+            db[kb][g >> 3] = __builtin_bit_cast(bf16x8, ww);
+          }
+        });
+      }
+    };
+    auto valu = [&](auto gic) {
+      constexpr int gi = decltype(gic)::value;
+      pack_p(IntC<gi - 2>{});
+      pack_ds(IntC<gi - 2>{});
+      if constexpr (gi < 20) {
+        constexpr int e0 = (32 * gi) / 20, e1 = (32 * (gi + 1)) / 20;
+        static_for<e1 - e0>([&](auto ec) {
+          constexpr int e = e0 + decltype(ec)::value;
+          S[CUR][e >> 4][e & 15] = __builtin_amdgcn_exp2f(S[CUR][e >> 4][e & 15]);
+          asm volatile("" : "+v"(S[CUR][e >> 4][e & 15]));
+        });
+      } else if constexpr (gi < 32) {
+        constexpr int e0 = (32 * (gi - 20)) / 12, e1 = (32 * (gi - 19)) / 12;
+        static_for<e1 - e0>([&](auto ec) {
+          constexpr int e = e0 + decltype(ec)::value;
+          dP[e >> 4][e & 15] *= S[CUR][e >> 4][e & 15];
+          asm volatile("" : "+v"(dP[e >> 4][e & 15]));
+        });
+      } else {
+        constexpr int e0 = (32 * (gi - 32)) / 12, e1 = (32 * (gi - 31)) / 12;
+        static_for<e1 - e0>([&](auto ec) {
+          constexpr int e = e0 + decltype(ec)::value;
+          S[NXT][e >> 4][e & 15] *= c;
+          asm volatile("" : "+v"(S[NXT][e >> 4][e & 15]));
+        });
+      }
+    };
+    auto mma = [&](auto ic, auto kbc, auto wc) {                   // MFMA of fragment i for key block kb; W >= 0: behind the counted wait
+      constexpr int i = decltype(ic)::value, kb = decltype(kbc)::value, W = decltype(wc)::value, q = (i + 2 * SUB) & 3;
+      if constexpr (i < 5) { if constexpr (i == 0) mfma32_vv_first<W>(S[NXT][kb], f[q], kf[kb][0]); else mfma32_vv<W>(S[NXT][kb], f[q], kf[kb][i]); }
+      else if constexpr (i < 10) { if constexpr (i == 5) mfma32_va_first<W>(dP[kb], f[q], vf[kb][0]); else mfma32_va<W>(dP[kb], f[q], vf[kb][i - 5]); }
+      else if constexpr (i < 16) mfma32_acc<W>(dv[kb][(i - 10) % 3], f[q], pb[kb][(i - 10) / 3]);
+      else mfma32_acc<W>(dk[kb][(i - 16) % 3], f[q], db[kb][(i - 16) / 3]);
+    };
+    static_for<11>([&](auto kc) {
+      constexpr int i = 2 * decltype(kc)::value;
+      if constexpr (SUB == 0 && i == 18) {                         // the tile's barrier, in front of the first look-ahead read into tile t+1: tile t+1 has
+        lds_dma_wait<7>();                                         // landed (this wave's pieces; t+2 may stay in flight) and is visible; every wave is past
+        __syncthreads();                                           // tile t-1, whose stage takes tile t+3 (fetched in four parts: here, behind the step's last
+        issue_part(IntC<0>{}, fst);                                // fragment pair, and behind the first two pairs of the next step)
+      }
+      if constexpr (SUB == 0 && i == 20) issue_part(IntC<1>{}, fst);
+      if constexpr (SUB == 1 && i == 0) issue_part(IntC<2>{}, fst);
+      if constexpr (SUB == 1 && i == 2) { issue_part(IntC<3>{}, fst); advance(); }
+      // (each MFMA alone in its scheduling region: the gap's vector work then sits BEHIND it, never adjacent to the previous gap's)
+      mma(IntC<i>{}, IntC<0>{}, IntC<dkv4_nreads(i + 2) + dkv4_nreads(i + 3)>{});
+      __builtin_amdgcn_sched_barrier(0);
+      valu(IntC<2 * i>{});
+      __builtin_amdgcn_sched_barrier(0);
+      mma(IntC<i>{}, IntC<1>{}, IntC<-1>{});
+      __builtin_amdgcn_sched_barrier(0);
+      rd_frag(subc, IntC<i + 4>{}, f[(i + 2 * SUB) & 3], cb, nb);
+      valu(IntC<2 * i + 1>{});
+      __builtin_amdgcn_sched_barrier(0);
+      mma(IntC<i + 1>{}, IntC<0>{}, IntC<-1>{});
+      __builtin_amdgcn_sched_barrier(0);
+      valu(IntC<2 * i + 2>{});
+      __builtin_amdgcn_sched_barrier(0);
+      mma(IntC<i + 1>{}, IntC<1>{}, IntC<-1>{});
+      __builtin_amdgcn_sched_barrier(0);
+      rd_frag(subc, IntC<i + 5>{}, f[(i + 1 + 2 * SUB) & 3], cb, nb);
+      valu(IntC<2 * i + 3>{});
+      __builtin_amdgcn_sched_barrier(0);
+    });
+  };
+  // stage rotation without per-tile multiplies: cur / nx / (the stage of tile t+3 = the one of tile t-1) walk the ring by additions
+  unsigned cur = lds0, nx = lds0 + STAGE_B, fst = lds0 + 3 * STAGE_B;
+  Bases cb = bases(cur);
+  for (t = 0; t < T; t++) {
+    const Bases nb = bases(nx);
+    step(IntC<0>{}, cb, nb, fst);
+    step(IntC<1>{}, cb, nb, fst);
+    cb = nb;
+    fst = cur;
+    cur = nx;
+    nx = nx + STAGE_B == lds0 + DKV4_STAGES * STAGE_B ? lds0 : nx + STAGE_B;
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]));
+  lds_dma_wait<0>();                                               // the clamped re-fetches must not land in a later workgroup's LDS
+  mfma_drain();
+#pragma unroll
+  for (int kb = 0; kb < 2; kb++) {
+    store_rows(p.dK + dkbase + (long)kv[kb] * p.dk_ts + (long)h * p.dk_hs, dk[kb], p.scale, hi);
+    store_rows(p.dV + dvbase + (long)kv[kb] * p.dv_ts + (long)h * p.dv_hs, dv[kb], 1.f, hi);
+    if (p.dk_colsum) colsum_rows(p.dk_colsum + (b % PXA_COLSUM_SLOTS) * p.colsum_stride + h * DH, dk[kb], p.scale, true, hi, lane);
+    if (p.dv_colsum) colsum_rows(p.dv_colsum + (b % PXA_COLSUM_SLOTS) * p.colsum_stride + h * DH, dv[kb], 1.f, true, hi, lane);
+  }
+}
+
 int fill(AttnParams& p, const pxa_attn_args* a) {
   PXA_CHECK(a, "attn: null args");
   PXA_CHECK(a->head_dim == DH, "attn: head_dim %d unsupported (PixArt XL/2 uses 72)", a->head_dim);
@@ -2507,10 +2848,16 @@ extern "C" int pxa_attn_bwd(const pxa_attn_args* a, hipStream_t stream) {
   }
   if (p.dK) {
     const int max_k = a->max_kv_len > 0 ? a->max_kv_len : p.Nk;
-    p.nx = dkv_mode == 3 ? (max_k + 255) / 256 : (max_k + 127) / 128;
+    // 4 = one wave per SIMD, 64 keys per wave (dense keys in whole 256-key blocks, whole 64-query tiles); PXA_ATTN_DKV=4 asks for it, the default takes it
+    // where it applies and falls back to 2 elsewhere
+    const bool dkv4_ok = p.stats && !p.kv_start && p.Nk % 256 == 0 && p.Nk > 0 && p.Nq % BKV == 0 && p.Nq >= 2 * BKV;
+    if (dkv_mode == 4 && !dkv4_ok) dkv_mode = 2;
+    if (!env && dkv_mode == 2 && PXA_ATTN_DKV4_DEFAULT && dkv4_ok) dkv_mode = 4;
+    p.nx = dkv_mode >= 3 ? (max_k + 255) / 256 : (max_k + 127) / 128;
     PXA_CHECK((long)p.nx * p.H * p.B < (1L << 31), "pxa_attn_bwd: grid too large");
     if (p.nx > 0) {
-      if (dkv_mode == 3) hipLaunchKernelGGL(attn_bwd_dkv3_kernel<2>, dim3(p.nx * p.H * p.B), dim3(512), 0, stream, p);   // prefetch distances 3 / 4 / 6 measured the same
+      if (dkv_mode == 4) hipLaunchKernelGGL(attn_bwd_dkv4_kernel, dim3(p.nx * p.H * p.B), dim3(256), 0, stream, p);
+      else if (dkv_mode == 3) hipLaunchKernelGGL(attn_bwd_dkv3_kernel<2>, dim3(p.nx * p.H * p.B), dim3(512), 0, stream, p);   // prefetch distances 3 / 4 / 6 measured the same
       else if (dkv_mode == 2) hipLaunchKernelGGL(attn_bwd_dkv2_kernel<1>, dim3(p.nx * p.H * p.B), dim3(256), 0, stream, p);
       else if (dkv_mode == 1) hipLaunchKernelGGL(attn_bwd_dkv2_kernel<0>, dim3(p.nx * p.H * p.B), dim3(256), 0, stream, p);
       else hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3(p.nx * p.H * p.B), dim3(256), 0, stream, p);
