@@ -30,8 +30,9 @@ sys.path.insert(0, ROOT)
 
 D, H, DFF, DEPTH, LTXT = 1152, 16, 4608, 28, 300
 MFMA_PEAK = 2.5e15   # dense bf16, MI355X (MI355X_MICROARCH.md)
-PMC_FILES = ["profiles/r03s_pmc_attention.json", "profiles/r03l_pmc_attention.json", "profiles/r03c_pmc_attention.json", "profiles/r02f_pmc_attention.json", "profiles/r02_pmc_attention.json"]   # newest first (tools/pmc_query.py --json)
-DOMINANT = "attn_bwd_dkv2_kernel"     # the step's largest kernel by total time (profiles/r03c_step_kernel_stats.csv: 28 self-attention launches, 15 %)
+PMC_FILES = ["profiles/r4final_pmc_attention.json", "profiles/r03s_pmc_attention.json", "profiles/r03l_pmc_attention.json", "profiles/r03c_pmc_attention.json", "profiles/r02f_pmc_attention.json", "profiles/r02_pmc_attention.json"]   # newest first (tools/pmc_query.py --json)
+DOMINANT = "attn_bwd_dkv4_kernel"     # the step's largest kernel by total time (profiles/r4final_step_kernel_stats.csv: 28 self-attention launches; round 4: the
+                                      # one-wave-per-SIMD dK/dV kernel, 256 keys per workgroup - attn_bwd_dkv2_kernel<1> until round 3)
 
 
 def pmc_traffic(kernel_substr, grid):
@@ -104,7 +105,7 @@ def kernel_rooflines(B, N):
     res["attn_bwd_self"] = dict(flops=10.0 * B * N * N * D, seconds=t)     # delta + dQ + dK/dV kernels, algorithmic 2.5x forward
     # The dominant kernel by itself, one event pair around EACH launch (no subtraction).  PXA_ATTN_BWD_NO_PREPASS makes
     # pxa_attn_bwd skip its delta / stats pre-pass - the workspace still holds this input's rows from the call above - and dq = NULL skips the dQ
-    # kernel, so each call is exactly one attn_bwd_dkv2_kernel launch.  Its contract needs S, dP, dV, dK = 4 of the 2 N^2 d products.
+    # kernel, so each call is exactly one attn_bwd_dkv4_kernel launch.  Its contract needs S, dP, dV, dK = 4 of the 2 N^2 d products.
     os.environ["PXA_ATTN_BWD_NO_PREPASS"] = "1"
     try:
         one = lambda: ops.attention_bwd(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], a, da, lse, delta, None, dqkv[:, D:2 * D], dqkv[:, 2 * D:],  # noqa: E731
@@ -333,8 +334,8 @@ def main():
             ks = kernel_rooflines(B, N)
             # dominant kernel of the step by total time (profiles/: attn_bwd_dkv_kernel, 56 launches, ~17 % of the step)
             dom = ks["attn_bwd_dkv_kernel"]
-            traffic, tsrc = pmc_traffic(DOMINANT, ((N // 128) * H * B, N // 128))   # workgroups of the self-attention launch: flat grid (since r02b), x extent of the old 3-D grid
-            roof = {"bound": "mfma", "kernel": DOMINANT + "<1> (dK/dV of self-attention, B16 H16 N4096 d72)", "achieved": dom["tflops"], "peak": MFMA_PEAK / 1e12,
+            traffic, tsrc = pmc_traffic(DOMINANT, ((N // 256) * H * B,))   # workgroups of the self-attention launch (flat grid, 256 keys per workgroup)
+            roof = {"bound": "mfma", "kernel": DOMINANT + " (dK/dV of self-attention, B16 H16 N4096 d72)", "achieved": dom["tflops"], "peak": MFMA_PEAK / 1e12,
                     "unit": "TFLOP/s", "frac": dom["frac"], "traffic": traffic, "traffic_source": tsrc,
                     "flops_per_launch": dom["flops"], "ms_per_launch": dom["seconds"] * 1e3,
                     "timing": f"HIP event pair around each of {dom['launches']} single launches on the launch stream (min {dom['min_s'] * 1e3:.3f} / max {dom['max_s'] * 1e3:.3f} ms)",

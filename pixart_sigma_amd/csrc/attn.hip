@@ -2720,6 +2720,294 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv4_kernel(AttnParams p) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------ backward: dQ, ONE wave per SIMD (round 4)
+// attn_bwd_dkv4_kernel's idea for the query-stationary half: a wave owns 64 queries (two 32-query blocks qb) and the whole register file, every K / V /
+// K^T fragment read from LDS feeds both blocks (20 read instructions for 40 MFMAs per 32-key sub-tile; attn_bwd_dq2_kernel: 35), half the waves read the
+// same tiles.  Q / dO rows (B operands, 80 registers) and dQ^T (80) live in the accumulator half; S / dP / dS in the arch half.  Products, layouts,
+// the delta fold and the 16-row second product are attn_bwd_dq2_kernel's; the pipeline, per 32-key sub-tile j (step):
+//   S(j+1)   10 v_mfma_f32_32x32x16   K rows of the NEXT sub-tile x Q^T                  || E(j): P = exp2(c S^T - lse): the fma one gap ahead of its exp2
+//   dP(j)    10 v_mfma_f32_32x32x16   V rows x dO^T  (delta rides in slots 72..74)       ||
+//   dQ(j-1)  20 v_mfma_f32_16x16x32   K^T (transpose reads) x dS^T(j-1)                   || M(j): dS^T = P dP', cvt_pk, v_permlane16_swap -> the x / y operands of dQ(j)
+// S and the packed dS are double-buffered.  Fragments: two sets of five quads, a block's set is loaded in the shadow of the block before it and waited for
+// ONCE (lgkmcnt(0): nothing else is in flight at a block boundary) - three waits per step.  Ring: {K tile, V tile} x 5 stages (120 KiB, one workgroup
+// per CU); tile t+3 is fetched behind the ONE barrier of tile t (in front of the dQ block of its first step, the first reads of tile t+1 behind it),
+// counted vmcnt(6): tile t+2 stays in flight.  Dense keys in whole 64-key tiles; everything else runs attn_bwd_dq2_kernel / the keys-resident kernel.
+#ifndef PXA_ATTN_DQ4_DEFAULT
+#define PXA_ATTN_DQ4_DEFAULT 1
+#endif
+constexpr int DQ4_STAGES = 5;
+__global__ __launch_bounds__(256, 1) void attn_bwd_dq4_kernel(AttnParams p) {
+  constexpr int STG = 2 * TILE_B;
+  __shared__ __attribute__((aligned(16))) char smem[DQ4_STAGES * STG];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), hi = lane >> 5;
+  int bx, h, b;
+  block_coords(p, bx, h, b);
+  const bf16_t* Kp = p.K + (long)b * p.k_bs + (long)h * p.k_hs;
+  const bf16_t* Vp = p.V + (long)b * p.v_bs + (long)h * p.v_hs;
+  const int kts = (int)p.k_ts, vts = (int)p.v_ts;
+  const int T = p.Nk / BKV;                                        // full 64-key tiles (checked by the launcher), >= 1
+  const float c = p.scale_log2;
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+  // stationary operands: Q / dO rows of this wave's 2 x 32 queries (B operands: lane = query), delta in slots 72..74 of the dO rows (split3)
+  int q[2];
+  bool qvalid[2];
+  float lse[2];
+  bf16x8 qf[2][KSTEPS], dof[2][KSTEPS];
+#pragma unroll
+  for (int qb = 0; qb < 2; qb++) {
+    q[qb] = bx * 256 + wave * 64 + qb * 32 + (lane & 31);
+    qvalid[qb] = q[qb] < p.Nq;
+    load_row_frags(qf[qb], p.Q + (long)b * p.q_bs + (long)q[qb] * p.q_ts + (long)h * p.q_hs, qvalid[qb], hi);
+    load_row_frags(dof[qb], p.dO + (long)b * p.o_bs + (long)q[qb] * p.o_ts + (long)h * p.o_hs, qvalid[qb], hi);
+    settle(qf[qb]);
+    settle(dof[qb]);
+    const long sidx = ((long)b * p.H + h) * p.Nq + q[qb];
+    lse[qb] = qvalid[qb] ? p.LSE[sidx] : 0.f;
+    const float delta = qvalid[qb] ? p.Delta[sidx] : 0.f;
+    if (hi == 1) {
+      u32x4 w = __builtin_bit_cast(u32x4, dof[qb][KSTEPS - 1]);
+      const uint2 d3 = split3(delta);
+      w[0] = d3.x; w[1] = d3.y;
+      dof[qb][KSTEPS - 1] = __builtin_bit_cast(bf16x8, w);
+    }
+#pragma unroll
+    for (int ks = 0; ks < KSTEPS; ks++) { to_agpr(qf[qb][ks]); to_agpr(dof[qb][ks]); }
+  }
+
+  // LDS-DMA plan (saddr form; K and V piece i share their lane mask); running source pointers, clamped to the last tile
+  DmaPlan pl;
+  dma_plan(pl, wave, lane);
+  unsigned offK[NDMA], offV[NDMA];
+  unsigned long long dmask[NDMA];
+#pragma unroll
+  for (int i = 0; i < NDMA; i++) {
+    offK[i] = (unsigned)(pl.row[i] * kts + pl.coff[i]) * 2u;
+    offV[i] = (unsigned)(pl.row[i] * vts + pl.coff[i]) * 2u;
+    dmask[i] = __builtin_amdgcn_ballot_w64(pl.coff[i] >= 0);
+  }
+  const unsigned lds0 = (unsigned)(uintptr_t)LDS_PTR(char, smem);
+  const unsigned wbase = __builtin_amdgcn_readfirstlane(wave * 1024);
+  const long kstep = (long)BKV * kts, vstep = (long)BKV * vts;
+  const bf16_t* knext = Kp;
+  const bf16_t* vnext = Vp;
+  int tfetch = 0;
+  auto issue_part = [&](auto pc, unsigned sb) {
+    constexpr int P = decltype(pc)::value;
+    dma_pair<P * 4096, TILE_B + P * 4096>(dmask[P], wbase + sb, offK[P], knext, offV[P], vnext);
+  };
+  auto advance = [&]() {
+    const bool more = tfetch + 1 < T;
+    knext += more ? kstep : 0; vnext += more ? vstep : 0;
+    tfetch++;
+  };
+  auto issue = [&](unsigned sb) { issue_part(IntC<0>{}, sb); issue_part(IntC<1>{}, sb); issue_part(IntC<2>{}, sb); advance(); };
+
+  FragAddr fa;
+  frag_addr(fa, lane);
+  Tr16Addr ta;
+  tr16_addr(ta, lane);
+  struct Bases { unsigned r0, r1, t00, t01, t10, t11; };
+  auto bases = [&](unsigned st) -> Bases { return Bases{st + (unsigned)fa.rb[0], st + (unsigned)fa.rb[1], st + (unsigned)ta.tb[0][0], st + (unsigned)ta.tb[0][1],
+                                                        st + (unsigned)ta.tb[1][0], st + (unsigned)ta.tb[1][1]}; };
+  for (int st = 0; st < 2 * DQ4_STAGES; st++) init_pads(smem + st * TILE_B, (st & 1) ? 2 : 0, tid);   // odd tiles = V: -1.0 in slots 72 .. 74
+
+  Acc16 dq[2];
+#pragma unroll
+  for (int qb = 0; qb < 2; qb++) {
+    zero16(dq[qb]);
+#pragma unroll
+    for (int t = 0; t < NT16; t++) { to_agpr(dq[qb].v[t][0]); to_agpr(dq[qb].v[t][1]); }
+  }
+  f32x16 S[2][2], DP[2];                                           // S[buffer][qb] (S^T(j) in buffer j & 1; E(j) leaves P there), DP[qb]
+  u32x4 dxu[2][2], dyu[2][2];                                      // [buffer][qb]: dS^T(j) packed in buffer j & 1 - the x / y operands of dQ(j), run one step later
+  bf16x8 fs[2][5];                                                 // fragment sets
+#pragma unroll
+  for (int qb = 0; qb < 2; qb++)
+#pragma unroll
+    for (int w = 0; w < 4; w++) { dxu[1][qb][w] = 0u; dyu[1][qb][w] = 0u; }     // "dS^T(-1)" = 0 for the first step's dQ block
+
+  // fragment loads.  K rows of sub-tile SUBR of the stage behind b: row fragment ks; V rows likewise (+ TILE_B); K^T: output tile tt (16 head dims)
+  auto rd_krow = [&](auto subc, auto kc, bf16x8& d, const Bases& bs) {
+    constexpr int sub = decltype(subc)::value, ks = decltype(kc)::value;
+    lds_row_asm<sub * 32 * ROWB + (ks >> 1) * 64>(d, (ks & 1) ? bs.r1 : bs.r0);
+  };
+  auto rd_vrow = [&](auto subc, auto kc, bf16x8& d, const Bases& bs) {
+    constexpr int sub = decltype(subc)::value, ks = decltype(kc)::value;
+    lds_row_asm<TILE_B + sub * 32 * ROWB + (ks >> 1) * 64>(d, (ks & 1) ? bs.r1 : bs.r0);
+  };
+  auto rd_ktr = [&](auto subc, auto tc, bf16x8& d, const Bases& bs) {
+    constexpr int sub = decltype(subc)::value, tt = decltype(tc)::value;
+    lds_tr_asm<sub * 32 * ROWB + (tt >> 1) * 64>(d, (tt & 1) ? bs.t01 : bs.t00, (tt & 1) ? bs.t11 : bs.t10);
+  };
+  auto wait_set = [&](bf16x8 (&d)[5]) { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(d[0]), "+v"(d[1]), "+v"(d[2]), "+v"(d[3]), "+v"(d[4])); };
+
+  // ---- prologue: tiles 0, 1, 2 in flight; S^T(0) cold; the first step's K rows (0, sub 1) into set 0
+  issue(lds0);
+  issue(lds0 + STG);
+  issue(lds0 + 2 * STG);
+  lds_dma_wait<12>();
+  __syncthreads();
+  {
+    const Bases cb0 = bases(lds0);
+    static_for<5>([&](auto kc) { rd_krow(IntC<0>{}, kc, fs[0][decltype(kc)::value], cb0); });
+    wait_set(fs[0]);
+#pragma unroll
+    for (int qb = 0; qb < 2; qb++) {
+      mfma32_va_first(S[0][qb], fs[0][0], qf[qb][0]);
+      mfma32_va(S[0][qb], fs[0][1], qf[qb][1]);
+      mfma32_va(S[0][qb], fs[0][2], qf[qb][2]);
+      mfma32_va(S[0][qb], fs[0][3], qf[qb][3]);
+      mfma32_va(S[0][qb], fs[0][4], qf[qb][4]);
+    }
+    mfma_drain();
+    static_for<5>([&](auto kc) { rd_krow(IntC<1>{}, kc, fs[0][decltype(kc)::value], cb0); });
+  }
+
+  // ---- one step = one 32-key sub-tile j (tile t, sub SUB).  Fragment sets: the S block uses set SUB, the dP block set SUB ^ 1, the dQ block set SUB.
+  // cb: this tile's stage, nb: the next tile's, pb_: the stage of sub-tile j-1 (this tile for SUB = 1, the previous one for SUB = 0).
+  int t = 0;
+  auto step = [&](auto subc, const Bases& cb, const Bases& nb, const Bases& pbs, unsigned fst) {
+    constexpr int SUB = decltype(subc)::value, CUR = SUB, NXT = SUB ^ 1, SA = SUB, SB = SUB ^ 1;
+    // E(j): elements e = 0..31 (qb = e >> 4, g = e & 15): gap ge: fma of the elements of gap ge, exp2 of those of gap ge - 1 (gaps 0..20)
+    auto e_fma = [&](auto gc) {
+      constexpr int ge = decltype(gc)::value;
+      if constexpr (ge >= 0 && ge < 20) {
+        constexpr int e0 = (32 * ge) / 20, e1 = (32 * (ge + 1)) / 20;
+        static_for<e1 - e0>([&](auto ec) {
+          constexpr int e = e0 + decltype(ec)::value, qb = e >> 4, g = e & 15;
+          S[CUR][qb][g] = fmaf(S[CUR][qb][g], c, -lse[qb]);
+          asm volatile("" : "+v"(S[CUR][qb][g]));
+        });
+      }
+    };
+    auto e_exp = [&](auto gc) {
+      constexpr int ge = decltype(gc)::value;
+      if constexpr (ge >= 0 && ge < 20) {
+        constexpr int e0 = (32 * ge) / 20, e1 = (32 * (ge + 1)) / 20;
+        static_for<e1 - e0>([&](auto ec) {
+          constexpr int e = e0 + decltype(ec)::value, qb = e >> 4, g = e & 15;
+          S[CUR][qb][g] = __builtin_amdgcn_exp2f(S[CUR][qb][g]);
+          asm volatile("" : "+v"(S[CUR][qb][g]));
+        });
+      }
+    };
+    // M(j) over the 20 gaps of the dQ block: dS of the element pair gm (two scores) one gap behind, its cvt_pk two gaps behind that; the lane swaps of a
+    // query block when its eight words are packed.  pack_xy's layout: ua = rows {0-3, 16-19} + 4 hi, ub = rows {8-11, 24-27} + 4 hi.
+    auto m_mul = [&](auto gc) {
+      constexpr int gm = decltype(gc)::value;
+      if constexpr (gm >= 0 && gm < 16) {
+        static_for<2>([&](auto ec) {
+          constexpr int e = 2 * gm + decltype(ec)::value, qb = e >> 4, g = e & 15;
+          DP[qb][g] *= S[CUR][qb][g];
+          asm volatile("" : "+v"(DP[qb][g]));
+        });
+      }
+    };
+    auto m_cvt = [&](auto gc) {                                    // the pair (2 gm, 2 gm + 1) -> one word of ua (-> dxu) or ub (-> dyu)
+      constexpr int gm = decltype(gc)::value;
+      if constexpr (gm >= 0 && gm < 16) {
+        constexpr int qb = gm >> 3, pr = gm & 7, g = 2 * pr;       // pairs in score order: g = 0, 2, .., 14
+        constexpr bool isb = (g & 4) != 0;                         // g 0-3 -> ua[0..1], 4-7 -> ub[0..1], 8-11 -> ua[2..3], 12-15 -> ub[2..3]
+        constexpr int w = (g >> 3) * 2 + ((g & 3) >> 1);
+        unsigned v = pack_bf16x2(DP[qb][g], DP[qb][g + 1]);
+        asm volatile("" : "+v"(v));
+        if constexpr (isb) dyu[CUR][qb][w] = v; else dxu[CUR][qb][w] = v;
+      }
+    };
+    auto m_swap = [&](auto gc) {                                   // gaps 12, 13 (qb 0: its words are packed by gap 10), gap 19 (qb 1: by gap 18)
+      constexpr int gm = decltype(gc)::value;
+      if constexpr (gm == 12 || gm == 13 || gm == 19) {
+        constexpr int qb = gm == 19, w0 = gm == 13 ? 2 : 0, nw = gm == 19 ? 4 : 2;
+        static_for<nw>([&](auto wc) {
+          constexpr int w = w0 + decltype(wc)::value;
+          const auto r = __builtin_amdgcn_permlane16_swap(dxu[CUR][qb][w], dyu[CUR][qb][w], false, false);
+          dxu[CUR][qb][w] = r[0]; dyu[CUR][qb][w] = r[1];
+          asm volatile("" : "+v"(dxu[CUR][qb][w]), "+v"(dyu[CUR][qb][w]));
+        });
+      }
+    };
+    // ---- S block: S^T(j+1) = K rows (set SA) x Q^T; loads the V rows of sub-tile j into set SB
+    wait_set(fs[SA]);
+    static_for<10>([&](auto gc) {
+      constexpr int g = decltype(gc)::value, ks = g >> 1, qb = g & 1;
+      if constexpr (ks == 0) mfma32_va_first(S[NXT][qb], fs[SA][0], qf[qb][0]); else mfma32_va(S[NXT][qb], fs[SA][ks], qf[qb][ks]);
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (qb == 1) rd_vrow(subc, IntC<ks>{}, fs[SB][ks], cb);
+      e_fma(gc);                                                   // (the fma first: the exp2 of the previous gap's elements then sits two instructions behind
+      e_exp(IntC<g - 1>{});                                        //  its own fma - directly behind the MFMA it drew a wait state, 36 per tile)
+      __builtin_amdgcn_sched_barrier(0);
+    });
+    // ---- dP block: dP^T(j) = V rows (set SB) x dO^T; loads the K^T fragments of sub-tile j-1 into set SA
+    wait_set(fs[SB]);
+    static_for<10>([&](auto gc) {
+      constexpr int g = decltype(gc)::value, ks = g >> 1, qb = g & 1;
+      if constexpr (ks == 0) mfma32_va_first(DP[qb], fs[SB][0], dof[qb][0]); else mfma32_va(DP[qb], fs[SB][ks], dof[qb][ks]);
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (qb == 1) rd_ktr(IntC<SUB ^ 1>{}, IntC<ks>{}, fs[SA][ks], pbs);
+      e_fma(IntC<10 + g>{});
+      e_exp(IntC<10 + g - 1>{});
+      __builtin_amdgcn_sched_barrier(0);
+    });
+    // ---- dQ block: dQ^T += K^T (set SA) x dS^T(j-1) (buffer NXT); loads the K rows of sub-tile j+2 into set SB; M(j) in its gaps
+    if constexpr (SUB == 0) {                                      // the tile's barrier: tile t+1 has landed (this wave's pieces; t+2 may stay in flight) and is
+      lds_dma_wait<6>();                                           // visible; every wave is past the dQ block of tile t-2's last sub-tile: its stage takes t+3
+      __syncthreads();
+      issue_part(IntC<0>{}, fst);
+    }
+    wait_set(fs[SA]);
+    static_for<20>([&](auto gc) {
+      constexpr int g = decltype(gc)::value, tt = g >> 2, qb = (g >> 1) & 1, half = g & 1;
+      mfma16_acc(dq[qb].v[tt][half], fs[SA][tt], __builtin_bit_cast(bf16x8, half ? dyu[NXT][qb] : dxu[NXT][qb]));
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr ((g & 3) == 3) {                                // K rows of sub-tile j+2: SUB = 0 -> (t+1, sub 0), SUB = 1 -> (t+1, sub 1)
+        rd_krow(subc, IntC<tt>{}, fs[SB][tt], nb);
+      }
+      if constexpr (g == 0) e_exp(IntC<19>{});
+      m_swap(gc);                                                  // (dS of pair gm: multiply in gap gm + 1 - the dP MFMAs' results need their distance -,
+      m_cvt(IntC<g - 3>{});                                        //  cvt_pk in gap gm + 3)
+      m_mul(IntC<g - 1>{});
+      if constexpr (SUB == 0 && g == 4) issue_part(IntC<1>{}, fst);
+      if constexpr (SUB == 0 && g == 8) { issue_part(IntC<2>{}, fst); advance(); }
+      __builtin_amdgcn_sched_barrier(0);
+    });
+  };
+
+  // stage rotation by additions: cur (tile t), nx (t+1), pv (t-1; tile 0 itself at t = 0, against dS^T(-1) = 0), fst (the stage of tile t+3 = of t-2)
+  const unsigned ring_end = lds0 + DQ4_STAGES * STG;
+  unsigned cur = lds0, nx = lds0 + STG, fst = lds0 + 3 * STG;
+  Bases cb = bases(cur), pbs = cb;
+  for (t = 0; t < T; t++) {
+    const Bases nb = bases(nx);
+    step(IntC<0>{}, cb, nb, pbs, fst);
+    step(IntC<1>{}, cb, nb, cb, fst);
+    pbs = cb;
+    cb = nb;
+    cur = nx;
+    nx = nx + STG == ring_end ? lds0 : nx + STG;
+    fst = fst + STG == ring_end ? lds0 : fst + STG;
+  }
+  // drain: dQ^T += K^T x dS^T of the last sub-tile (tile T-1, sub 1; buffer 1); the look-ahead K rows in set 0 are dropped
+  {
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fs[0][0]), "+v"(fs[0][1]), "+v"(fs[0][2]), "+v"(fs[0][3]), "+v"(fs[0][4]));
+    static_for<5>([&](auto tc) { rd_ktr(IntC<1>{}, tc, fs[1][decltype(tc)::value], pbs); });
+    wait_set(fs[1]);
+    static_for<20>([&](auto gc) {
+      constexpr int g = decltype(gc)::value, tt = g >> 2, qb = (g >> 1) & 1, half = g & 1;
+      mfma16_acc(dq[qb].v[tt][half], fs[1][tt], __builtin_bit_cast(bf16x8, half ? dyu[1][qb] : dxu[1][qb]));
+    });
+  }
+  lds_dma_wait<0>();                                               // the clamped re-fetches must not land in a later workgroup's LDS
+  mfma_drain();
+#pragma unroll
+  for (int qb = 0; qb < 2; qb++) {
+    const int q0w = bx * 256 + wave * 64 + qb * 32;
+    const bool ok0 = q0w + (lane & 15) < p.Nq, ok1 = q0w + 16 + (lane & 15) < p.Nq;
+    store_rows16(p.dQ + (long)b * p.dq_bs + (long)q0w * p.dq_ts + (long)h * p.dq_hs, p.dq_ts, dq[qb], p.scale, p.scale, ok0, ok1, lane);
+    if (p.dq_colsum) colsum_rows16(p.dq_colsum + (b % PXA_COLSUM_SLOTS) * p.colsum_stride + h * DH, dq[qb], p.scale, ok0, ok1, lane);
+  }
+}
+
 int fill(AttnParams& p, const pxa_attn_args* a) {
   PXA_CHECK(a, "attn: null args");
   PXA_CHECK(a->head_dim == DH, "attn: head_dim %d unsupported (PixArt XL/2 uses 72)", a->head_dim);
@@ -2841,8 +3129,15 @@ extern "C" int pxa_attn_bwd(const pxa_attn_args* a, hipStream_t stream) {
     p.nx = (p.Nq + 127) / 128;
     PXA_CHECK((long)p.nx * p.H * p.B < (1L << 31), "pxa_attn_bwd: grid too large");
     const char* dqe = getenv("PXA_ATTN_DQ");                // 0 = round-2 kernel (compiler-scheduled), 1 = hand-placed pipeline (needs the delta fold)
-    const int dq_mode = (dqe ? atoi(dqe) : PXA_ATTN_DQ_DEFAULT) && ATTN_FOLD_DELTA;
-    if (dq_mode) hipLaunchKernelGGL(attn_bwd_dq2_kernel, dim3(p.nx * p.H * p.B), dim3(256), 0, stream, p);
+    int dq_mode = ATTN_FOLD_DELTA ? (dqe ? atoi(dqe) : PXA_ATTN_DQ_DEFAULT) : 0;
+    // 4 = one wave per SIMD, 64 queries per wave (dense keys in whole 64-key tiles); PXA_ATTN_DQ=4 asks for it, the default takes it where it applies
+    const bool dq4_ok = ATTN_FOLD_DELTA && !p.kv_start && p.Nk % BKV == 0 && p.Nk >= 2 * BKV && p.Nq >= 256;
+    if (dq_mode == 4 && !dq4_ok) dq_mode = 1;
+    if (!dqe && dq_mode == 1 && PXA_ATTN_DQ4_DEFAULT && dq4_ok) dq_mode = 4;
+    if (dq_mode == 4) {
+      p.nx = (p.Nq + 255) / 256;
+      hipLaunchKernelGGL(attn_bwd_dq4_kernel, dim3(p.nx * p.H * p.B), dim3(256), 0, stream, p);
+    } else if (dq_mode) hipLaunchKernelGGL(attn_bwd_dq2_kernel, dim3(p.nx * p.H * p.B), dim3(256), 0, stream, p);
     else hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3(p.nx * p.H * p.B), dim3(256), 0, stream, p);
     PXA_LAUNCH_CHECK();
   }

@@ -31,10 +31,11 @@ def asm(tmp_path_factory):
     return out
 
 
-@pytest.mark.parametrize("kernel,tag", [("attn_bwd_dkv2_kernelILi1E", "bf16"), ("attn_bwd_dq2_kernel", "bf16"), ("attn_fwd4_kernel", "bf16"), ("attn_fwd4_kernel", "f16")])
+@pytest.mark.parametrize("kernel,tag", [("attn_bwd_dkv2_kernelILi1E", "bf16"), ("attn_bwd_dq2_kernel", "bf16"), ("attn_fwd4_kernel", "bf16"), ("attn_fwd4_kernel", "f16"),
+                                        ("attn_bwd_dkv4_kernel", "bf16"), ("attn_bwd_dkv4_kernel", "f16"), ("attn_bwd_dq4_kernel", "bf16"), ("attn_bwd_dq4_kernel", "f16")])
 def test_hand_counted_lds_waits(asm, kernel, tag):
     import check_lds_waits as C
-    r = C.check(asm[("attn.hip", tag)], kernel, inflight_at_back_edge="fwd4" in kernel)
+    r = C.check(asm[("attn.hip", tag)], kernel, inflight_at_back_edge=kernel.endswith("4_kernel"))
     assert not r["errors"], r["errors"][:5]
     assert r["reads"] > 0 and r["waits"] > 0 and r["mfma"] > 0
 
@@ -72,6 +73,24 @@ def test_fwd4_register_ownership(asm, tag):
         assert not any("accvgpr" in o for o in ops), "register-file traffic on the hot path"
         assert sum(o.startswith("v_mfma_f32_32x32x16") for o in ops) == 20 and sum(o.startswith("v_mfma_f32_16x16x32") for o in ops) == 40
         assert sum(o.startswith("global_load_lds") for o in ops) == 6 and sum(o == "s_barrier" for o in ops) == 1
+
+
+@pytest.mark.parametrize("kernel,n32,n16", [("attn_bwd_dkv4_kernel", 88, 0), ("attn_bwd_dq4_kernel", 40, 40)])
+@pytest.mark.parametrize("tag", ["bf16", "f16"])
+def test_one_wave_backward_kernels_keep_the_tile_loop_clean(asm, kernel, n32, n16, tag):
+    """The round-4 backward kernels: no scratch, and per 64-row tile of the loop exactly the contracted MFMAs, ONE barrier, no register-file traffic."""
+    text = asm[("attn.hip", tag)]
+    name = re.search(r"^(_Z\w*" + kernel + r"\w*):", text, re.M).group(1)
+    body = text[text.index("\n" + name + ":"):]
+    body = body[:body.index(".Lfunc_end")]
+    assert "scratch_" not in body
+    lines = body.split("\n")
+    h = max(i for i, l in enumerate(lines) if "Loop Header" in l)
+    end = next(i for i in range(h + 1, len(lines)) if re.match(r"^\.LBB", lines[i]))
+    ops = [l.split()[0] for l in lines[h:end] if re.match(r"\s+[a-z]", l)]
+    assert not any("accvgpr" in o for o in ops)
+    assert sum(o.startswith("v_mfma_f32_32x32x16") for o in ops) == n32 and sum(o.startswith("v_mfma_f32_16x16x32") for o in ops) == n16
+    assert sum(o == "s_barrier" for o in ops) == 1
 
 
 def test_m0_has_no_other_user(asm):

@@ -77,6 +77,72 @@ def check():
     return bad
 
 
+def check_dq():
+    """attn_bwd_dq4_kernel (PXA_ATTN_DQ=4) against attn_bwd_dq2_kernel (=1) and fp32 attention gradients"""
+    bad = 0
+    g = torch.Generator(device=dev).manual_seed(1)
+    tol = 1e-3 if OPD == torch.float16 else 8e-3
+    for B, H, Nq, Nk, sc in [(1, 2, 256, 128, 1.0), (2, 3, 300, 192, 1.0), (1, 2, 1024, 256, 1.0), (2, 16, 1024, 1024, 1.0), (1, 4, 512, 4096, 2.0), (1, 16, 4096, 320, 1.0)]:
+        C = H * 72
+        q = (torch.randn(B, Nq, C, device=dev, generator=g) * sc).to(OPD)
+        k = (torch.randn(B, Nk, C, device=dev, generator=g) * sc).to(OPD)
+        v, do = (torch.randn(B, n, C, device=dev, generator=g).to(OPD) for n in (Nk, Nq))
+        o = torch.empty(B, Nq, C, dtype=OPD, device=dev)
+        lse, delta = torch.empty(B, H, Nq, device=dev), torch.empty(B, H, Nq, device=dev)
+        sq, sk = (Nq * C, C, 72), (Nk * C, C, 72)
+        ops.attention_fwd(q, k, v, o, lse, B, H, Nq, Nk, (sq, sk, sk, sq))
+        res = {}
+        for mode in ("4", "1"):
+            os.environ["PXA_ATTN_DQ"] = mode
+            dq = torch.full_like(q, float("nan"))
+            ops.attention_bwd(q, k, v, o, do, lse, delta, dq, None, None, B, H, Nq, Nk, (sq, sk, sk, sq), (sq, sk, sk))
+            torch.cuda.synchronize()
+            res[mode] = dq
+        del os.environ["PXA_ATTN_DQ"]
+        qf, kf, vf = (t.float().view(B, -1, H, 72).transpose(1, 2).requires_grad_(True) for t in (q, k, v))
+        s = (qf @ kf.transpose(-1, -2)) * 72 ** -0.5
+        (s.softmax(-1) @ vf).backward(do.float().view(B, Nq, H, 72).transpose(1, 2))
+        rq = qf.grad.transpose(1, 2).reshape(B, Nq, C)
+        e4, e1, e41 = rel(res["4"].float(), rq), rel(res["1"].float(), rq), rel(res["4"].float(), res["1"].float())
+        ok = e4 < max(tol, 1.2 * e1) and torch.isfinite(res["4"].float()).all().item()
+        bad += not ok
+        print(f"dQ B{B} H{H} Nq{Nq} Nk{Nk} x{sc}: dq4 {e4:.2e} dq2 {e1:.2e} dq4 vs dq2 {e41:.2e}" + ("  ok" if ok else "  FAIL"), flush=True)
+    return bad
+
+
+def time_dq():
+    B, H, N, D = 16, 16, 4096, 1152
+    R = B * N
+    qkv = torch.randn(R, 3 * D, device=dev).to(OPD)
+    a = torch.empty(R, D, dtype=OPD, device=dev)
+    lse, delta = torch.empty(B, H, N, device=dev), torch.empty(B, H, N, device=dev)
+    s3 = (N * 3 * D, 3 * D, 72)
+    st = (s3, s3, s3, (N * D, D, 72))
+    q, k, v = qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:]
+    ops.attention_fwd(q, k, v, a, lse, B, H, N, N, st)
+    da, dqkv = torch.randn(R, D, device=dev).to(OPD), torch.empty_like(qkv)
+    ops.attention_bwd(q, k, v, a, da, lse, delta, dqkv[:, :D], dqkv[:, D:2 * D], dqkv[:, 2 * D:], B, H, N, N, st, (s3, s3, s3))
+    fl = 6.0 * B * H * N * N * 72
+    os.environ["PXA_ATTN_BWD_NO_PREPASS"] = "1"
+    outs = {}
+    for mode in ("1", "4", "1", "4"):
+        os.environ["PXA_ATTN_DQ"] = mode
+        fn = lambda: ops.attention_bwd(q, k, v, a, da, lse, delta, dqkv[:, :D], None, None, B, H, N, N, st, (s3, s3, s3))
+        for _ in range(10):
+            fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(60):
+            fn()
+        e1.record()
+        e1.synchronize()
+        t = e0.elapsed_time(e1) / 60 * 1e-3
+        outs[mode] = dqkv[:, :D].clone()
+        print(f"dQ kernel alone B16 H16 N4096 PXA_ATTN_DQ={mode} lib={os.environ.get('PXA_LIB_PATH', 'default')}: {t * 1e3:7.3f} ms {fl / t / 1e12:7.1f} TF/s", flush=True)
+    print(f"full grid B16: dq4 vs dq2 rel-L2 {rel(outs['4'].float(), outs['1'].float()):.2e}, finite {torch.isfinite(outs['4'].float()).all().item()}", flush=True)
+    del os.environ["PXA_ATTN_BWD_NO_PREPASS"], os.environ["PXA_ATTN_DQ"]
+
+
 def timeit():
     B, H, N, D = 16, 16, 4096, 1152
     R = B * N
@@ -114,4 +180,7 @@ if __name__ == "__main__":
         rc = check()
     if what in ("time", "all"):
         timeit()
+    if what in ("dq",):
+        rc = check_dq()
+        time_dq()
     sys.exit(1 if rc else 0)
