@@ -17,6 +17,8 @@
 // from the saved log2-sum-exp.  Grids are flat and keep the blocks of a head on one XCD (block_coords).
 #include "common.h"
 #include "../../include/pixart_hip.h"
+#include <map>
+#include <mutex>
 #include <utility>
 
 namespace {
@@ -2425,6 +2427,9 @@ template <int W = -1> __device__ __forceinline__ void mfma32_acc(f32x16& d, cons
 #ifndef PXA_ATTN_DKV4_DEFAULT
 #define PXA_ATTN_DKV4_DEFAULT 1
 #endif
+#ifndef DKV4_ABL
+#define DKV4_ABL 0          // ablation builds (wrong results, timing only): 1 no exp2, 2 no cvt_pk, 4 no multiplies, 8 no LDS fragment reads, 16 no LDS-DMA, 32 no MFMAs
+#endif
 constexpr int DKV4_STAGES = 4;
 constexpr int dkv4_nreads(int i) { const int k = ((i % 22) + 22) % 22; return k < 10 ? 1 : 2; }   // fragment i of a step: 10 row fragments, 12 transposed ones
 __global__ __launch_bounds__(256, 1) void attn_bwd_dkv4_kernel(AttnParams p) {
@@ -2606,7 +2611,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv4_kernel(AttnParams p) {
         static_for<p1 - p0>([&](auto ec) {
           constexpr int e = p0 + decltype(ec)::value, kb = e >> 4, g = e & 15;
           if constexpr (g & 1) {
-            unsigned w = pack_bf16x2(S[CUR][kb][g - 1], S[CUR][kb][g]);
+            unsigned w = (DKV4_ABL & 2) ? __builtin_bit_cast(unsigned, S[CUR][kb][g]) : pack_bf16x2(S[CUR][kb][g - 1], S[CUR][kb][g]);
             asm volatile("" : "+v"(w));
             u32x4 ww = __builtin_bit_cast(u32x4, pb[kb][g >> 3]);
             ww[(g & 7) >> 1] = w;
@@ -2622,7 +2627,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv4_kernel(AttnParams p) {
         static_for<p1 - p0>([&](auto ec) {
           constexpr int e = p0 + decltype(ec)::value, kb = e >> 4, g = e & 15;
           if constexpr (g & 1) {
-            unsigned w = pack_bf16x2(dP[kb][g - 1], dP[kb][g]);
+            unsigned w = (DKV4_ABL & 2) ? __builtin_bit_cast(unsigned, dP[kb][g]) : pack_bf16x2(dP[kb][g - 1], dP[kb][g]);
             asm volatile("" : "+v"(w));
             u32x4 ww = __builtin_bit_cast(u32x4, db[kb][g >> 3]);
             ww[(g & 7) >> 1] = w;
@@ -2639,27 +2644,28 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv4_kernel(AttnParams p) {
         constexpr int e0 = (32 * gi) / 20, e1 = (32 * (gi + 1)) / 20;
         static_for<e1 - e0>([&](auto ec) {
           constexpr int e = e0 + decltype(ec)::value;
-          S[CUR][e >> 4][e & 15] = __builtin_amdgcn_exp2f(S[CUR][e >> 4][e & 15]);
+          if (!(DKV4_ABL & 1)) S[CUR][e >> 4][e & 15] = __builtin_amdgcn_exp2f(S[CUR][e >> 4][e & 15]);
           asm volatile("" : "+v"(S[CUR][e >> 4][e & 15]));
         });
       } else if constexpr (gi < 32) {
         constexpr int e0 = (32 * (gi - 20)) / 12, e1 = (32 * (gi - 19)) / 12;
         static_for<e1 - e0>([&](auto ec) {
           constexpr int e = e0 + decltype(ec)::value;
-          dP[e >> 4][e & 15] *= S[CUR][e >> 4][e & 15];
+          if (!(DKV4_ABL & 4)) dP[e >> 4][e & 15] *= S[CUR][e >> 4][e & 15];
           asm volatile("" : "+v"(dP[e >> 4][e & 15]));
         });
       } else {
         constexpr int e0 = (32 * (gi - 32)) / 12, e1 = (32 * (gi - 31)) / 12;
         static_for<e1 - e0>([&](auto ec) {
           constexpr int e = e0 + decltype(ec)::value;
-          S[NXT][e >> 4][e & 15] *= c;
+          if (!(DKV4_ABL & 4)) S[NXT][e >> 4][e & 15] *= c;
           asm volatile("" : "+v"(S[NXT][e >> 4][e & 15]));
         });
       }
     };
     auto mma = [&](auto ic, auto kbc, auto wc) {                   // MFMA of fragment i for key block kb; W >= 0: behind the counted wait
       constexpr int i = decltype(ic)::value, kb = decltype(kbc)::value, W = decltype(wc)::value, q = (i + 2 * SUB) & 3;
+      if constexpr (DKV4_ABL & 32) { if constexpr (W >= 0) lds_wait<(W >= 0 ? W : 0)>(f[q]); return; }
       if constexpr (i < 5) { if constexpr (i == 0) mfma32_vv_first<W>(S[NXT][kb], f[q], kf[kb][0]); else mfma32_vv<W>(S[NXT][kb], f[q], kf[kb][i]); }
       else if constexpr (i < 10) { if constexpr (i == 5) mfma32_va_first<W>(dP[kb], f[q], vf[kb][0]); else mfma32_va<W>(dP[kb], f[q], vf[kb][i - 5]); }
       else if constexpr (i < 16) mfma32_acc<W>(dv[kb][(i - 10) % 3], f[q], pb[kb][(i - 10) / 3]);
@@ -2670,11 +2676,11 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv4_kernel(AttnParams p) {
       if constexpr (SUB == 0 && i == 18) {                         // the tile's barrier, in front of the first look-ahead read into tile t+1: tile t+1 has
         lds_dma_wait<7>();                                         // landed (this wave's pieces; t+2 may stay in flight) and is visible; every wave is past
         __syncthreads();                                           // tile t-1, whose stage takes tile t+3 (fetched in four parts: here, behind the step's last
-        issue_part(IntC<0>{}, fst);                                // fragment pair, and behind the first two pairs of the next step)
+        if constexpr (!(DKV4_ABL & 16)) issue_part(IntC<0>{}, fst);   // fragment pair, and behind the first two pairs of the next step)
       }
-      if constexpr (SUB == 0 && i == 20) issue_part(IntC<1>{}, fst);
-      if constexpr (SUB == 1 && i == 0) issue_part(IntC<2>{}, fst);
-      if constexpr (SUB == 1 && i == 2) { issue_part(IntC<3>{}, fst); advance(); }
+      if constexpr (SUB == 0 && i == 20 && !(DKV4_ABL & 16)) issue_part(IntC<1>{}, fst);
+      if constexpr (SUB == 1 && i == 0 && !(DKV4_ABL & 16)) issue_part(IntC<2>{}, fst);
+      if constexpr (SUB == 1 && i == 2 && !(DKV4_ABL & 16)) { issue_part(IntC<3>{}, fst); advance(); }
       // (each MFMA alone in its scheduling region: the gap's vector work then sits BEHIND it, never adjacent to the previous gap's)
       mma(IntC<i>{}, IntC<0>{}, IntC<dkv4_nreads(i + 2) + dkv4_nreads(i + 3)>{});
       __builtin_amdgcn_sched_barrier(0);
@@ -2682,7 +2688,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv4_kernel(AttnParams p) {
       __builtin_amdgcn_sched_barrier(0);
       mma(IntC<i>{}, IntC<1>{}, IntC<-1>{});
       __builtin_amdgcn_sched_barrier(0);
-      rd_frag(subc, IntC<i + 4>{}, f[(i + 2 * SUB) & 3], cb, nb);
+      if constexpr (!(DKV4_ABL & 8)) rd_frag(subc, IntC<i + 4>{}, f[(i + 2 * SUB) & 3], cb, nb);
       valu(IntC<2 * i + 1>{});
       __builtin_amdgcn_sched_barrier(0);
       mma(IntC<i + 1>{}, IntC<0>{}, IntC<-1>{});
@@ -2691,7 +2697,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv4_kernel(AttnParams p) {
       __builtin_amdgcn_sched_barrier(0);
       mma(IntC<i + 1>{}, IntC<1>{}, IntC<-1>{});
       __builtin_amdgcn_sched_barrier(0);
-      rd_frag(subc, IntC<i + 5>{}, f[(i + 1 + 2 * SUB) & 3], cb, nb);
+      if constexpr (!(DKV4_ABL & 8)) rd_frag(subc, IntC<i + 5>{}, f[(i + 1 + 2 * SUB) & 3], cb, nb);
       valu(IntC<2 * i + 3>{});
       __builtin_amdgcn_sched_barrier(0);
     });
@@ -3034,6 +3040,22 @@ int fill(AttnParams& p, const pxa_attn_args* a) {
 }
 }  // namespace
 
+// The keys-resident kernels need 120 KiB of dynamic LDS: the opt-in is per device (and per function), tried once per device under a lock; where it fails
+// the callers fall back to the streaming kernels instead of failing every call.
+static bool kvres_lds_ok(const void* fn) {
+  static std::mutex mu;
+  static std::map<std::pair<int, const void*>, bool> state;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return false;
+  std::lock_guard<std::mutex> lk(mu);
+  auto it = state.find({dev, fn});
+  if (it != state.end()) return it->second;
+  const bool ok = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, KVRES_TILES * 2 * TILE_B) == hipSuccess;
+  if (!ok) (void)hipGetLastError();
+  state[{dev, fn}] = ok;
+  return ok;
+}
+
 extern "C" int pxa_attn_fwd(const pxa_attn_args* a, hipStream_t stream) {
   AttnParams p;
   if (int rc = fill(p, a)) return rc;
@@ -3044,16 +3066,12 @@ extern "C" int pxa_attn_fwd(const pxa_attn_args* a, hipStream_t stream) {
   if (!no_kvres && !one_sub && max_k > 0 && max_k <= KVRES_TILES * BKV && p.Nq >= 512) {   // every key of a sample fits one workgroup's LDS: attn_fwd_kvres_kernel
     const int tiles = (max_k + BKV - 1) / BKV, lds = tiles * 2 * TILE_B;
     const int qpb = p.Nq >= 4096 ? 4096 : (p.Nq + 511) / 512 * 512;        // a whole head per workgroup up to 4,096 queries
-    static bool attr_set = false;
-    if (!attr_set) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_fwd_kvres_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, KVRES_TILES * 2 * TILE_B);
-      PXA_CHECK(e == hipSuccess, "pxa_attn_fwd: hipFuncSetAttribute: %s", hipGetErrorString(e));
-      attr_set = true;
+    if (kvres_lds_ok(reinterpret_cast<const void*>(attn_fwd_kvres_kernel))) {     // else (a part with less LDS): the streaming kernels below
+      p.nx = (p.Nq + qpb - 1) / qpb;
+      hipLaunchKernelGGL(attn_fwd_kvres_kernel, dim3(p.nx * p.H * p.B), dim3(512), lds, stream, p, qpb, tiles);
+      PXA_LAUNCH_CHECK();
+      return 0;
     }
-    p.nx = (p.Nq + qpb - 1) / qpb;
-    hipLaunchKernelGGL(attn_fwd_kvres_kernel, dim3(p.nx * p.H * p.B), dim3(512), lds, stream, p, qpb, tiles);
-    PXA_LAUNCH_CHECK();
-    return 0;
   }
   const bool two = !one_sub && p.Nq >= 256;
   p.nx = two ? (p.Nq + 255) / 256 : (p.Nq + 127) / 128;
@@ -3102,7 +3120,8 @@ extern "C" int pxa_attn_bwd(const pxa_attn_args* a, hipStream_t stream) {
   // cross-attention (every key of a sample fits one workgroup's LDS): the dQ kernel keeps them resident and takes over the delta / statistics pre-pass
   static const bool no_kvres = getenv("PXA_ATTN_NO_KVRES") != nullptr;
   const int max_kr = a->max_kv_len > 0 ? a->max_kv_len : p.Nk;
-  const bool dq_kvres = !no_kvres && ATTN_FOLD_DELTA && p.dQ && max_kr > 0 && max_kr <= KVRES_TILES * BKV && p.Nq >= 512;
+  const bool dq_kvres = !no_kvres && ATTN_FOLD_DELTA && p.dQ && max_kr > 0 && max_kr <= KVRES_TILES * BKV && p.Nq >= 512 &&
+                        kvres_lds_ok(reinterpret_cast<const void*>(attn_bwd_dq_kvres_kernel));
   if (no_prepass || dq_kvres) {
   } else if (p.o_hs == DH && p.o_ts == (long)p.H * DH && p.o_bs == (long)p.Nq * p.o_ts && p.H <= 16 && ((uintptr_t)p.O % 16) == 0 && ((uintptr_t)p.dO % 16) == 0) {
     const long tokens = (long)p.B * p.Nq;                  // token-contiguous rows: the coalesced form
@@ -3116,12 +3135,6 @@ extern "C" int pxa_attn_bwd(const pxa_attn_args* a, hipStream_t stream) {
   if (dq_kvres) {
     const int tiles = (max_kr + BKV - 1) / BKV, lds = tiles * 2 * TILE_B;
     const int qpb = p.Nq >= 4096 ? 4096 : (p.Nq + 255) / 256 * 256;
-    static bool attr_set = false;
-    if (!attr_set) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(attn_bwd_dq_kvres_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, KVRES_TILES * 2 * TILE_B);
-      PXA_CHECK(e == hipSuccess, "pxa_attn_bwd: hipFuncSetAttribute: %s", hipGetErrorString(e));
-      attr_set = true;
-    }
     p.nx = (p.Nq + qpb - 1) / qpb;
     hipLaunchKernelGGL(attn_bwd_dq_kvres_kernel, dim3(p.nx * p.H * p.B), dim3(512), lds, stream, p, qpb, tiles, a->delta, stats, inv_c);
     PXA_LAUNCH_CHECK();

@@ -64,7 +64,15 @@ class LRSchedule:
         return self.lr
 
     def state_dict(self):
-        return {"last_step": self.last_step, "base_lr": self.base_lr}
+        return {"last_step": self.last_step, "base_lr": self.base_lr, "steps_per_call": self.steps_per_call}
 
     def load_state_dict(self, sd):
-        self.last_step = int(sd.get("last_step", sd.get("last_epoch", 0)))     # 'last_epoch' = torch LambdaLR's name for the same counter
+        """`last_step` counts scheduler steps = steps_per_call x applied optimizer steps (the reference's `last_epoch` on a `world`-GPU job, see the module
+        header).  A checkpoint that recorded another unit - round-2 checkpoints of this repo counted optimizer steps and carry no `steps_per_call`; a job
+        resumed on a different number of GPUs - is rescaled to this run's unit, so the schedule resumes at the same point of its warm-up / decay."""
+        last = int(sd.get("last_step", sd.get("last_epoch", 0)))             # 'last_epoch' = torch LambdaLR's name for the same counter
+        if "last_step" in sd:                                                 # this repo's format: the unit is known (absent = 1, the round-2 format)
+            saved_unit = int(sd.get("steps_per_call", 1))
+            if saved_unit != self.steps_per_call:
+                last = last * self.steps_per_call // max(1, saved_unit)
+        self.last_step = last

@@ -159,8 +159,17 @@ def _attn_args(q, k, v, o, B, H, Nq, Nk, strides, kv_start=None, kv_len=None, ma
     return a
 
 
+def _check_max_kv_len(kw):
+    """The keys-resident kernels size their LDS by max_kv_len and clamp to it: a sample longer than the caller's bound would be truncated silently where
+    the streaming kernels honour kv_len.  The lengths are only known here when the caller keeps a host copy (`kv_len_host`)."""
+    lens = kw.pop("kv_len_host", None)
+    if lens is not None and kw.get("max_kv_len", 0) > 0:
+        assert max(lens) <= kw["max_kv_len"], f"max_kv_len {kw['max_kv_len']} < longest sample {max(lens)}"
+
+
 def attention_fwd(q, k, v, o, lse, B, H, Nq, Nk, strides, **kw):
     """q/k/v/o: bf16 tensors (any view); strides = ((q_bs,q_ts,q_hs),(k..),(v..),(o..)) in elements."""
+    _check_max_kv_len(kw)
     a = _attn_args(q, k, v, o, B, H, Nq, Nk, strides, **kw)
     a.lse = ptr(lse)
     call("pxa_attn_fwd", a)
@@ -172,16 +181,22 @@ _bwd_stats = {}
 
 def attn_bwd_stats(B, H, Nq, device):
     """The dK/dV kernel's lse / delta workspace (include/pixart_hip.h: pxa_attn_args.bwd_stats): written by the backward's own pre-pass and consumed
-    by its last kernel on one stream, so every call of a device shares the largest buffer asked for so far."""
+    by its last kernel on ONE stream, so the calls of a (device, stream) pair share the largest buffer asked for so far.  Keyed by the current stream
+    (two streams would overwrite each other's rows) and bypassed while a graph is being captured (a buffer first allocated during capture lives in the
+    graph's private pool and must not be handed to eager calls): there the caching allocator serves each call."""
     n = lib.load().pxa_attn_bwd_stats_bytes(B, H, Nq)
-    buf = _bwd_stats.get(device)
+    if torch.cuda.is_current_stream_capturing():
+        return torch.empty(n, dtype=torch.uint8, device=device)
+    key = (device, torch.cuda.current_stream(device).cuda_stream)
+    buf = _bwd_stats.get(key)
     if buf is None or buf.numel() < n:
-        buf = _bwd_stats[device] = torch.empty(n, dtype=torch.uint8, device=device)
+        buf = _bwd_stats[key] = torch.empty(n, dtype=torch.uint8, device=device)
     return buf
 
 
 def attention_bwd(q, k, v, o, d_o, lse, delta, dq, dk, dv, B, H, Nq, Nk, strides, dstrides, colsums=(None, None, None), **kw):
     """colsums: optional fp32 (H*72,) accumulators receiving the column sums of dq / dk / dv (bias gradients)."""
+    _check_max_kv_len(kw)
     a = _attn_args(q, k, v, o, B, H, Nq, Nk, strides, **kw)
     if dk is not None:
         a.bwd_stats = ptr(attn_bwd_stats(B, H, Nq, q.device))

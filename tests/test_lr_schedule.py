@@ -92,3 +92,26 @@ def test_cosine_decay_to_constant_rejects_ratio_below_one():
     import pytest
     with pytest.raises(AssertionError):
         LRSchedule(2e-5, "cosine_decay_to_constant", num_warmup_steps=10, num_training_steps=100, lr_scale_ratio=0.7)
+
+
+def test_state_dict_records_its_unit_and_rescales_on_load():
+    """`last_step` is in world x optimizer-step units; a checkpoint in another unit (round-2 format = optimizer steps, or another GPU count)
+    resumes at the same point of the schedule."""
+    from pixart_sigma_amd.lr_schedule import LRSchedule
+    a = LRSchedule(1e-4, "constant", num_warmup_steps=1000, steps_per_call=8)
+    for _ in range(50):
+        a.step()
+    sd = a.state_dict()
+    assert sd["last_step"] == 400 and sd["steps_per_call"] == 8
+    b = LRSchedule(1e-4, "constant", num_warmup_steps=1000, steps_per_call=8)
+    b.load_state_dict(sd)
+    assert b.last_step == 400 and b.lr == a.lr
+    c = LRSchedule(1e-4, "constant", num_warmup_steps=1000, steps_per_call=2)      # resumed on 2 GPUs: 50 optimizer steps = 100 scheduler steps there
+    c.load_state_dict(sd)
+    assert c.last_step == 100
+    d = LRSchedule(1e-4, "constant", num_warmup_steps=1000, steps_per_call=8)
+    d.load_state_dict({"last_step": 50, "base_lr": 1e-4})                           # round-2 format: optimizer steps
+    assert d.last_step == 400
+    e = LRSchedule(1e-4, "constant", num_warmup_steps=1000, steps_per_call=8)
+    e.load_state_dict({"last_epoch": 400})                                          # a reference checkpoint's LambdaLR state: already world x steps
+    assert e.last_step == 400

@@ -258,16 +258,17 @@ def main():
         opt.step()
         sched.step()
         step += 1
-        if scaler and step % cfg["log_interval"] == 0:          # accelerate does not advance the schedule on a step the GradScaler skipped; the skip count lives
-            skipped = scaler.steps_skipped                     # on the device, so the schedule is reconciled where the host syncs anyway (skips are rare)
-            sched.last_step -= world * (skipped - sched_skips_seen)
-            sched_skips_seen = skipped
+        saving = step % cfg["save_model_steps"] == 0
+        if scaler and (step % cfg["log_interval"] == 0 or saving):   # accelerate does not advance the schedule on a step the GradScaler skipped; the skip count
+            skipped = scaler.steps_skipped                     # lives on the device, so the schedule is reconciled where the host syncs anyway (skips are rare) -
+            sched.last_step -= world * (skipped - sched_skips_seen)   # and ALWAYS in front of a checkpoint: a resumed run starts its own count from the loaded
+            sched_skips_seen = skipped                         # scaler's total, so skips not yet subtracted at save time would never be
         if step % cfg["log_interval"] == 0 and rank == 0:      # host sync only here (the reference syncs every step, train.py:187)
             extra = f" loss_scale {scaler.value:g} skipped {scaler.steps_skipped}" if scaler else ""
             print(f"step {step} loss {loss.item() * accum:.4f} grad_norm {opt.last_norm.item():.4f} lr {opt.lr:.3e}{extra} "
                   f"{(time.time() - t0) / cfg['log_interval']:.3f} s/step", flush=True)
             t0 = time.time()
-        if step % cfg["save_model_steps"] == 0 and rank == 0:
+        if saving and rank == 0:
             torch.save({"state_dict": model.state_dict(), "optimizer": opt.state_dict(), "lr_scheduler": sched.state_dict(), "step": step,
                         **({"loss_scaler": scaler.state_dict()} if scaler else {})},
                        os.path.join(a.work_dir, "checkpoints", f"epoch_1_step_{step}.pth"))
