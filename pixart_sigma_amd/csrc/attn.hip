@@ -2726,6 +2726,316 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv4_kernel(AttnParams p) {
   }
 }
 
+// attn_bwd_dkv4_kernel with the SECOND products (dV^T = dO^T P, dK^T = Q^T dS: head_dim as output rows) on v_mfma_f32_16x16x32: 72 rows pad to 80 (5 tiles of 16)
+// instead of 96 (3 of 32) - 40 MFMAs of 16 cycles per sub-tile instead of 24 of 32 (640 against 768 matrix-pipe cycles; the whole step 1280 against 1408), in
+// the shape the power limit favours (common.h mfma16).  Round 2 measured this 3-7 % SLOWER in the two-wave kernel - issue-bound: the 16-cycle MFMAs left the
+// partner wave's softmax too few slots; the one-wave kernel has them (ablation r4_17: its vector and LDS work fit with room).  P and dS take pack_xy's
+// lane exchange (4 v_permlane16_swap per 32 x 32 block), the A operands are trfrag16 reads; dK^T / dV^T leave through store_rows16 (PXA_ATTN_DKV=5).
+__global__ __launch_bounds__(256, 1) void attn_bwd_dkv5_kernel(AttnParams p) {
+  __shared__ __attribute__((aligned(16))) char smem[DKV4_STAGES * STAGE_B];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), hi = lane >> 5;
+  int bx, h, b;
+  block_coords(p, bx, h, b);
+  const long kbase = (long)b * p.k_bs, vbase = (long)b * p.v_bs, dkbase = (long)b * p.dk_bs, dvbase = (long)b * p.dv_bs;
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+  // stationary operands: K / V rows of this wave's 2 x 32 keys (B operands: lane = key), -1.0 in k-slots 72..74 against the statistics rows
+  int kv[2];
+  bf16x8 kf[2][KSTEPS], vf[2][KSTEPS];
+#pragma unroll
+  for (int kb = 0; kb < 2; kb++) {
+    kv[kb] = bx * 256 + wave * 64 + kb * 32 + (lane & 31);
+    load_row_frags(kf[kb], p.K + kbase + (long)kv[kb] * p.k_ts + (long)h * p.k_hs, true, hi);
+    load_row_frags(vf[kb], p.V + vbase + (long)kv[kb] * p.v_ts + (long)h * p.v_hs, true, hi);
+    settle(kf[kb]);
+    settle(vf[kb]);
+    if (hi == 1) {
+      u32x4 w = __builtin_bit_cast(u32x4, kf[kb][KSTEPS - 1]);
+      w[0] = PXA_OPERAND_MINUS_ONE_X2; w[1] = PXA_OPERAND_MINUS_ONE_X1;
+      kf[kb][KSTEPS - 1] = __builtin_bit_cast(bf16x8, w);
+      w = __builtin_bit_cast(u32x4, vf[kb][KSTEPS - 1]);
+      w[0] = PXA_OPERAND_MINUS_ONE_X2; w[1] = PXA_OPERAND_MINUS_ONE_X1;
+      vf[kb][KSTEPS - 1] = __builtin_bit_cast(bf16x8, w);
+    }
+#pragma unroll
+    for (int ks = 0; ks < KSTEPS; ks++) to_agpr(vf[kb][ks]);
+  }
+  const bf16_t* Qp = p.Q + (long)b * p.q_bs + (long)h * p.q_hs;
+  const bf16_t* Dp = p.dO + (long)b * p.o_bs + (long)h * p.o_hs;
+  const bf16_t* Ls = p.stats + ((long)b * p.H + h) * p.Nq64 * 8;
+  const bf16_t* Ds = Ls + (long)p.B * p.H * p.Nq64 * 8;
+  const int qts = (int)p.q_ts, ots = (int)p.o_ts;
+  const int T = p.Nq / BKV;                                        // full 64-query tiles (checked by the launcher)
+  const float c = p.scale_log2;
+
+  // LDS-DMA plan (saddr form: wave-uniform tile base + per-lane byte offset; Q and dO piece i share their lane mask)
+  DmaPlan pl;
+  dma_plan(pl, wave, lane);
+  unsigned offQ[NDMA], offD[NDMA];
+  unsigned long long dmask[NDMA];
+#pragma unroll
+  for (int i = 0; i < NDMA; i++) {
+    offQ[i] = (unsigned)(pl.row[i] * qts + pl.coff[i]) * 2u;
+    offD[i] = (unsigned)(pl.row[i] * ots + pl.coff[i]) * 2u;
+    dmask[i] = __builtin_amdgcn_ballot_w64(pl.coff[i] >= 0);
+  }
+  const unsigned lds0 = (unsigned)(uintptr_t)LDS_PTR(char, smem);
+  const unsigned wbase = __builtin_amdgcn_readfirstlane(wave * 1024);          // (stage addresses are added per fetch)
+  const long qstep = (long)BKV * qts, ostep = (long)BKV * ots;
+  const unsigned stat_off = (unsigned)lane * 16u;                  // statistics rows: 64 x 16 B per tile, one piece; waves 0 / 2 fetch L, waves 1 / 3 D
+  const bf16_t* statp = (wave & 1) ? Ds : Ls;
+  const unsigned stat_dst = __builtin_amdgcn_readfirstlane((wave & 1) ? 2 * TILE_B + STAT_B : TILE_B);
+  // tile fetch, in four parts (three {Q, dO} piece pairs + the statistics piece) so that the loop can spread them over MFMA gaps; the source pointers
+  // are running ones (qnext / dnext / snext: the next tile to fetch, clamped to the last one - past it a harmless re-fetch keeps every wave's piece
+  // count, and with it the counted vmcnt, uniform)
+  const bf16_t* qnext = Qp;
+  const bf16_t* dnext = Dp;
+  const bf16_t* snext = statp;
+  auto issue_part = [&](auto pc, unsigned sb) {                    // sb = LDS byte address of the stage
+    constexpr int P = decltype(pc)::value;
+    const unsigned wb = wbase + sb, so = stat_off, sd = stat_dst + sb;
+    const bf16_t* sn = snext;
+    if constexpr (P == 0) dma_pair<0, TILE_B + STAT_B>(dmask[0], wb, offQ[0], qnext, offD[0], dnext);
+    if constexpr (P == 1) dma_pair<4096, TILE_B + STAT_B + 4096>(dmask[1], wb, offQ[1], qnext, offD[1], dnext);
+    if constexpr (P == 2) dma_pair<8192, TILE_B + STAT_B + 8192>(dmask[2], wb, offQ[2], qnext, offD[2], dnext);
+    if constexpr (P == 3) asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" :: "s"(sd), "v"(so), "s"(sn) : "memory");
+  };
+  int tfetch = 0;                                                  // tile index behind qnext / dnext / snext
+  auto advance = [&]() {
+    const bool more = tfetch + 1 < T;
+    qnext += more ? qstep : 0; dnext += more ? ostep : 0; snext += more ? (long)BKV * 8 : 0;
+    tfetch++;
+  };
+  auto issue = [&](unsigned sb) { issue_part(IntC<0>{}, sb); issue_part(IntC<1>{}, sb); issue_part(IntC<2>{}, sb); issue_part(IntC<3>{}, sb); advance(); };
+
+  // fragment addressing inside a stage: per-lane bases + instruction immediates (see attn_bwd_dkv2_kernel); `cur` = stage of tile t, `nxt` = of tile t+1
+  FragAddr fa;
+  frag_addr(fa, lane);
+  int r4[2];
+#pragma unroll
+  for (int sub = 0; sub < 2; sub++) r4[sub] = hi ? TILE_B + (sub * 32 + (lane & 31)) * 16 : fa.rb[0] + 2 * 64 + sub * 32 * ROWB;
+  Tr16Addr ta;
+  tr16_addr(ta, lane);
+  struct Bases { unsigned r0, r1, r40, r41, t00, t01, t10, t11; };
+  auto bases = [&](unsigned st) -> Bases { return Bases{st + (unsigned)fa.rb[0], st + (unsigned)fa.rb[1], st + (unsigned)r4[0], st + (unsigned)r4[1],
+                                                        st + (unsigned)ta.tb[0][0], st + (unsigned)ta.tb[0][1], st + (unsigned)ta.tb[1][0], st + (unsigned)ta.tb[1][1]}; };
+  constexpr int DOFF = TILE_B + STAT_B;
+
+  for (int st = 0; st < DKV4_STAGES; st++) {
+    init_pads(smem + st * STAGE_B, 0, tid);
+    init_pads(smem + st * STAGE_B + DOFF, 0, tid);
+  }
+  Acc16 dk[2], dv[2];                                              // [kb]: dK^T / dV^T in 16-row tiles: lane (R, c): d = 16 t + 4 R + g, key c (half 0) / 16 + c (half 1)
+#pragma unroll
+  for (int kb = 0; kb < 2; kb++) {
+    zero16(dk[kb]); zero16(dv[kb]);
+#pragma unroll
+    for (int tt = 0; tt < NT16; tt++) { to_agpr(dk[kb].v[tt][0]); to_agpr(dk[kb].v[tt][1]); to_agpr(dv[kb].v[tt][0]); to_agpr(dv[kb].v[tt][1]); }
+  }
+  f32x16 S[2][2], dP[2];                                           // S[buffer][kb] (S'(j) in buffer j & 1; E(j) leaves P there), dP[kb]
+  u32x4 pxu[2], pyu[2], dxu[2], dyu[2];                            // [kb]: P / dS of the sub-tile's 32 queries, packed and lane-exchanged (pack_xy): keys 0-15 / 16-31 of the block
+  bf16x8 f[4];                                                     // fragment quads
+
+  // fragment i of step (SUB): 0..4 Q rows of the next sub-tile (k-step i), 5..9 dO rows, 10..14 dO^T (16-row tile t), 15..19 Q^T (tile t); i >= 20: the
+  // next step's fragments (look-ahead).  cb = this tile's stage, nb = the next tile's.
+  auto rd_frag = [&](auto subc, auto ic, bf16x8& d, const Bases& cb, const Bases& nb) {
+    constexpr int SUB = decltype(subc)::value, I = decltype(ic)::value;
+    if constexpr (I >= 20) {                                       // next step: its fragments 0..3 are looked ahead (Q rows, k-steps 0..3)
+      constexpr int ks = I - 20;
+      static_assert(ks < KSTEPS - 1, "look-ahead reaches the statistics fragment");
+      // next step = (SUB ^ 1): its S block reads the sub-tile after it: SUB == 0 -> next step is sub 1 of this tile, reads (t+1, sub 0); SUB == 1 -> next
+      // step is sub 0 of tile t+1, reads (t+1, sub 1)
+      lds_row_asm<(SUB ? 32 * ROWB : 0) + (ks >> 1) * 64>(d, (ks & 1) ? nb.r1 : nb.r0);
+    } else if constexpr (I < 5) {
+      constexpr int ks = I;
+      if constexpr (SUB == 0) {                                    // (t, sub 1)
+        if constexpr (ks < KSTEPS - 1) lds_row_asm<32 * ROWB + (ks >> 1) * 64>(d, (ks & 1) ? cb.r1 : cb.r0);
+        else lds_row_asm<0>(d, cb.r41);
+      } else {                                                     // (t+1, sub 0)
+        if constexpr (ks < KSTEPS - 1) lds_row_asm<(ks >> 1) * 64>(d, (ks & 1) ? nb.r1 : nb.r0);
+        else lds_row_asm<0>(d, nb.r40);
+      }
+    } else if constexpr (I < 10) {
+      constexpr int ks = I - 5;
+      if constexpr (ks < KSTEPS - 1) lds_row_asm<DOFF + SUB * 32 * ROWB + (ks >> 1) * 64>(d, (ks & 1) ? cb.r1 : cb.r0);
+      else lds_row_asm<DOFF>(d, SUB ? cb.r41 : cb.r40);
+    } else {
+      constexpr int tt = (I - 10) % 5, isq = I >= 15;               // trfrag16: rows of the sub-tile's 32 queries, 16 head dims
+      lds_tr_asm<(isq ? 0 : DOFF) + SUB * 32 * ROWB + (tt >> 1) * 64>(d, (tt & 1) ? cb.t01 : cb.t00, (tt & 1) ? cb.t11 : cb.t10);
+    }
+  };
+
+  // ---- prologue: tiles 0, 1, 2 in flight; S'(0); look-ahead fragments 0, 1 of step 0
+  issue(lds0);
+  issue(lds0 + STAGE_B);
+  issue(lds0 + 2 * STAGE_B);
+  lds_dma_wait<14>();
+  __syncthreads();
+  {
+    const Bases cb = bases(lds0);
+    static_for<5>([&](auto kc) {
+      constexpr int ks = decltype(kc)::value;
+      if constexpr (ks < KSTEPS - 1) lds_row_asm<(ks >> 1) * 64>(f[ks & 3], (ks & 1) ? cb.r1 : cb.r0);
+      else lds_row_asm<0>(f[0], cb.r40);
+      if constexpr (ks == 3) { lds_wait<0>(f[0]); }                // (quad 0 is reused by k-step 4: settle k-step 0 first)
+      if constexpr (ks == 3) { mfma32_vv_first(S[0][0], f[0], kf[0][0]); mfma32_vv_first(S[0][1], f[0], kf[1][0]); }
+    });
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]));
+    mfma32_vv(S[0][0], f[1], kf[0][1]); mfma32_vv(S[0][1], f[1], kf[1][1]);
+    mfma32_vv(S[0][0], f[2], kf[0][2]); mfma32_vv(S[0][1], f[2], kf[1][2]);
+    mfma32_vv(S[0][0], f[3], kf[0][3]); mfma32_vv(S[0][1], f[3], kf[1][3]);
+    mfma32_vv(S[0][0], f[0], kf[0][4]); mfma32_vv(S[0][1], f[0], kf[1][4]);
+    mfma_drain();
+#pragma unroll
+    for (int kb = 0; kb < 2; kb++)
+#pragma unroll
+      for (int g = 0; g < 16; g++) S[0][kb][g] *= c;               // (inside the loop the next step's scores are scaled under the dK MFMAs)
+    static_for<4>([&](auto ic) { rd_frag(IntC<0>{}, ic, f[decltype(ic)::value], cb, cb); });   // step 0 (tile 0, sub 0): fragments 0..3 = Q rows of (0, sub 1)
+  }
+
+  // ---- one step = one 32-query sub-tile: 20 fragments (quad of fragment i = i & 3), consumed in pairs behind ONE counted wait, re-read four ahead.
+  // MFMA gaps: 0..19 S(j+1) / dP(j) (v_mfma_f32_32x32x16, two per row fragment: key blocks 0, 1), 20..39 dV(j), 40..59 dK(j) (v_mfma_f32_16x16x32, four per
+  // transposed fragment: {kb 0, kb 1} x {keys 0-15, keys 16-31}).  Vector work, a producer always at least one MFMA in front of its consumer:
+  //   gaps  0..15  exp2 of S'(j) c (2 scores per gap) -> P;  cvt_pk two gaps behind;  the four lane swaps of key block 0 in gaps 13 / 14, of 1 in 18 / 19
+  //   gaps 20..35  dS = P dP' (2 per gap);  cvt_pk two gaps behind (.. 37);  swaps of key block 0 in gaps 30 / 31, of key block 1 in 38 / 39
+  //   gaps 40..59  S'(j+1) *= c
+  int t = 0;
+  auto step = [&](auto subc, const Bases& cb, const Bases& nb, unsigned fst) {      // fst: LDS address of the stage tile t+3 is fetched into
+    constexpr int SUB = decltype(subc)::value, CUR = SUB, NXT = SUB ^ 1;
+    // pair pr = 0..15 of a 32-score block set (kb = pr >> 3, scores g = 2 (pr & 7), + 1) -> word of ua (-> x) or ub (-> y), pack_xy's layout
+    auto cvt_pair = [&](auto prc, f32x16 (&src)[2], u32x4 (&xu)[2], u32x4 (&yu)[2]) {
+      constexpr int pr = decltype(prc)::value;
+      if constexpr (pr >= 0 && pr < 16) {
+        constexpr int kb = pr >> 3, g = 2 * (pr & 7), w = (g >> 3) * 2 + ((g & 3) >> 1);
+        constexpr bool isb = (g & 4) != 0;
+        unsigned v = (DKV4_ABL & 2) ? __builtin_bit_cast(unsigned, src[kb][g]) : pack_bf16x2(src[kb][g], src[kb][g + 1]);
+        asm volatile("" : "+v"(v));
+        if constexpr (isb) yu[kb][w] = v; else xu[kb][w] = v;
+      }
+    };
+    auto swap2 = [&](auto kbc, auto w0c, u32x4 (&xu)[2], u32x4 (&yu)[2]) {
+      constexpr int kb = decltype(kbc)::value, w0 = decltype(w0c)::value;
+      static_for<2>([&](auto wc) {
+        constexpr int w = w0 + decltype(wc)::value;
+        if (!(DKV4_ABL & 2)) { const auto r = __builtin_amdgcn_permlane16_swap(xu[kb][w], yu[kb][w], false, false); xu[kb][w] = r[0]; yu[kb][w] = r[1]; }
+        asm volatile("" : "+v"(xu[kb][w]), "+v"(yu[kb][w]));
+      });
+    };
+    auto valu = [&](auto gic) {
+      constexpr int gi = decltype(gic)::value;
+      if constexpr (gi < 20) {
+        if constexpr (gi < 16) static_for<2>([&](auto ec) {
+          constexpr int e = 2 * gi + decltype(ec)::value;
+          if (!(DKV4_ABL & 1)) S[CUR][e >> 4][e & 15] = __builtin_amdgcn_exp2f(S[CUR][e >> 4][e & 15]);
+          asm volatile("" : "+v"(S[CUR][e >> 4][e & 15]));
+        });
+        cvt_pair(IntC<gi - 2>{}, S[CUR], pxu, pyu);
+        if constexpr (gi == 13) swap2(IntC<0>{}, IntC<0>{}, pxu, pyu);
+        if constexpr (gi == 14) swap2(IntC<0>{}, IntC<2>{}, pxu, pyu);
+        if constexpr (gi == 18) swap2(IntC<1>{}, IntC<0>{}, pxu, pyu);
+        if constexpr (gi == 19) swap2(IntC<1>{}, IntC<2>{}, pxu, pyu);
+      } else if constexpr (gi < 40) {
+        if constexpr (gi < 36) static_for<2>([&](auto ec) {
+          constexpr int e = 2 * (gi - 20) + decltype(ec)::value;
+          if (!(DKV4_ABL & 4)) dP[e >> 4][e & 15] *= S[CUR][e >> 4][e & 15];
+          asm volatile("" : "+v"(dP[e >> 4][e & 15]));
+        });
+        cvt_pair(IntC<gi - 22>{}, dP, dxu, dyu);
+        if constexpr (gi == 30) swap2(IntC<0>{}, IntC<0>{}, dxu, dyu);
+        if constexpr (gi == 31) swap2(IntC<0>{}, IntC<2>{}, dxu, dyu);
+        if constexpr (gi == 38) swap2(IntC<1>{}, IntC<0>{}, dxu, dyu);
+        if constexpr (gi == 39) swap2(IntC<1>{}, IntC<2>{}, dxu, dyu);
+      } else if constexpr (gi < 56) {
+        static_for<2>([&](auto ec) {
+          constexpr int e = 2 * (gi - 40) + decltype(ec)::value;
+          if (!(DKV4_ABL & 4)) S[NXT][e >> 4][e & 15] *= c;
+          asm volatile("" : "+v"(S[NXT][e >> 4][e & 15]));
+        });
+      }
+    };
+    // MFMA m of fragment i (row fragments: m = kb; transposed ones: m = 2 kb + half); W >= 0: behind the counted wait
+    auto mma = [&](auto ic, auto mc, auto wc) {
+      constexpr int i = decltype(ic)::value, m = decltype(mc)::value, W = decltype(wc)::value, q = i & 3;
+      if constexpr (DKV4_ABL & 32) { if constexpr (W >= 0) lds_wait<(W >= 0 ? W : 0)>(f[q]); return; }
+      if constexpr (i < 5) { if constexpr (i == 0) mfma32_vv_first<W>(S[NXT][m], f[q], kf[m][0]); else mfma32_vv<W>(S[NXT][m], f[q], kf[m][i]); }
+      else if constexpr (i < 10) { if constexpr (i == 5) mfma32_va_first<W>(dP[m], f[q], vf[m][0]); else mfma32_va<W>(dP[m], f[q], vf[m][i - 5]); }
+      else {
+        constexpr int kb = m >> 1, half = m & 1, tt = (i - 10) % 5;
+        if constexpr (W >= 0) lds_wait<(W >= 0 ? W : 0)>(f[q]);
+        if constexpr (i < 15) mfma16_acc(dv[kb].v[tt][half], f[q], __builtin_bit_cast(bf16x8, half ? pyu[kb] : pxu[kb]));
+        else mfma16_acc(dk[kb].v[tt][half], f[q], __builtin_bit_cast(bf16x8, half ? dyu[kb] : dxu[kb]));
+      }
+    };
+    auto nrd = [](int i) { const int k = ((i % 20) + 20) % 20; return k < 10 ? 1 : 2; };
+    static_for<10>([&](auto kc) {
+      constexpr int i = 2 * decltype(kc)::value;
+      constexpr int G0 = i < 10 ? 2 * i : 20 + 4 * (i - 10);       // gap index of the pair's first MFMA
+      if constexpr (SUB == 0 && i == 16) {                         // the tile's barrier, in front of the first look-ahead read into tile t+1
+        lds_dma_wait<7>();
+        __syncthreads();
+        if constexpr (!(DKV4_ABL & 16)) issue_part(IntC<0>{}, fst);
+      }
+      if constexpr (SUB == 0 && i == 18 && !(DKV4_ABL & 16)) issue_part(IntC<1>{}, fst);
+      if constexpr (SUB == 1 && i == 0 && !(DKV4_ABL & 16)) issue_part(IntC<2>{}, fst);
+      if constexpr (SUB == 1 && i == 2 && !(DKV4_ABL & 16)) { issue_part(IntC<3>{}, fst); advance(); }
+      constexpr int W = nrd(i + 2) + nrd(i + 3);
+      if constexpr (i < 10) {                                      // row fragments: two MFMAs each
+        mma(IntC<i>{}, IntC<0>{}, IntC<W>{});
+        __builtin_amdgcn_sched_barrier(0);
+        valu(IntC<G0>{});
+        __builtin_amdgcn_sched_barrier(0);
+        mma(IntC<i>{}, IntC<1>{}, IntC<-1>{});
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (!(DKV4_ABL & 8)) rd_frag(subc, IntC<i + 4>{}, f[i & 3], cb, nb);
+        valu(IntC<G0 + 1>{});
+        __builtin_amdgcn_sched_barrier(0);
+        mma(IntC<i + 1>{}, IntC<0>{}, IntC<-1>{});
+        __builtin_amdgcn_sched_barrier(0);
+        valu(IntC<G0 + 2>{});
+        __builtin_amdgcn_sched_barrier(0);
+        mma(IntC<i + 1>{}, IntC<1>{}, IntC<-1>{});
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (!(DKV4_ABL & 8)) rd_frag(subc, IntC<i + 5>{}, f[(i + 1) & 3], cb, nb);
+        valu(IntC<G0 + 3>{});
+        __builtin_amdgcn_sched_barrier(0);
+      } else {                                                     // transposed fragments: four MFMAs each
+        static_for<8>([&](auto mc) {
+          constexpr int mm = decltype(mc)::value, fi = i + (mm >> 2), m = mm & 3;
+          mma(IntC<fi>{}, IntC<m>{}, IntC<(mm == 0 ? W : -1)>{});
+          __builtin_amdgcn_sched_barrier(0);
+          if constexpr (m == 3 && !(DKV4_ABL & 8)) rd_frag(subc, IntC<fi + 4>{}, f[fi & 3], cb, nb);
+          valu(IntC<G0 + mm>{});
+          __builtin_amdgcn_sched_barrier(0);
+        });
+      }
+    });
+  };
+  // stage rotation without per-tile multiplies: cur / nx / (the stage of tile t+3 = the one of tile t-1) walk the ring by additions
+  unsigned cur = lds0, nx = lds0 + STAGE_B, fst = lds0 + 3 * STAGE_B;
+  Bases cb = bases(cur);
+  for (t = 0; t < T; t++) {
+    const Bases nb = bases(nx);
+    step(IntC<0>{}, cb, nb, fst);
+    step(IntC<1>{}, cb, nb, fst);
+    cb = nb;
+    fst = cur;
+    cur = nx;
+    nx = nx + STAGE_B == lds0 + DKV4_STAGES * STAGE_B ? lds0 : nx + STAGE_B;
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f[0]), "+v"(f[1]), "+v"(f[2]), "+v"(f[3]));
+  lds_dma_wait<0>();                                               // the clamped re-fetches must not land in a later workgroup's LDS
+  mfma_drain();
+#pragma unroll
+  for (int kb = 0; kb < 2; kb++) {
+    const long k0 = (long)bx * 256 + wave * 64 + kb * 32;          // first key of the block: lane (R, c) stores rows k0 + c and k0 + 16 + c
+    store_rows16(p.dK + dkbase + k0 * p.dk_ts + (long)h * p.dk_hs, p.dk_ts, dk[kb], p.scale, p.scale, true, true, lane);
+    store_rows16(p.dV + dvbase + k0 * p.dv_ts + (long)h * p.dv_hs, p.dv_ts, dv[kb], 1.f, 1.f, true, true, lane);
+    if (p.dk_colsum) colsum_rows16(p.dk_colsum + (b % PXA_COLSUM_SLOTS) * p.colsum_stride + h * DH, dk[kb], p.scale, true, true, lane);
+    if (p.dv_colsum) colsum_rows16(p.dv_colsum + (b % PXA_COLSUM_SLOTS) * p.colsum_stride + h * DH, dv[kb], 1.f, true, true, lane);
+  }
+}
+
+
 // ------------------------------------------------------------------------------------------------ backward: dQ, ONE wave per SIMD (round 4)
 // attn_bwd_dkv4_kernel's idea for the query-stationary half: a wave owns 64 queries (two 32-query blocks qb) and the whole register file, every K / V /
 // K^T fragment read from LDS feeds both blocks (20 read instructions for 40 MFMAs per 32-key sub-tile; attn_bwd_dq2_kernel: 35), half the waves read the
@@ -3159,12 +3469,13 @@ extern "C" int pxa_attn_bwd(const pxa_attn_args* a, hipStream_t stream) {
     // 4 = one wave per SIMD, 64 keys per wave (dense keys in whole 256-key blocks, whole 64-query tiles); PXA_ATTN_DKV=4 asks for it, the default takes it
     // where it applies and falls back to 2 elsewhere
     const bool dkv4_ok = p.stats && !p.kv_start && p.Nk % 256 == 0 && p.Nk > 0 && p.Nq % BKV == 0 && p.Nq >= 2 * BKV;
-    if (dkv_mode == 4 && !dkv4_ok) dkv_mode = 2;
-    if (!env && dkv_mode == 2 && PXA_ATTN_DKV4_DEFAULT && dkv4_ok) dkv_mode = 4;
+    if (dkv_mode >= 4 && !dkv4_ok) dkv_mode = 2;
+    if (!env && dkv_mode == 2 && PXA_ATTN_DKV4_DEFAULT && dkv4_ok) dkv_mode = 5;     // 5 = 4 + second products on 16-row tiles (-2.5 %, profiles/r4_19_*)
     p.nx = dkv_mode >= 3 ? (max_k + 255) / 256 : (max_k + 127) / 128;
     PXA_CHECK((long)p.nx * p.H * p.B < (1L << 31), "pxa_attn_bwd: grid too large");
     if (p.nx > 0) {
-      if (dkv_mode == 4) hipLaunchKernelGGL(attn_bwd_dkv4_kernel, dim3(p.nx * p.H * p.B), dim3(256), 0, stream, p);
+      if (dkv_mode == 5) hipLaunchKernelGGL(attn_bwd_dkv5_kernel, dim3(p.nx * p.H * p.B), dim3(256), 0, stream, p);
+      else if (dkv_mode == 4) hipLaunchKernelGGL(attn_bwd_dkv4_kernel, dim3(p.nx * p.H * p.B), dim3(256), 0, stream, p);
       else if (dkv_mode == 3) hipLaunchKernelGGL(attn_bwd_dkv3_kernel<2>, dim3(p.nx * p.H * p.B), dim3(512), 0, stream, p);   // prefetch distances 3 / 4 / 6 measured the same
       else if (dkv_mode == 2) hipLaunchKernelGGL(attn_bwd_dkv2_kernel<1>, dim3(p.nx * p.H * p.B), dim3(256), 0, stream, p);
       else if (dkv_mode == 1) hipLaunchKernelGGL(attn_bwd_dkv2_kernel<0>, dim3(p.nx * p.H * p.B), dim3(256), 0, stream, p);

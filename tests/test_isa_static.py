@@ -32,7 +32,8 @@ def asm(tmp_path_factory):
 
 
 @pytest.mark.parametrize("kernel,tag", [("attn_bwd_dkv2_kernelILi1E", "bf16"), ("attn_bwd_dq2_kernel", "bf16"), ("attn_fwd4_kernel", "bf16"), ("attn_fwd4_kernel", "f16"),
-                                        ("attn_bwd_dkv4_kernel", "bf16"), ("attn_bwd_dkv4_kernel", "f16"), ("attn_bwd_dq4_kernel", "bf16"), ("attn_bwd_dq4_kernel", "f16")])
+                                        ("attn_bwd_dkv4_kernel", "bf16"), ("attn_bwd_dkv4_kernel", "f16"), ("attn_bwd_dq4_kernel", "bf16"), ("attn_bwd_dq4_kernel", "f16"),
+                                        ("attn_bwd_dkv5_kernel", "bf16"), ("attn_bwd_dkv5_kernel", "f16")])
 def test_hand_counted_lds_waits(asm, kernel, tag):
     import check_lds_waits as C
     r = C.check(asm[("attn.hip", tag)], kernel, inflight_at_back_edge=kernel.endswith("4_kernel"))
@@ -75,7 +76,7 @@ def test_fwd4_register_ownership(asm, tag):
         assert sum(o.startswith("global_load_lds") for o in ops) == 6 and sum(o == "s_barrier" for o in ops) == 1
 
 
-@pytest.mark.parametrize("kernel,n32,n16", [("attn_bwd_dkv4_kernel", 88, 0), ("attn_bwd_dq4_kernel", 40, 40)])
+@pytest.mark.parametrize("kernel,n32,n16", [("attn_bwd_dkv4_kernel", 88, 0), ("attn_bwd_dkv5_kernel", 40, 80), ("attn_bwd_dq4_kernel", 40, 40)])
 @pytest.mark.parametrize("tag", ["bf16", "f16"])
 def test_one_wave_backward_kernels_keep_the_tile_loop_clean(asm, kernel, n32, n16, tag):
     """The round-4 backward kernels: no scratch, and per 64-row tile of the loop exactly the contracted MFMAs, ONE barrier, no register-file traffic."""

@@ -596,7 +596,7 @@ def test_attention_headline_shapes(ops, B, H, Nq, Nk):
     assert max(errs["dq"], errs["dk"], errs["dv"]) < 2 * BF16_TOL
 
 
-@pytest.mark.parametrize("mode,dqm", [("0", "0"), ("1", "1"), ("2", "1"), ("2", "0"), ("3", "1"), ("4", "1"), ("4", "4"), ("2", "4")])
+@pytest.mark.parametrize("mode,dqm", [("0", "0"), ("1", "1"), ("2", "1"), ("2", "0"), ("3", "1"), ("4", "1"), ("4", "4"), ("2", "4"), ("5", "4")])
 @pytest.mark.parametrize("B,H,Nq,Nk,lens", [(2, 3, 130, 77, None), (1, 2, 64, 1024, None), (2, 2, 520, 200, None), (1, 4, 96, 96, None),
                                              (3, 16, 160, 300, [300, 7, 64]), (2, 16, 1024, 1024, None), (1, 2, 200, 40, None),
                                              (1, 2, 128, 256, None), (2, 3, 192, 512, None), (1, 2, 1024, 256, None), (1, 16, 2048, 1024, None)])
@@ -604,7 +604,7 @@ def test_attention_dkv_kernel_modes(ops, monkeypatch, mode, dqm, B, H, Nq, Nk, l
     """The three dK/dV kernels of csrc/attn.hip (PXA_ATTN_DKV: 0 = round-2 kernel, 1 = lse / delta through the matrix products + three-stage ring,
     2 = + hand-placed software pipeline with asm LDS reads, 3 = 512-thread workgroups whose two waves per SIMD alternate matrix and softmax phases
     in lock-step, 4 = round 4: one wave per SIMD with 64 keys per wave and asm-owned accumulator registers - dense keys in whole 256-key blocks and
-    whole 64-query tiles, the launcher falls back to 2 elsewhere) and the three dQ kernels (PXA_ATTN_DQ: 0 = round-2 kernel, 1 = hand-placed pipeline; its ragged
+    whole 64-query tiles, the launcher falls back to 2 elsewhere; 5 = 4 with the second products on 16-row MFMA tiles - the default where it applies) and the three dQ kernels (PXA_ATTN_DQ: 0 = round-2 kernel, 1 = hand-placed pipeline; its ragged
     last key tile runs the masked compiler-scheduled path; 4 = round 4: one wave per SIMD with 64 queries per wave - dense keys in whole 64-key tiles, the
     launcher falls back to 1 elsewhere) against fp32 attention per head: ragged query tiles (Nq % 64 != 0: sentinel stats rows),
     one / many key blocks, fewer than 64 keys, partial key waves, packed varlen text keys with inactive waves, and the bias-gradient column sums."""

@@ -95,7 +95,7 @@ def compile_asm():
 
 if __name__ == "__main__":
     sub = sys.argv[1] if len(sys.argv) > 1 else "attn_bwd_dkv2_kernelILi1E"
-    r = check(compile_asm(), sub, inflight_at_back_edge=any(k in sub for k in ("fwd4", "dkv4", "dq4")))
+    r = check(compile_asm(), sub, inflight_at_back_edge=any(k in sub for k in ("fwd4", "dkv4", "dkv5", "dq4")))
     print({k: v for k, v in r.items() if k != "errors"})
     for e in r["errors"][:20]:
         print("ERROR", e)

@@ -8,6 +8,7 @@ import torch
 from pixart_sigma_amd import ops
 
 dev, OPD = "cuda", ops.BF16
+NEW = os.environ.get("KB_DKV_MODE", "4")      # the dK/dV kernel under test (4: one wave per SIMD; 5: + 16-row second products)
 
 
 def rel(a, b):
@@ -40,7 +41,7 @@ def check():
         lse = torch.empty(B, H, Nq, device=dev)
         sq, sk = (Nq * C, C, 72), (Nk * C, C, 72)
         ops.attention_fwd(q, k, v, o, lse, B, H, Nq, Nk, (sq, sk, sk, sq))
-        dk4, dv4 = bwd(q, k, v, o, do, lse, B, H, Nq, Nk, "4")
+        dk4, dv4 = bwd(q, k, v, o, do, lse, B, H, Nq, Nk, NEW)
         dk2, dv2 = bwd(q, k, v, o, do, lse, B, H, Nq, Nk, "2")
         qf, kf, vf = (t.float().view(B, -1, H, 72).transpose(1, 2).requires_grad_(True) for t in (q, k, v))
         s = (qf @ kf.transpose(-1, -2)) * 72 ** -0.5
@@ -62,15 +63,15 @@ def check():
     st = (s3, s3, s3, (N * C, C, 72))
     ops.attention_fwd(q, k, v, o, lse, B, H, N, N, st)
     outs = {}
-    for mode in ("4", "4", "2"):
+    for mode in (NEW, NEW, "2"):
         os.environ["PXA_ATTN_DKV"] = mode
         d = torch.full_like(qkv, float("nan"))
         ops.attention_bwd(q, k, v, o, do, lse, delta, d[..., :C], d[..., C:2 * C], d[..., 2 * C:], B, H, N, N, st, (s3, s3, s3))
         torch.cuda.synchronize()
         outs.setdefault(mode, []).append(d)
-    a, b2 = outs["4"][0].float(), outs["2"][0].float()
+    a, b2 = outs[NEW][0].float(), outs["2"][0].float()
     per_head = (a - b2).view(B, N, 3, H, 72).pow(2).sum((1, 4)).sqrt() / b2.view(B, N, 3, H, 72).pow(2).sum((1, 4)).sqrt()
-    rep = torch.equal(outs["4"][0], outs["4"][1])
+    rep = torch.equal(outs[NEW][0], outs[NEW][1])
     ok = per_head.max().item() < tol and rep and torch.isfinite(a).all().item()
     bad += not ok
     print(f"full grid B16: worst (head, tensor) vs the two-wave kernel {per_head.max().item():.2e}, bit-reproducible {rep}  {'ok' if ok else 'FAIL'}", flush=True)
@@ -157,7 +158,7 @@ def timeit():
     ops.attention_bwd(q, k, v, a, da, lse, delta, dqkv[:, :D], dqkv[:, D:2 * D], dqkv[:, 2 * D:], B, H, N, N, st, (s3, s3, s3))   # fills the statistics workspace
     fl = 8.0 * B * H * N * N * 72
     os.environ["PXA_ATTN_BWD_NO_PREPASS"] = "1"
-    for mode in ("2", "4", "2", "4"):
+    for mode in ("2", NEW, "2", NEW):
         os.environ["PXA_ATTN_DKV"] = mode
         fn = lambda: ops.attention_bwd(q, k, v, a, da, lse, delta, None, dqkv[:, D:2 * D], dqkv[:, 2 * D:], B, H, N, N, st, (s3, s3, s3))
         for _ in range(10):
