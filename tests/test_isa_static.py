@@ -36,7 +36,7 @@ def asm(tmp_path_factory):
                                         ("attn_bwd_dkv5_kernel", "bf16"), ("attn_bwd_dkv5_kernel", "f16")])
 def test_hand_counted_lds_waits(asm, kernel, tag):
     import check_lds_waits as C
-    r = C.check(asm[("attn.hip", tag)], kernel, inflight_at_back_edge=kernel.endswith("4_kernel"))
+    r = C.check(asm[("attn.hip", tag)], kernel, inflight_at_back_edge=kernel.endswith(("4_kernel", "5_kernel")))
     assert not r["errors"], r["errors"][:5]
     assert r["reads"] > 0 and r["waits"] > 0 and r["mfma"] > 0
 
