@@ -2085,25 +2085,9 @@ __global__ __launch_bounds__(256, 1) void attn_fwd4_kernel(AttnParams p) {
   const float c = p.scale_log2;
   typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
-  // query operands (FOLD: prescaled, Q~ = c Q in the operand type; slot 72 = k-step 4, upper half, element 0 carries -m c, initially 0)
   int q[QS];
   bool qvalid[QS];
-  bf16x8 qf[QS][KSTEPS];
-#pragma unroll
-  for (int s = 0; s < QS; s++) {
-    q[s] = bx * 256 + wave * 64 + s * 32 + (lane & 31);
-    qvalid[s] = q[s] < p.Nq;
-    load_row_frags(qf[s], p.Q + (long)b * p.q_bs + (long)q[s] * p.q_ts + (long)h * p.q_hs, qvalid[s], hi);
-    settle(qf[s]);
-    if constexpr (FOLD) {
-#pragma unroll
-      for (int ks = 0; ks < KSTEPS; ks++)
-#pragma unroll
-        for (int e = 0; e < 8; e++) qf[s][ks][e] = (bf16_t)((float)qf[s][ks][e] * c);
-    }
-#pragma unroll
-    for (int ks = 0; ks < KSTEPS; ks++) to_agpr(qf[s][ks]);
-  }
+  bf16x8 qf[QS][KSTEPS];                                           // (loaded in the prologue, behind the first tiles' DMA)
   for (int st = 0; st < 2 * RING; st++) init_pads(smem + st * TILE_B, 1, tid);   // column 72 = 1.0 in K tiles (x slot 72 of Q~) and V tiles (row sums)
 
   // LDS-DMA plan: per-lane byte offsets inside a tile's rows (saddr form), one lane mask per piece index
@@ -2176,6 +2160,9 @@ __global__ __launch_bounds__(256, 1) void attn_fwd4_kernel(AttnParams p) {
     bcast_halves(mrel, mx[0], mx[1]);
 #pragma unroll
     for (int s = 0; s < QS; s++) {
+      // a query block none of whose rows left the window keeps its maximum (wave-uniform skip: usually ONE block triggers the event, and the block's
+      // share of the slow path - 32 score updates, 80 register moves + 40 multiplies on O - is most of its cost)
+      if (!first && __builtin_amdgcn_ballot_w64(mx[s] > FWD4_THRESH) == 0) continue;
       const float dmax = first ? mx[s] + FWD4_MARGIN : fmaxf(mx[s], 0.f);
       float mnew = mc[s] + dmax;
       bf16_t nb = (bf16_t)0.f;
@@ -2220,6 +2207,23 @@ __global__ __launch_bounds__(256, 1) void attn_fwd4_kernel(AttnParams p) {
   dma_k(IntC<1>{}, ktile(1));
   dma_kv(IntC<2>{}, IntC<0>{}, ktile(2), vtile(0));
   dma_kv(IntC<3>{}, IntC<1>{}, ktile(3), vtile(1));
+  // (the query rows are fetched BEHIND the first tiles' DMA: their latency and the tiles' overlap instead of adding up - 2 us of a 75 us workgroup)
+  // query operands (FOLD: prescaled, Q~ = c Q in the operand type; slot 72 = k-step 4, upper half, element 0 carries -m c, initially 0)
+#pragma unroll
+  for (int s = 0; s < QS; s++) {
+    q[s] = bx * 256 + wave * 64 + s * 32 + (lane & 31);
+    qvalid[s] = q[s] < p.Nq;
+    load_row_frags(qf[s], p.Q + (long)b * p.q_bs + (long)q[s] * p.q_ts + (long)h * p.q_hs, qvalid[s], hi);
+    settle(qf[s]);
+    if constexpr (FOLD) {
+#pragma unroll
+      for (int ks = 0; ks < KSTEPS; ks++)
+#pragma unroll
+        for (int e = 0; e < 8; e++) qf[s][ks][e] = (bf16_t)((float)qf[s][ks][e] * c);
+    }
+#pragma unroll
+    for (int ks = 0; ks < KSTEPS; ks++) to_agpr(qf[s][ks]);
+  }
   lds_dma_wait<12>();                                              // K(0), K(1) landed (this wave's pieces)
   __syncthreads();                                                 // ... everybody's, and the pads are written
   static_for<10>([&](auto kc) { rd_k(IntC<0>{}, kc); });
@@ -2400,7 +2404,8 @@ __global__ __launch_bounds__(256, 1) void attn_fwd4_kernel(AttnParams p) {
 // Ring: {Q tile, L rows, dO tile, D rows} x 4 stages (104 KiB, one workgroup per CU), tile t+3 fetched behind the ONE barrier of tile t, which sits in
 // front of the first look-ahead read into tile t+1 (two fragments before the end of sub-tile 0) behind a counted vmcnt(7): tile t+2 stays in flight.
 // Every wave issues 7 LDS-DMA pieces per tile (waves 2 / 3 repeat the statistics pieces of waves 0 / 1: same bytes, uniform vmcnt accounting).
-// Dense keys, Nk % 256 == 0, Nq % 64 == 0 (every self-attention shape of the square buckets); everything else runs attn_bwd_dkv2_kernel.
+// Dense keys in whole 64-key blocks (a workgroup's last waves may own no keys: they serve DMA and barriers on zero operands), whole 64-query tiles;
+// everything else runs attn_bwd_dkv2_kernel.
 // (W >= 0: the counted wait for the fragment `a` rides in the MFMA's own statement - a separate wait statement with the fragment as its output draws a
 // compiler boundary s_nop in front of every consumer: 44 per tile in the first build of this kernel)
 #define PXA_WAIT_STR "s_waitcnt lgkmcnt(%3)\n\t"
@@ -2440,27 +2445,6 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv4_kernel(AttnParams p) {
   const long kbase = (long)b * p.k_bs, vbase = (long)b * p.v_bs, dkbase = (long)b * p.dk_bs, dvbase = (long)b * p.dv_bs;
   typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
-  // stationary operands: K / V rows of this wave's 2 x 32 keys (B operands: lane = key), -1.0 in k-slots 72..74 against the statistics rows
-  int kv[2];
-  bf16x8 kf[2][KSTEPS], vf[2][KSTEPS];
-#pragma unroll
-  for (int kb = 0; kb < 2; kb++) {
-    kv[kb] = bx * 256 + wave * 64 + kb * 32 + (lane & 31);
-    load_row_frags(kf[kb], p.K + kbase + (long)kv[kb] * p.k_ts + (long)h * p.k_hs, true, hi);
-    load_row_frags(vf[kb], p.V + vbase + (long)kv[kb] * p.v_ts + (long)h * p.v_hs, true, hi);
-    settle(kf[kb]);
-    settle(vf[kb]);
-    if (hi == 1) {
-      u32x4 w = __builtin_bit_cast(u32x4, kf[kb][KSTEPS - 1]);
-      w[0] = PXA_OPERAND_MINUS_ONE_X2; w[1] = PXA_OPERAND_MINUS_ONE_X1;
-      kf[kb][KSTEPS - 1] = __builtin_bit_cast(bf16x8, w);
-      w = __builtin_bit_cast(u32x4, vf[kb][KSTEPS - 1]);
-      w[0] = PXA_OPERAND_MINUS_ONE_X2; w[1] = PXA_OPERAND_MINUS_ONE_X1;
-      vf[kb][KSTEPS - 1] = __builtin_bit_cast(bf16x8, w);
-    }
-#pragma unroll
-    for (int ks = 0; ks < KSTEPS; ks++) to_agpr(vf[kb][ks]);
-  }
   const bf16_t* Qp = p.Q + (long)b * p.q_bs + (long)h * p.q_hs;
   const bf16_t* Dp = p.dO + (long)b * p.o_bs + (long)h * p.o_hs;
   const bf16_t* Ls = p.stats + ((long)b * p.H + h) * p.Nq64 * 8;
@@ -2568,6 +2552,29 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv4_kernel(AttnParams p) {
   issue(lds0);
   issue(lds0 + STAGE_B);
   issue(lds0 + 2 * STAGE_B);
+  // (the stationary rows are fetched BEHIND the first tiles' DMA: the two latencies overlap)
+  // stationary operands: K / V rows of this wave's 2 x 32 keys (B operands: lane = key), -1.0 in k-slots 72..74 against the statistics rows
+  int kv[2];
+  bf16x8 kf[2][KSTEPS], vf[2][KSTEPS];
+#pragma unroll
+  for (int kb = 0; kb < 2; kb++) {
+    kv[kb] = bx * 256 + wave * 64 + kb * 32 + (lane & 31);
+    const bool kvok = kv[kb] < p.Nk;                               // Nk % 64 == 0: a key block is whole or absent (its waves then carry zeros and store nothing)
+    load_row_frags(kf[kb], p.K + kbase + (long)kv[kb] * p.k_ts + (long)h * p.k_hs, kvok, hi);
+    load_row_frags(vf[kb], p.V + vbase + (long)kv[kb] * p.v_ts + (long)h * p.v_hs, kvok, hi);
+    settle(kf[kb]);
+    settle(vf[kb]);
+    if (hi == 1) {
+      u32x4 w = __builtin_bit_cast(u32x4, kf[kb][KSTEPS - 1]);
+      w[0] = PXA_OPERAND_MINUS_ONE_X2; w[1] = PXA_OPERAND_MINUS_ONE_X1;
+      kf[kb][KSTEPS - 1] = __builtin_bit_cast(bf16x8, w);
+      w = __builtin_bit_cast(u32x4, vf[kb][KSTEPS - 1]);
+      w[0] = PXA_OPERAND_MINUS_ONE_X2; w[1] = PXA_OPERAND_MINUS_ONE_X1;
+      vf[kb][KSTEPS - 1] = __builtin_bit_cast(bf16x8, w);
+    }
+#pragma unroll
+    for (int ks = 0; ks < KSTEPS; ks++) to_agpr(vf[kb][ks]);
+  }
   lds_dma_wait<14>();
   __syncthreads();
   {
@@ -2719,10 +2726,13 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv4_kernel(AttnParams p) {
   mfma_drain();
 #pragma unroll
   for (int kb = 0; kb < 2; kb++) {
-    store_rows(p.dK + dkbase + (long)kv[kb] * p.dk_ts + (long)h * p.dk_hs, dk[kb], p.scale, hi);
-    store_rows(p.dV + dvbase + (long)kv[kb] * p.dv_ts + (long)h * p.dv_hs, dv[kb], 1.f, hi);
-    if (p.dk_colsum) colsum_rows(p.dk_colsum + (b % PXA_COLSUM_SLOTS) * p.colsum_stride + h * DH, dk[kb], p.scale, true, hi, lane);
-    if (p.dv_colsum) colsum_rows(p.dv_colsum + (b % PXA_COLSUM_SLOTS) * p.colsum_stride + h * DH, dv[kb], 1.f, true, hi, lane);
+    const bool kvok = kv[kb] < p.Nk;
+    if (kvok) {
+      store_rows(p.dK + dkbase + (long)kv[kb] * p.dk_ts + (long)h * p.dk_hs, dk[kb], p.scale, hi);
+      store_rows(p.dV + dvbase + (long)kv[kb] * p.dv_ts + (long)h * p.dv_hs, dv[kb], 1.f, hi);
+    }
+    if (p.dk_colsum) colsum_rows(p.dk_colsum + (b % PXA_COLSUM_SLOTS) * p.colsum_stride + h * DH, dk[kb], p.scale, kvok, hi, lane);
+    if (p.dv_colsum) colsum_rows(p.dv_colsum + (b % PXA_COLSUM_SLOTS) * p.colsum_stride + h * DH, dv[kb], 1.f, kvok, hi, lane);
   }
 }
 
@@ -2739,27 +2749,6 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv5_kernel(AttnParams p) {
   const long kbase = (long)b * p.k_bs, vbase = (long)b * p.v_bs, dkbase = (long)b * p.dk_bs, dvbase = (long)b * p.dv_bs;
   typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
-  // stationary operands: K / V rows of this wave's 2 x 32 keys (B operands: lane = key), -1.0 in k-slots 72..74 against the statistics rows
-  int kv[2];
-  bf16x8 kf[2][KSTEPS], vf[2][KSTEPS];
-#pragma unroll
-  for (int kb = 0; kb < 2; kb++) {
-    kv[kb] = bx * 256 + wave * 64 + kb * 32 + (lane & 31);
-    load_row_frags(kf[kb], p.K + kbase + (long)kv[kb] * p.k_ts + (long)h * p.k_hs, true, hi);
-    load_row_frags(vf[kb], p.V + vbase + (long)kv[kb] * p.v_ts + (long)h * p.v_hs, true, hi);
-    settle(kf[kb]);
-    settle(vf[kb]);
-    if (hi == 1) {
-      u32x4 w = __builtin_bit_cast(u32x4, kf[kb][KSTEPS - 1]);
-      w[0] = PXA_OPERAND_MINUS_ONE_X2; w[1] = PXA_OPERAND_MINUS_ONE_X1;
-      kf[kb][KSTEPS - 1] = __builtin_bit_cast(bf16x8, w);
-      w = __builtin_bit_cast(u32x4, vf[kb][KSTEPS - 1]);
-      w[0] = PXA_OPERAND_MINUS_ONE_X2; w[1] = PXA_OPERAND_MINUS_ONE_X1;
-      vf[kb][KSTEPS - 1] = __builtin_bit_cast(bf16x8, w);
-    }
-#pragma unroll
-    for (int ks = 0; ks < KSTEPS; ks++) to_agpr(vf[kb][ks]);
-  }
   const bf16_t* Qp = p.Q + (long)b * p.q_bs + (long)h * p.q_hs;
   const bf16_t* Dp = p.dO + (long)b * p.o_bs + (long)h * p.o_hs;
   const bf16_t* Ls = p.stats + ((long)b * p.H + h) * p.Nq64 * 8;
@@ -2869,6 +2858,29 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv5_kernel(AttnParams p) {
   issue(lds0);
   issue(lds0 + STAGE_B);
   issue(lds0 + 2 * STAGE_B);
+  // (the stationary rows are fetched BEHIND the first tiles' DMA: the two latencies overlap)
+  // stationary operands: K / V rows of this wave's 2 x 32 keys (B operands: lane = key), -1.0 in k-slots 72..74 against the statistics rows
+  int kv[2];
+  bf16x8 kf[2][KSTEPS], vf[2][KSTEPS];
+#pragma unroll
+  for (int kb = 0; kb < 2; kb++) {
+    kv[kb] = bx * 256 + wave * 64 + kb * 32 + (lane & 31);
+    const bool kvok = kv[kb] < p.Nk;                               // Nk % 64 == 0: a key block is whole or absent (its waves then carry zeros and store nothing)
+    load_row_frags(kf[kb], p.K + kbase + (long)kv[kb] * p.k_ts + (long)h * p.k_hs, kvok, hi);
+    load_row_frags(vf[kb], p.V + vbase + (long)kv[kb] * p.v_ts + (long)h * p.v_hs, kvok, hi);
+    settle(kf[kb]);
+    settle(vf[kb]);
+    if (hi == 1) {
+      u32x4 w = __builtin_bit_cast(u32x4, kf[kb][KSTEPS - 1]);
+      w[0] = PXA_OPERAND_MINUS_ONE_X2; w[1] = PXA_OPERAND_MINUS_ONE_X1;
+      kf[kb][KSTEPS - 1] = __builtin_bit_cast(bf16x8, w);
+      w = __builtin_bit_cast(u32x4, vf[kb][KSTEPS - 1]);
+      w[0] = PXA_OPERAND_MINUS_ONE_X2; w[1] = PXA_OPERAND_MINUS_ONE_X1;
+      vf[kb][KSTEPS - 1] = __builtin_bit_cast(bf16x8, w);
+    }
+#pragma unroll
+    for (int ks = 0; ks < KSTEPS; ks++) to_agpr(vf[kb][ks]);
+  }
   lds_dma_wait<14>();
   __syncthreads();
   {
@@ -3028,10 +3040,11 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv5_kernel(AttnParams p) {
 #pragma unroll
   for (int kb = 0; kb < 2; kb++) {
     const long k0 = (long)bx * 256 + wave * 64 + kb * 32;          // first key of the block: lane (R, c) stores rows k0 + c and k0 + 16 + c
-    store_rows16(p.dK + dkbase + k0 * p.dk_ts + (long)h * p.dk_hs, p.dk_ts, dk[kb], p.scale, p.scale, true, true, lane);
-    store_rows16(p.dV + dvbase + k0 * p.dv_ts + (long)h * p.dv_hs, p.dv_ts, dv[kb], 1.f, 1.f, true, true, lane);
-    if (p.dk_colsum) colsum_rows16(p.dk_colsum + (b % PXA_COLSUM_SLOTS) * p.colsum_stride + h * DH, dk[kb], p.scale, true, true, lane);
-    if (p.dv_colsum) colsum_rows16(p.dv_colsum + (b % PXA_COLSUM_SLOTS) * p.colsum_stride + h * DH, dv[kb], 1.f, true, true, lane);
+    const bool kvok = k0 < p.Nk;                                   // whole block or none (Nk % 64 == 0)
+    store_rows16(p.dK + dkbase + k0 * p.dk_ts + (long)h * p.dk_hs, p.dk_ts, dk[kb], p.scale, p.scale, kvok, kvok, lane);
+    store_rows16(p.dV + dvbase + k0 * p.dv_ts + (long)h * p.dv_hs, p.dv_ts, dv[kb], 1.f, 1.f, kvok, kvok, lane);
+    if (p.dk_colsum) colsum_rows16(p.dk_colsum + (b % PXA_COLSUM_SLOTS) * p.colsum_stride + h * DH, dk[kb], p.scale, kvok, kvok, lane);
+    if (p.dv_colsum) colsum_rows16(p.dv_colsum + (b % PXA_COLSUM_SLOTS) * p.colsum_stride + h * DH, dv[kb], 1.f, kvok, kvok, lane);
   }
 }
 
@@ -3064,32 +3077,6 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq4_kernel(AttnParams p) {
   const int T = p.Nk / BKV;                                        // full 64-key tiles (checked by the launcher), >= 1
   const float c = p.scale_log2;
   typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-
-  // stationary operands: Q / dO rows of this wave's 2 x 32 queries (B operands: lane = query), delta in slots 72..74 of the dO rows (split3)
-  int q[2];
-  bool qvalid[2];
-  float lse[2];
-  bf16x8 qf[2][KSTEPS], dof[2][KSTEPS];
-#pragma unroll
-  for (int qb = 0; qb < 2; qb++) {
-    q[qb] = bx * 256 + wave * 64 + qb * 32 + (lane & 31);
-    qvalid[qb] = q[qb] < p.Nq;
-    load_row_frags(qf[qb], p.Q + (long)b * p.q_bs + (long)q[qb] * p.q_ts + (long)h * p.q_hs, qvalid[qb], hi);
-    load_row_frags(dof[qb], p.dO + (long)b * p.o_bs + (long)q[qb] * p.o_ts + (long)h * p.o_hs, qvalid[qb], hi);
-    settle(qf[qb]);
-    settle(dof[qb]);
-    const long sidx = ((long)b * p.H + h) * p.Nq + q[qb];
-    lse[qb] = qvalid[qb] ? p.LSE[sidx] : 0.f;
-    const float delta = qvalid[qb] ? p.Delta[sidx] : 0.f;
-    if (hi == 1) {
-      u32x4 w = __builtin_bit_cast(u32x4, dof[qb][KSTEPS - 1]);
-      const uint2 d3 = split3(delta);
-      w[0] = d3.x; w[1] = d3.y;
-      dof[qb][KSTEPS - 1] = __builtin_bit_cast(bf16x8, w);
-    }
-#pragma unroll
-    for (int ks = 0; ks < KSTEPS; ks++) { to_agpr(qf[qb][ks]); to_agpr(dof[qb][ks]); }
-  }
 
   // LDS-DMA plan (saddr form; K and V piece i share their lane mask); running source pointers, clamped to the last tile
   DmaPlan pl;
@@ -3162,6 +3149,33 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq4_kernel(AttnParams p) {
   issue(lds0);
   issue(lds0 + STG);
   issue(lds0 + 2 * STG);
+  // (the stationary rows are fetched BEHIND the first tiles' DMA: the two latencies overlap)
+  // stationary operands: Q / dO rows of this wave's 2 x 32 queries (B operands: lane = query), delta in slots 72..74 of the dO rows (split3)
+  int q[2];
+  bool qvalid[2];
+  float lse[2];
+  bf16x8 qf[2][KSTEPS], dof[2][KSTEPS];
+#pragma unroll
+  for (int qb = 0; qb < 2; qb++) {
+    q[qb] = bx * 256 + wave * 64 + qb * 32 + (lane & 31);
+    qvalid[qb] = q[qb] < p.Nq;
+    load_row_frags(qf[qb], p.Q + (long)b * p.q_bs + (long)q[qb] * p.q_ts + (long)h * p.q_hs, qvalid[qb], hi);
+    load_row_frags(dof[qb], p.dO + (long)b * p.o_bs + (long)q[qb] * p.o_ts + (long)h * p.o_hs, qvalid[qb], hi);
+    settle(qf[qb]);
+    settle(dof[qb]);
+    const long sidx = ((long)b * p.H + h) * p.Nq + q[qb];
+    lse[qb] = qvalid[qb] ? p.LSE[sidx] : 0.f;
+    const float delta = qvalid[qb] ? p.Delta[sidx] : 0.f;
+    if (hi == 1) {
+      u32x4 w = __builtin_bit_cast(u32x4, dof[qb][KSTEPS - 1]);
+      const uint2 d3 = split3(delta);
+      w[0] = d3.x; w[1] = d3.y;
+      dof[qb][KSTEPS - 1] = __builtin_bit_cast(bf16x8, w);
+    }
+#pragma unroll
+    for (int ks = 0; ks < KSTEPS; ks++) { to_agpr(qf[qb][ks]); to_agpr(dof[qb][ks]); }
+  }
+
   lds_dma_wait<12>();
   __syncthreads();
   {
@@ -3468,7 +3482,7 @@ extern "C" int pxa_attn_bwd(const pxa_attn_args* a, hipStream_t stream) {
     const int max_k = a->max_kv_len > 0 ? a->max_kv_len : p.Nk;
     // 4 = one wave per SIMD, 64 keys per wave (dense keys in whole 256-key blocks, whole 64-query tiles); PXA_ATTN_DKV=4 asks for it, the default takes it
     // where it applies and falls back to 2 elsewhere
-    const bool dkv4_ok = p.stats && !p.kv_start && p.Nk % 256 == 0 && p.Nk > 0 && p.Nq % BKV == 0 && p.Nq >= 2 * BKV;
+    const bool dkv4_ok = p.stats && !p.kv_start && p.Nk % BKV == 0 && p.Nk >= 256 && p.Nq % BKV == 0 && p.Nq >= 2 * BKV;
     if (dkv_mode >= 4 && !dkv4_ok) dkv_mode = 2;
     if (!env && dkv_mode == 2 && PXA_ATTN_DKV4_DEFAULT && dkv4_ok) dkv_mode = 5;     // 5 = 4 + second products on 16-row tiles (-2.5 %, profiles/r4_19_*)
     p.nx = dkv_mode >= 3 ? (max_k + 255) / 256 : (max_k + 127) / 128;

@@ -599,7 +599,7 @@ def test_attention_headline_shapes(ops, B, H, Nq, Nk):
 @pytest.mark.parametrize("mode,dqm", [("0", "0"), ("1", "1"), ("2", "1"), ("2", "0"), ("3", "1"), ("4", "1"), ("4", "4"), ("2", "4"), ("5", "4")])
 @pytest.mark.parametrize("B,H,Nq,Nk,lens", [(2, 3, 130, 77, None), (1, 2, 64, 1024, None), (2, 2, 520, 200, None), (1, 4, 96, 96, None),
                                              (3, 16, 160, 300, [300, 7, 64]), (2, 16, 1024, 1024, None), (1, 2, 200, 40, None),
-                                             (1, 2, 128, 256, None), (2, 3, 192, 512, None), (1, 2, 1024, 256, None), (1, 16, 2048, 1024, None)])
+                                             (1, 2, 128, 256, None), (2, 3, 192, 512, None), (1, 2, 1024, 256, None), (1, 16, 2048, 1024, None), (2, 2, 960, 960, None), (1, 3, 320, 576, None)])
 def test_attention_dkv_kernel_modes(ops, monkeypatch, mode, dqm, B, H, Nq, Nk, lens):
     """The three dK/dV kernels of csrc/attn.hip (PXA_ATTN_DKV: 0 = round-2 kernel, 1 = lse / delta through the matrix products + three-stage ring,
     2 = + hand-placed software pipeline with asm LDS reads, 3 = 512-thread workgroups whose two waves per SIMD alternate matrix and softmax phases

@@ -32,7 +32,7 @@ def check():
     bad = 0
     g = torch.Generator(device=dev).manual_seed(0)
     tol = 1e-3 if OPD == torch.float16 else 8e-3
-    for B, H, Nq, Nk, sc in [(1, 2, 128, 256, 1.0), (2, 3, 192, 512, 1.0), (1, 2, 1024, 256, 1.0), (2, 16, 1024, 1024, 1.0), (1, 4, 4096, 1024, 2.0), (1, 16, 256, 4096, 1.0)]:
+    for B, H, Nq, Nk, sc in [(1, 2, 128, 256, 1.0), (2, 3, 192, 512, 1.0), (1, 2, 1024, 256, 1.0), (2, 16, 1024, 1024, 1.0), (1, 4, 4096, 1024, 2.0), (1, 16, 256, 4096, 1.0), (2, 2, 960, 960, 1.0), (1, 3, 320, 576, 1.0)]:
         C = H * 72
         q = (torch.randn(B, Nq, C, device=dev, generator=g) * sc).to(OPD)
         k = (torch.randn(B, Nk, C, device=dev, generator=g) * sc).to(OPD)
