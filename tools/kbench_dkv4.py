@@ -5,6 +5,7 @@ import os
 import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
+from box_sampler import Sampler
 from pixart_sigma_amd import ops
 
 dev, OPD = "cuda", ops.BF16
@@ -132,14 +133,15 @@ def time_dq():
         for _ in range(10):
             fn()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(60):
-            fn()
-        e1.record()
-        e1.synchronize()
+        with Sampler() as box:
+            e0.record()
+            for _ in range(60):
+                fn()
+            e1.record()
+            e1.synchronize()
         t = e0.elapsed_time(e1) / 60 * 1e-3
         outs[mode] = dqkv[:, :D].clone()
-        print(f"dQ kernel alone B16 H16 N4096 PXA_ATTN_DQ={mode} lib={os.environ.get('PXA_LIB_PATH', 'default')}: {t * 1e3:7.3f} ms {fl / t / 1e12:7.1f} TF/s", flush=True)
+        print(f"dQ kernel alone B16 H16 N4096 PXA_ATTN_DQ={mode} lib={os.environ.get('PXA_LIB_PATH', 'default')}: {t * 1e3:7.3f} ms {fl / t / 1e12:7.1f} TF/s  {box.summary()}", flush=True)
     print(f"full grid B16: dq4 vs dq2 rel-L2 {rel(outs['4'].float(), outs['1'].float()):.2e}, finite {torch.isfinite(outs['4'].float()).all().item()}", flush=True)
     del os.environ["PXA_ATTN_BWD_NO_PREPASS"], os.environ["PXA_ATTN_DQ"]
 
@@ -164,13 +166,14 @@ def timeit():
         for _ in range(10):
             fn()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(60):
-            fn()
-        e1.record()
-        e1.synchronize()
+        with Sampler() as box:
+            e0.record()
+            for _ in range(60):
+                fn()
+            e1.record()
+            e1.synchronize()
         t = e0.elapsed_time(e1) / 60 * 1e-3
-        print(f"dK/dV kernel alone B16 H16 N4096 PXA_ATTN_DKV={mode} lib={os.environ.get('PXA_LIB_PATH', 'default')}: {t * 1e3:7.3f} ms {fl / t / 1e12:7.1f} TF/s", flush=True)
+        print(f"dK/dV kernel alone B16 H16 N4096 PXA_ATTN_DKV={mode} lib={os.environ.get('PXA_LIB_PATH', 'default')}: {t * 1e3:7.3f} ms {fl / t / 1e12:7.1f} TF/s  {box.summary()}", flush=True)
     del os.environ["PXA_ATTN_BWD_NO_PREPASS"]
 
 

@@ -6,6 +6,7 @@ import os
 import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
+from box_sampler import Sampler
 from pixart_sigma_amd import ops
 
 dev = "cuda"
@@ -50,7 +51,11 @@ def check():
         o2, l2 = run_fwd(q, k, v, B, H, Nq, Nk, "0")
         ro, rl = ref(q, k, v, B, H, Nq, Nk)
         e4, e2, el4, el2 = rel(o4.float(), ro), rel(o2.float(), ro), (l4 - rl).abs().max().item(), (l2 - rl).abs().max().item()
-        ok = e4 < max(tol, 1.3 * e2) and el4 < max(2e-3, 1.5 * el2) and torch.isfinite(o4.float()).all().item()
+        if OPD == torch.float16 and sc > 1:     # the folded scale rounds the query operand once more; its effect grows with the score level (|c S| ~ 400 here)
+            ok = e4 < 2e-3 and el4 < 0.1         # - the bounds of tests/test_kernels_gpu.py::test_attention_fwd4_one_wave_per_simd
+        else:
+            ok = e4 < max(tol, 1.3 * e2) and el4 < max(2e-3, 1.5 * el2, 2e-5 * rl.abs().max().item())
+        ok = ok and torch.isfinite(o4.float()).all().item()
         bad += not ok
         print(f"B{B} H{H} Nq{Nq} Nk{Nk} x{sc}: fwd4 o {e4:.2e} lse {el4:.1e} | fwd2 o {e2:.2e} lse {el2:.1e} | fwd4 vs fwd2 {rel(o4.float(), o2.float()):.2e}  {'ok' if ok else 'FAIL'}", flush=True)
     # full grid: every workgroup of the B16 launch, per head against the two-wave kernel, and run-to-run reproducibility
@@ -89,13 +94,14 @@ def timeit():
         for _ in range(10):
             fn()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(100):
-            fn()
-        e1.record()
-        e1.synchronize()
+        with Sampler() as box:
+            e0.record()
+            for _ in range(100):
+                fn()
+            e1.record()
+            e1.synchronize()
         t = e0.elapsed_time(e1) / 100 * 1e-3
-        print(f"attn fwd self B16 H16 N4096 PXA_ATTN_FWD4={mode} lib={os.environ.get('PXA_LIB_PATH', 'default')} qk_scale={qs:g}: {t * 1e3:7.3f} ms {fl / t / 1e12:7.1f} TF/s", flush=True)
+        print(f"attn fwd self B16 H16 N4096 PXA_ATTN_FWD4={mode} lib={os.environ.get('PXA_LIB_PATH', 'default')} qk_scale={qs:g}: {t * 1e3:7.3f} ms {fl / t / 1e12:7.1f} TF/s  {box.summary()}", flush=True)
 
 
 def trace():
