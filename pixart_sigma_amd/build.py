@@ -35,7 +35,7 @@ def _hipcc():
 
 def _digest(path, extra=()):
     h = hashlib.sha256()
-    for p in [path, os.path.join(CSRC, "common.h"), os.path.join(INCLUDE, "pixart_hip.h")]:
+    for p in [path, os.path.join(CSRC, "common.h"), os.path.join(CSRC, "gemm_params.h"), os.path.join(INCLUDE, "pixart_hip.h")]:
         with open(p, "rb") as f:
             h.update(f.read())
     h.update(" ".join([*FLAGS, *PER_FILE_FLAGS.get(os.path.basename(path), []), *extra]).encode())

@@ -10,6 +10,7 @@
 // k-strided operands sit as [64][128+32] and are read with ds_read_b64_tr_b16 (hardware transpose).
 #include <atomic>
 #include "common.h"
+#include "gemm_params.h"
 #include "../../include/pixart_hip.h"
 #include <cstdlib>
 #include <cstring>
@@ -22,25 +23,6 @@ constexpr int KC_BYTES = 128 * BK * 2;       // 16384
 constexpr int RC_STRIDE = (128 + 32) * 2;    // 320 B per k-row (pad: 4 tr-read rows hit disjoint banks)
 constexpr int RC_BYTES = BK * RC_STRIDE;     // 20480
 
-struct GemmParams {
-  const bf16_t* A; const bf16_t* B; int lda, ldb;
-  int M, N, K;
-  const float* bias; const bf16_t* aux; int ldaux;
-  bf16_t* out; bf16_t* out2; int ldo;
-  float* outf; int ldf;
-  int act, accumulate, k_per_split, tile_hint, split, sched_slot;
-  float* slab;
-  float* colsum;   // optional [PXA_COLSUM_SLOTS][colsum_stride] partials: += column sums of the bf16 output, staged epilogue only
-  long colsum_stride;
-  int k_seg;       // segmented-K A operand (implicit 3x3 convolution, layout NT): A[m][k] = A[m*lda + k + (k / k_seg) * seg_jump]
-  long seg_jump;   // = a_seg_stride - k_seg
-  int k_tap;       // > 0: tap-interleaved K order of the 3x3 convolution (see pxa_gemm_args): [k_tap/64 chunks][3 rows][3 taps][64]
-  long tap_s;      // = a_seg_stride (elements between kernel rows)
-  // GroupNorm statistics of an implicit-convolution output (persistent SEG instances, EPI 5 / 6): per-channel sum and sum of squares of
-  // the bf16 output over the INTERIOR pixels of each image, per QUAD of adjacent channels (GroupNorm groups are multiples of 4 channels
-  // wide), added into gn_part[slot][image][N/4][2] (slot = 128-row block % PXA_COLSUM_SLOTS)
-  float* gn_part; int gn_img_rows, gn_rp, gn_h, gn_w, gn_B; float gn_inv_rp;
-};
 
 // ---- global -> registers (4 x 16 B per thread per operand tile), zero-filled out of bounds
 template <bool KC>
@@ -1444,6 +1426,9 @@ int launch_glds(GemmParams p, int split, hipStream_t s) {
     constexpr int LY = LAYOUT == 2 ? 0 : LAYOUT;
     static const bool no_half = getenv("PXA_GEMM_NO_HALF_ITEMS") != nullptr;   // A/B: pad the remainder column to a full tile
     const bool hc = pers_halfcol(p.N) && !no_half;
+    if constexpr (LAYOUT == 0) {                          // the one-wave-per-SIMD NT kernel (gemm_nt4.hip) where it applies
+      if (p.act == 0 && !p.colsum) { GemmParams q = p; q.split = 1; const int rc = pxa_gemm_nt4_launch(q, s); if (rc <= 0) return rc; }
+    }
     if (p.act == 0 && !p.colsum) return hc ? launch_pers<LY, 0, 2>(p, 1, s) : launch_pers<LY, 0, 0>(p, 1, s);
     if (p.act == 3 && !p.colsum) return launch_pers<LY, 1, 0>(p, 1, s);      // fc1 forward: N = 4608, no remainder column
     if (p.act == 4 && p.colsum) return hc ? launch_pers<LY, 2, 2>(p, 1, s) : launch_pers<LY, 2, 0>(p, 1, s);
