@@ -7,15 +7,20 @@
 //   8 x 8 (8 x 4) accumulator tiles of v_mfma_f32_16x16x32 = 256 (128) registers, ALL in the accumulator half of the 512-register file ("+a" constraints:
 //   every MFMA is inline asm, as in the one-wave attention kernels of attn.hip); the arch half holds two sets of operand fragments (8 A + 8 B row
 //   fragments of one k-unit each) so that the reads of unit u+1 run under the MFMAs of unit u.
-//   k-units of 32 in a 4-slot LDS ring (A image 256 rows x 64 B + B image 256 rows x 64 B = 32 KiB per slot), filled by LDS-DMA four units ahead as ONE
-//   continuous stream across the workgroup's items (the next item's first units arrive under this item's last MFMAs and its epilogue);
-//   one barrier per k-unit: at the top of unit u every wave has finished reading unit u (it did so during u-1) and unit u+1 has landed, so the body is
-//   64 back-to-back MFMAs with the 16 fragment reads of u+1 in their first half and the 8 DMA pieces of u+4 (into the slot unit u just freed) in the second.
-//   Per MFMA: 0.25 LDS reads (ping-pong kernel: 0.375), 1/64 barrier (1/16).
+//   k-units of 32 in a 4-slot LDS ring (A image 256 rows x 64 B + B image 256 rows x 64 B = 32 KiB per slot), filled by LDS-DMA as ONE continuous stream
+//   across the workgroup's items (the next item's first units arrive under this item's last MFMAs and its epilogue), in LINE PAIRS (see `unit`): the two
+//   64-byte halves of an operand line - units 2v and 2v+1 of the same rows - are fetched by consecutive instructions so that the texture cache sends the L2 one
+//   request per line; the kernel is bound by the rate at which operand bytes reach the CU, and that rate is 20 % higher with whole lines.
+//   Two barriers per two units (the ping-pong kernel: eight), 0.25 LDS reads per MFMA (0.375).
+//   Measured (profiles/r4_30_nt4_pairs_midbarrier.txt, one box, bf16): qkv 0.437 ms (ping-pong kernel 0.47-0.51, vendor library 0.474), N = K = 1152
+//   projections 0.146 (0.167, 0.152), fc1 shape without GELU 0.557 (0.589, 0.510), fc2 shape 0.615 (0.604, 0.523): ahead of the vendor's kernel at the two
+//   shapes with few items per CU, 9-17 % behind it at the MLP shapes, where its register-staged pipeline keeps whole lines AND a deeper look-ahead than 128 KiB
+//   of ring allow an LDS-DMA stream (probe/gemm_nt4_regstaged.hip: the same idea rebuilt here, parity-green, slower - the experiments and what bounds each).
 // Epilogue: accumulators -> (+ bias) -> 16-bit -> the wave's private 8 KiB staging slice (XOR-swizzled) -> whole 256-byte row segments, 32 rows at a time;
 // the stores drain under the next item's first units (counted vmcnt: they retire in issue order behind the units already in flight).
 // Items: XCD-aware order as in gemm.hip (an XCD's 32 workgroups cover 8 m-tiles x 4 n-tiles per round), static persistent split - `b, b + G, ...`.
-// Takes: M % 256 == 0, N % 128 == 0, K % 128 == 0, K >= 256, act 0; everything else stays with gemm.hip.  PXA_GEMM_NT4 = 0 / 1 (A/B).
+// Takes: M % 256 == 0 (>= 2048), N % 128 == 0 (>= 256), K % 128 == 0 (>= 256), act 0, 16-bit output only; by default K <= 2304.  Everything else stays with
+// gemm.hip.  PXA_GEMM_NT4 = 0 / 1: never / every call it can take (A/B).
 #include "common.h"
 #include "gemm_params.h"
 #include <cstdlib>
@@ -50,6 +55,9 @@ template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_wai
 
 constexpr int NT4_SLOT = 32768, NT4_RING = 4, NT4_STG = 8192;
 constexpr int NT4_LDS = NT4_RING * NT4_SLOT + 4 * NT4_STG;          // 163,840 B: the CU's whole LDS, one workgroup per CU
+#ifndef NT4_PAIRS
+#define NT4_PAIRS 1          // 1: the LDS-DMA stream in line pairs (below); 0: every unit fetches its own half lines (A/B builds)
+#endif
 #ifndef NT4_ABL
 #define NT4_ABL 0            // ablation builds (wrong results, timing only): 1 no LDS-DMA in the loop, 2 no fragment reads in the loop, 4 no epilogue stores
 #endif
@@ -125,7 +133,7 @@ __global__ __launch_bounds__(256, 1) void gemm_nt4_kernel(GemmParams p, int n_be
     constexpr int u = decltype(uc)::value;
     static_for<NDMA>([&](auto ic) { issue_piece(ic, u, cA + u * 64, cB + u * 64); });
   });
-  wait_vm<3 * NDMA>();
+  wait_vm<NT4_PAIRS ? 0 : 3 * NDMA>();
   __builtin_amdgcn_s_barrier();
   static_for<8 + TNB>([&](auto rc) { read_frag(rc, IntC<0>{}, 0); });
 
@@ -135,6 +143,41 @@ __global__ __launch_bounds__(256, 1) void gemm_nt4_kernel(GemmParams p, int n_be
     constexpr int U = decltype(uc)::value, CUR = U & 1, NXT = CUR ^ 1;
     constexpr bool FIRST = decltype(firstc)::value;
     constexpr int EXTRA = decltype(extrac)::value;
+    constexpr int NM = 8 * TNB, NR = 8 + TNB;
+    if constexpr (NT4_PAIRS) {
+      // LINE PAIRS.  The two 64-byte halves of a 128-byte operand line belong to units 2v and 2v+1; fetched a unit apart (the scheme below) they cost the L2 two
+      // requests per line and the kernel is bound by that request rate (profiles/r4_24_nt4_ablations.txt, r4_25*: 0.63 ms on the fc2 shape, 0.52 with the same
+      // bytes as whole lines).  Fetched by CONSECUTIVE instructions of a wave they merge in the texture cache - but a pair needs two free slots at once.  So:
+      // the fragment reads of unit u+1 open unit u (the register set of unit u-1 is free then); an EVEN unit follows them with lgkmcnt(0) + a barrier - now every
+      // wave holds units u and u+1 in registers, both slots are free - and issues the pair (u+4, u+5) under the rest of its MFMAs, 2.6 units ahead of its first
+      // read; an ODD unit opens with the counted wait for the pair (u+1, u+2) and the barrier that publishes it.  Two barriers per two units, as before.
+      constexpr bool ODD = (U & 1) != 0;
+      constexpr int RB = NR + 4;                                    // even units: the barrier sits behind MFMA RB - 1
+      constexpr int DSTEP = TNB == 8 ? 2 : 1;
+      const char *da = nullptr, *db = nullptr;
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");            // this unit's fragments
+      if constexpr (ODD) {
+        wait_vm<2 * NDMA + EXTRA>();                                // the pair (u + 1, u + 2) has landed (the pair issued in unit u - 1 may be in flight)
+        __builtin_amdgcn_s_barrier();
+      } else {
+        const int v = u + 4;
+        const bool cross = v >= nk;
+        da = cross ? nA + (size_t)(v - nk) * 64 : cA + (size_t)v * 64;
+        db = cross ? nB + (size_t)(v - nk) * 64 : cB + (size_t)v * 64;
+      }
+      static_for<NM>([&](auto tc) {
+        constexpr int t = decltype(tc)::value, i = t / TNB, j = t % TNB;
+        if constexpr (!ODD && t == RB) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); }
+        if constexpr (FIRST) mma0(acc[i][j], fb[CUR][j], fa[CUR][i]); else mma(acc[i][j], fb[CUR][j], fa[CUR][i]);
+        if constexpr (t < NR) read_frag(IntC<t>{}, IntC<NXT>{}, (U + 1) & 3);
+        if constexpr (!ODD && t >= RB && (t - RB) % DSTEP == 0 && (t - RB) / DSTEP < 2 * NDMA) {
+          constexpr int q = (t - RB) / DSTEP;                      // piece q / 2, line half q & 1 -> the slot of unit u / u + 1
+          issue_piece(IntC<q / 2>{}, U + (q & 1), da + (q & 1) * 64, db + (q & 1) * 64);
+        }
+      });
+      return;
+    }
+    // (NT4_PAIRS = 0, the first form: every unit fetches its own half lines three units ahead)
     // the DMA pieces this unit issues: unit u + 4 of the stream, into the slot unit u frees
     const bool cross = u + 4 >= nk;
     const char* da = cross ? nA + (size_t)(u + 4 - nk) * 64 : cA + (size_t)(u + 4) * 64;
@@ -142,7 +185,6 @@ __global__ __launch_bounds__(256, 1) void gemm_nt4_kernel(GemmParams p, int n_be
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");              // this unit's fragments (read during the previous unit)
     wait_vm<2 * NDMA + EXTRA>();                                    // unit u + 1 has landed (u + 2, u + 3 may be in flight)
     __builtin_amdgcn_s_barrier();
-    constexpr int NM = 8 * TNB, NR = 8 + TNB;
     constexpr int RSTEP = TNB == 8 ? 2 : 1;                         // a fragment read behind every RSTEP-th MFMA of the first half
     constexpr int D0 = TNB == 8 ? 33 : 14, DSTEP = TNB == 8 ? 4 : 3;
     static_for<NM>([&](auto tc) {
@@ -166,16 +208,23 @@ __global__ __launch_bounds__(256, 1) void gemm_nt4_kernel(GemmParams p, int n_be
 #pragma unroll
       for (int j = 0; j < TNB; j++) asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(bias4[j]) : "v"(bp + 16 * j) : "memory");
     }
-    if (idx == sx) {
-      unit(IntC<0>{}, IntC<true>{}, IntC<NBL>{}, 0);
-      unit(IntC<1>{}, IntC<false>{}, IntC<NBL>{}, 1);
-      unit(IntC<2>{}, IntC<false>{}, IntC<NBL>{}, 2);
+    if constexpr (NT4_PAIRS) {                                      // (first item: the prologue waited for everything, any allowance is safe - one code path)
+      unit(IntC<0>{}, IntC<true>{}, IntC<0>{}, 0);
+      unit(IntC<1>{}, IntC<false>{}, IntC<NST + NBL>{}, 1);         // behind the pair (2, 3): the previous item's stores, this item's bias loads, the pair (4, 5)
+      unit(IntC<2>{}, IntC<false>{}, IntC<0>{}, 2);
+      unit(IntC<3>{}, IntC<false>{}, IntC<0>{}, 3);
     } else {
-      unit(IntC<0>{}, IntC<true>{}, IntC<NST + NBL>{}, 0);
-      unit(IntC<1>{}, IntC<false>{}, IntC<NST + NBL>{}, 1);
-      unit(IntC<2>{}, IntC<false>{}, IntC<NST + NBL>{}, 2);
+      if (idx == sx) {
+        unit(IntC<0>{}, IntC<true>{}, IntC<NBL>{}, 0);
+        unit(IntC<1>{}, IntC<false>{}, IntC<NBL>{}, 1);
+        unit(IntC<2>{}, IntC<false>{}, IntC<NBL>{}, 2);
+      } else {
+        unit(IntC<0>{}, IntC<true>{}, IntC<NST + NBL>{}, 0);
+        unit(IntC<1>{}, IntC<false>{}, IntC<NST + NBL>{}, 1);
+        unit(IntC<2>{}, IntC<false>{}, IntC<NST + NBL>{}, 2);
+      }
+      unit(IntC<3>{}, IntC<false>{}, IntC<0>{}, 3);
     }
-    unit(IntC<3>{}, IntC<false>{}, IntC<0>{}, 3);
     for (int u = 4; u < nk; u += 4) {
       unit(IntC<0>{}, IntC<false>{}, IntC<0>{}, u);
       unit(IntC<1>{}, IntC<false>{}, IntC<0>{}, u + 1);
@@ -244,9 +293,11 @@ int launch_nt4(const GemmParams& p, int n_begin, int nt, hipStream_t s) {
 int pxa_gemm_nt4_launch(const GemmParams& p, hipStream_t stream) {
   const char* env = getenv("PXA_GEMM_NT4");                        // (read per call: tests and benches switch it inside one process)
 #ifndef PXA_GEMM_NT4_DEFAULT
-#define PXA_GEMM_NT4_DEFAULT 0
+#define PXA_GEMM_NT4_DEFAULT 1
 #endif
-  const bool on = env ? atoi(env) != 0 : PXA_GEMM_NT4_DEFAULT != 0;
+  // default: where it measured ahead of the ping-pong kernel (profiles/r4_30_nt4_pairs_midbarrier.txt: qkv -8 %, the three N = K = 1152 projections -12 %, the fc1
+  // shape -5 %; at K = 4608 - fc2 - it is 2 % behind and stays off).  PXA_GEMM_NT4 = 1: every call it can take, 0: none.
+  const bool on = env ? atoi(env) != 0 : (PXA_GEMM_NT4_DEFAULT != 0 && p.K <= 2304);
   if (!on) return 1;
   if (!p.out || p.outf || p.out2 || p.act != 0 || p.colsum || p.k_seg || p.gn_part || p.split > 1) return 1;
   if (p.M % 256 || p.N % 128 || p.K % 128 || p.K < 256 || p.N < 256 || p.M < 2048) return 1;

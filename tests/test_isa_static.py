@@ -20,7 +20,7 @@ def asm(tmp_path_factory):
     from pixart_sigma_amd import build as B
     out = {}
     td = tmp_path_factory.mktemp("isa")
-    for src in ("attn.hip", "gemm.hip"):
+    for src in ("attn.hip", "gemm.hip", "gemm_nt4.hip"):
         for tag, extra in (("bf16", []), ("f16", ["-DPXA_OPERAND_F16"])):
             if src == "gemm.hip" and tag == "f16":
                 continue
@@ -92,6 +92,34 @@ def test_one_wave_backward_kernels_keep_the_tile_loop_clean(asm, kernel, n32, n1
     assert not any("accvgpr" in o for o in ops)
     assert sum(o.startswith("v_mfma_f32_32x32x16") for o in ops) == n32 and sum(o.startswith("v_mfma_f32_16x16x32") for o in ops) == n16
     assert sum(o == "s_barrier" for o in ops) == 1
+
+
+@pytest.mark.parametrize("tnb,bias", [(8, 1), (8, 0), (4, 1), (4, 0)])
+@pytest.mark.parametrize("tag", ["bf16", "f16"])
+def test_nt4_gemm_register_ownership_and_waits(asm, tnb, bias, tag):
+    """gemm_nt4_kernel (one wave per SIMD NT GEMM): all 8 x TNB accumulator tiles in the accumulator half and NO scratch anywhere (an asynchronous load whose
+    destination the allocator spills is a wrong result); the steady-state loop of four k-units is exactly 4 x 8 x TNB MFMAs, 4 x (8 + TNB) fragment reads,
+    2 line pairs of LDS-DMA pieces and two barriers, with no register-file traffic; and the replay of its LDS waits finds every fragment waited for."""
+    import check_lds_waits as C
+    text = asm[("gemm_nt4.hip", tag)]
+    name = re.search(r"^(_Z\w*gemm_nt4_kernelILi%dELb%dE\w*):" % (tnb, bias), text, re.M).group(1)
+    body = text[text.index("\n" + name + ":"):]
+    body = body[:body.index(".Lfunc_end")]
+    assert "scratch_" not in body
+    meta = text[text.index(".amdhsa_kernel " + name):]
+    meta = meta[:meta.index(".end_amdhsa_kernel")]
+    assert int(re.search(r"\.amdhsa_accum_offset (\d+)", meta).group(1)) <= 256
+    lines = body.split("\n")
+    h = max(i for i, l in enumerate(lines) if "Inner Loop Header" in l)
+    end = next(i for i in range(h + 1, len(lines)) if re.search(r"s_cbranch_scc", lines[i]))
+    ops = [l.split()[0] for l in lines[h:end] if re.match(r"\s+[a-z]", l)]
+    assert not any("accvgpr" in o or o.startswith("v_mov") for o in ops)
+    assert sum(o.startswith("v_mfma_f32_16x16x32") for o in ops) == 4 * 8 * tnb
+    assert sum(o == "ds_read_b128" for o in ops) == 4 * (8 + tnb)
+    assert sum(o.startswith("global_load_lds") for o in ops) == 4 * (4 + tnb // 2)
+    assert sum(o == "s_barrier" for o in ops) == 4
+    r = C.check(text, "gemm_nt4_kernelILi%dELb%dE" % (tnb, bias), inflight_at_back_edge=True)
+    assert not r["errors"], r["errors"][:5]
 
 
 def test_m0_has_no_other_user(asm):

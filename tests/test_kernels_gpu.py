@@ -522,6 +522,28 @@ def test_gemm_nt_headline_shapes(ops, N, K, flavour):
     assert e < BF16_TOL
 
 
+@pytest.mark.parametrize("M,N,K,bias,strided", [(2048, 256, 256, True, False), (2048, 384, 256, True, False), (4096, 1152, 1152, True, False), (8192, 3456, 1152, True, True),
+                                                (65536, 1152, 1152, True, False), (16384, 4608, 1152, False, False), (16384, 1152, 4608, True, False),
+                                                (2304, 1280, 384, True, True), (65536, 256, 384, False, False)])
+def test_gemm_nt4_one_wave_per_simd(ops, monkeypatch, M, N, K, bias, strided):
+    """gemm_nt4_kernel (csrc/gemm_nt4.hip: one wave per SIMD, 128 x 128 per wave, LDS-DMA line pairs) forced on for every call it can take, against fp32 and
+    BIT FOR BIT against the eight-wave ping-pong kernel (same k order, same MFMA shape, same epilogue arithmetic): full and half-width items, 8 .. 144
+    k-units, fewer / more items than one round of the CUs, operands and outputs that are column slices of wider tensors, with and without bias (the
+    no-bias instance once re-used the registers of an in-flight dummy load), and run-to-run reproducibility of the persistent item stream."""
+    a = bf(_gpu_rnd(M, K + (64 if strided else 0), seed=1))[:, :K]
+    w, b = bf(_gpu_rnd(N, K, scale=K ** -0.5, seed=2)), (_gpu_rnd(N, seed=3) if bias else None)
+    outs = []
+    for mode in ("1", "1", "0"):
+        monkeypatch.setenv("PXA_GEMM_NT4", mode)
+        o = torch.full((M, N + (128 if strided else 0)), float("nan"), dtype=_opd(), device="cuda")[:, :N]
+        outs.append(ops.gemm(a, w, ops.NT, bias=b, out=o))
+    ref = a.float() @ w.float().t() + (b if bias else 0)
+    e4, e8 = rel_l2(outs[0].float(), ref), rel_l2(outs[2].float(), ref)
+    print(f"\n[NT4 {M}x{N}x{K} bias {bias} strided {strided}] rel-L2 {e4:.2e} (ping-pong kernel {e8:.2e}), bit-identical {torch.equal(outs[0], outs[2])}")
+    record_parity(f"gemm_nt4 {M}x{N}x{K} vs fp32", e4, BF16_TOL)
+    assert e4 < BF16_TOL and torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+
+
 @pytest.mark.parametrize("K,N,flavour", [(3456, 1152, "plain"), (1152, 1152, "plain"), (4608, 1152, "plain"), (1152, 4608, "mul_aux_colsum")])
 def test_gemm_nn_headline_shapes(ops, K, N, flavour):
     """dX = dY W at M = 65,536: qkv / proj / fc1 input gradients and the fc2 input gradient times the saved GELU' with the fused fc1
