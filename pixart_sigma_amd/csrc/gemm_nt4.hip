@@ -12,18 +12,21 @@
 //   64-byte halves of an operand line - units 2v and 2v+1 of the same rows - are fetched by consecutive instructions so that the texture cache sends the L2 one
 //   request per line; the kernel is bound by the rate at which operand bytes reach the CU, and that rate is 20 % higher with whole lines.
 //   Two barriers per two units (the ping-pong kernel: eight), 0.25 LDS reads per MFMA (0.375).
-//   Measured (profiles/r4_30_nt4_pairs_midbarrier.txt, one box, bf16): qkv 0.437 ms (ping-pong kernel 0.47-0.51, vendor library 0.474), N = K = 1152
-//   projections 0.146 (0.167, 0.152), fc1 shape without GELU 0.557 (0.589, 0.510), fc2 shape 0.615 (0.604, 0.523): ahead of the vendor's kernel at the two
-//   shapes with few items per CU, 9-17 % behind it at the MLP shapes, where its register-staged pipeline keeps whole lines AND a deeper look-ahead than 128 KiB
-//   of ring allow an LDS-DMA stream (probe/gemm_nt4_regstaged.hip: the same idea rebuilt here, parity-green, slower - the experiments and what bounds each).
+//   Measured, repeated launches of one shape (profiles/r4_30_nt4_pairs_midbarrier.txt, one box, bf16): qkv 0.437 ms (ping-pong kernel 0.47-0.51, vendor
+//   library 0.474), N = K = 1152 projections 0.146 (0.167, 0.152), fc1 shape without GELU 0.557 (0.589, 0.510), fc2 shape 0.615 (0.604, 0.523).  With cold
+//   operands (rotating sets, profiles/r4_32_nt4_rotating.txt): qkv 0.455-0.461 (0.469, 0.489), projections 0.181 (0.183, 0.169).  At the MLP shapes the
+//   vendor's register-staged pipeline keeps whole lines AND a deeper look-ahead than 128 KiB of ring allow an LDS-DMA stream (probe/gemm_nt4_regstaged.hip:
+//   the same idea rebuilt here, parity-green, slower - the experiments and what bounds each).
 // Epilogue: accumulators -> (+ bias) -> 16-bit -> the wave's private 8 KiB staging slice (XOR-swizzled) -> whole 256-byte row segments, 32 rows at a time;
 // the stores drain under the next item's first units (counted vmcnt: they retire in issue order behind the units already in flight).
 // Items: XCD-aware order as in gemm.hip (an XCD's 32 workgroups cover 8 m-tiles x 4 n-tiles per round), static persistent split - `b, b + G, ...`.
-// Takes: M % 256 == 0 (>= 2048), N % 128 == 0 (>= 256), K % 128 == 0 (>= 256), act 0, 16-bit output only; by default K <= 2304.  Everything else stays with
-// gemm.hip.  PXA_GEMM_NT4 = 0 / 1: never / every call it can take (A/B).
+// Takes: M % 256 == 0 (>= 2048), N % 128 == 0 (>= 256), K % 128 == 0 (>= 256), act 0, 16-bit output only.  An A/B partner, OFF by default (see
+// pxa_gemm_nt4_launch: its bench advantage does not survive cold operands); PXA_GEMM_NT4 = 1 turns it on for every call it can take.
 #include "common.h"
 #include "gemm_params.h"
 #include <cstdlib>
+#include <map>
+#include <mutex>
 
 namespace {
 using namespace pxa;
@@ -268,19 +271,27 @@ __global__ __launch_bounds__(256, 1) void gemm_nt4_kernel(GemmParams p, int n_be
   wait_vm<0>();                                                     // the re-fetches behind the last item must not land in a later workgroup's LDS
 }
 
+// per device: the kernel's LDS request granted?  and the CU count (-1: this part cannot run it - the caller goes on to the other kernels)
+int nt4_device_cus(const void* fn) {
+  static std::mutex mu;
+  static std::map<std::pair<int, const void*>, int> state;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return -1;
+  std::lock_guard<std::mutex> lk(mu);
+  auto it = state.find({dev, fn});
+  if (it != state.end()) return it->second;
+  int cus = -1;
+  hipDeviceProp_t prop;
+  if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, NT4_LDS) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+  else (void)hipGetLastError();
+  state[{dev, fn}] = cus;
+  return cus;
+}
+
 template <int TNB, bool BIAS>
 int launch_nt4(const GemmParams& p, int n_begin, int nt, hipStream_t s) {
-  static bool attr_set = false;
-  static int n_cu = 0;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt4_kernel<TNB, BIAS>), hipFuncAttributeMaxDynamicSharedMemorySize, NT4_LDS);
-    if (e != hipSuccess) { pxa_set_error("hipFuncSetAttribute(gemm_nt4<%d>): %s", TNB, hipGetErrorString(e)); return -3; }
-    int dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) { pxa_set_error("gemm_nt4: device query failed"); return -3; }
-    n_cu = prop.multiProcessorCount;
-    attr_set = true;
-  }
+  const int n_cu = nt4_device_cus(reinterpret_cast<const void*>(gemm_nt4_kernel<TNB, BIAS>));
+  if (n_cu < 8) return 1;
   const int T = (p.M / 256) * nt;
   int g = (T < n_cu ? T : n_cu) & ~7;
   if (g < 8) g = 8;
@@ -293,11 +304,13 @@ int launch_nt4(const GemmParams& p, int n_begin, int nt, hipStream_t s) {
 int pxa_gemm_nt4_launch(const GemmParams& p, hipStream_t stream) {
   const char* env = getenv("PXA_GEMM_NT4");                        // (read per call: tests and benches switch it inside one process)
 #ifndef PXA_GEMM_NT4_DEFAULT
-#define PXA_GEMM_NT4_DEFAULT 1
+#define PXA_GEMM_NT4_DEFAULT 0
 #endif
-  // default: where it measured ahead of the ping-pong kernel (profiles/r4_30_nt4_pairs_midbarrier.txt: qkv -8 %, the three N = K = 1152 projections -12 %, the fc1
-  // shape -5 %; at K = 4608 - fc2 - it is 2 % behind and stays off).  PXA_GEMM_NT4 = 1: every call it can take, 0: none.
-  const bool on = env ? atoi(env) != 0 : (PXA_GEMM_NT4_DEFAULT != 0 && p.K <= 2304);
+  // OFF by default.  The repeated-launch bench shows this kernel 8-12 % ahead of the ping-pong kernel at the qkv / projection shapes (and ahead of the vendor
+  // library there), but that bench serves every launch its operands from L2 / MALL: with rotating operand sets (tools/kbench_nt4.py KB_NT4_ROTATE=6,
+  // profiles/r4_32_nt4_rotating.txt) the gain is 2-3 % at qkv and nothing at the projections, and the training step measured the same with and without it
+  // (profiles/r4_31_step_ab_nt4.txt: 425.5-426.2 / 425.2-426.0 ms).  PXA_GEMM_NT4 = 1: every call it can take (tests, benches), 0: none.
+  const bool on = env ? atoi(env) != 0 : PXA_GEMM_NT4_DEFAULT != 0;
   if (!on) return 1;
   if (!p.out || p.outf || p.out2 || p.act != 0 || p.colsum || p.k_seg || p.gn_part || p.split > 1) return 1;
   if (p.M % 256 || p.N % 128 || p.K % 128 || p.K < 256 || p.N < 256 || p.M < 2048) return 1;
@@ -305,6 +318,10 @@ int pxa_gemm_nt4_launch(const GemmParams& p, hipStream_t stream) {
   if ((long)256 * p.lda * 2 >= (1L << 32) || (long)256 * p.ldb * 2 >= (1L << 32)) return 1;     // 32-bit per-lane DMA offsets
   if (p.bias && (reinterpret_cast<uintptr_t>(p.bias) & 15)) return 1;
   const int nf = p.N / 256;
+  if (p.N % 256) {                                                  // the remainder column's kernel must be runnable too before anything is launched
+    const void* f4 = p.bias ? reinterpret_cast<const void*>(gemm_nt4_kernel<4, true>) : reinterpret_cast<const void*>(gemm_nt4_kernel<4, false>);
+    if (nt4_device_cus(f4) < 8) return 1;
+  }
   int rc = p.bias ? launch_nt4<8, true>(p, 0, nf, stream) : launch_nt4<8, false>(p, 0, nf, stream);
   if (rc) return rc;
   if (p.N % 256) rc = p.bias ? launch_nt4<4, true>(p, nf * 256, 1, stream) : launch_nt4<4, false>(p, nf * 256, 1, stream);

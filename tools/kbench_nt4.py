@@ -55,17 +55,26 @@ def timeit():
     if os.environ.get("KB_NT4_SHAPES"):
         shapes = [s for s in shapes if s[0] in os.environ["KB_NT4_SHAPES"].split(",")]
     for name, M, N, K in shapes:
-        a = torch.randn(M, K, device=dev).to(OPD)
-        b = (torch.randn(N, K, device=dev) * K ** -0.5).to(OPD)
+        ROT = int(os.environ.get("KB_NT4_ROTATE", "1"))           # > 1: cycle through ROT operand / output sets, so that no launch finds its own data in L2 / MALL
+        sets = [(torch.randn(M, K, device=dev).to(OPD), (torch.randn(N, K, device=dev) * K ** -0.5).to(OPD), torch.empty(M, N, dtype=OPD, device=dev)) for _ in range(ROT)]
+        a, b, out = sets[0]
         bias = torch.randn(N, device=dev)
-        out = torch.empty(M, N, dtype=OPD, device=dev)
         fl = 2.0 * M * N * K
+        it = [0]
         for mode in os.environ.get("KB_NT4_MODES", "0,1,0,1,lib").split(","):
+            def nxt():
+                it[0] += 1
+                return sets[it[0] % ROT]
             if mode == "lib":
-                fn = lambda: torch.addmm(bias.to(OPD), a, b.t(), out=out)
+                bb = bias.to(OPD)
+                def fn():
+                    a_, b_, o_ = nxt()
+                    torch.addmm(bb, a_, b_.t(), out=o_)
             else:
                 os.environ["PXA_GEMM_NT4"] = mode
-                fn = lambda: ops.gemm(a, b, ops.NT, bias=bias, out=out)
+                def fn():
+                    a_, b_, o_ = nxt()
+                    ops.gemm(a_, b_, ops.NT, bias=bias, out=o_)
             for _ in range(5):
                 fn()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -76,7 +85,7 @@ def timeit():
                 e1.record()
                 e1.synchronize()
             t = e0.elapsed_time(e1) / 50 * 1e-3
-            print(f"[{os.path.basename(os.environ.get('PXA_LIB_PATH', 'default'))}] NT {name} M{M} N{N} K{K} {'vendor library (addmm)' if mode == 'lib' else 'PXA_GEMM_NT4=' + mode}: {t * 1e3:7.3f} ms {fl / t / 1e12:7.1f} TF/s  {box.summary()}", flush=True)
+            print(f"[{os.path.basename(os.environ.get('PXA_LIB_PATH', 'default'))} rot {ROT}] NT {name} M{M} N{N} K{K} {'vendor library (addmm)' if mode == 'lib' else 'PXA_GEMM_NT4=' + mode}: {t * 1e3:7.3f} ms {fl / t / 1e12:7.1f} TF/s  {box.summary()}", flush=True)
 
 
 if __name__ == "__main__":
