@@ -30,9 +30,10 @@ sys.path.insert(0, ROOT)
 
 D, H, DFF, DEPTH, LTXT = 1152, 16, 4608, 28, 300
 MFMA_PEAK = 2.5e15   # dense bf16, MI355X (MI355X_MICROARCH.md)
-PMC_FILES = ["profiles/r4final_pmc_attention.json", "profiles/r03s_pmc_attention.json", "profiles/r03l_pmc_attention.json", "profiles/r03c_pmc_attention.json", "profiles/r02f_pmc_attention.json", "profiles/r02_pmc_attention.json"]   # newest first (tools/pmc_query.py --json)
-DOMINANT = "attn_bwd_dkv5_kernel"     # the step's largest kernel by total time (profiles/r4final_step_kernel_stats.csv: 28 self-attention launches; round 4: the
-                                      # one-wave-per-SIMD dK/dV kernel with 16-row second products, 256 keys per workgroup - attn_bwd_dkv2_kernel<1> until round 3)
+PMC_FILES = ["profiles/r4final_pmc_attention.json", "profiles/r4_18_pmc_attention.json", "profiles/r03s_pmc_attention.json", "profiles/r03l_pmc_attention.json", "profiles/r03c_pmc_attention.json", "profiles/r02f_pmc_attention.json", "profiles/r02_pmc_attention.json"]   # newest first (tools/pmc_query.py --json)
+DOMINANT = "attn_bwd_dkv4_kernel"     # the step's largest kernel by total time (profiles/r4final_step_kernel_stats.csv: 28 self-attention launches; round 4: the
+                                      # one-wave-per-SIMD dK/dV kernel, 256 keys per workgroup - attn_bwd_dkv2_kernel<1> until round 3; its 16-row variant dkv5 is
+                                      # faster alone and slower in the step, profiles/r4_34_step_ab_attention.txt)
 
 
 def pmc_traffic(kernel_substr, grid):
@@ -105,7 +106,7 @@ def kernel_rooflines(B, N):
     res["attn_bwd_self"] = dict(flops=10.0 * B * N * N * D, seconds=t)     # delta + dQ + dK/dV kernels, algorithmic 2.5x forward
     # The dominant kernel by itself, one event pair around EACH launch (no subtraction).  PXA_ATTN_BWD_NO_PREPASS makes
     # pxa_attn_bwd skip its delta / stats pre-pass - the workspace still holds this input's rows from the call above - and dq = NULL skips the dQ
-    # kernel, so each call is exactly one attn_bwd_dkv5_kernel launch.  Its contract needs S, dP, dV, dK = 4 of the 2 N^2 d products.
+    # kernel, so each call is exactly one attn_bwd_dkv4_kernel launch.  Its contract needs S, dP, dV, dK = 4 of the 2 N^2 d products.
     os.environ["PXA_ATTN_BWD_NO_PREPASS"] = "1"
     try:
         one = lambda: ops.attention_bwd(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], a, da, lse, delta, None, dqkv[:, D:2 * D], dqkv[:, 2 * D:],  # noqa: E731

@@ -3484,7 +3484,10 @@ extern "C" int pxa_attn_bwd(const pxa_attn_args* a, hipStream_t stream) {
     // where it applies and falls back to 2 elsewhere
     const bool dkv4_ok = p.stats && !p.kv_start && p.Nk % BKV == 0 && p.Nk >= 256 && p.Nq % BKV == 0 && p.Nq >= 2 * BKV;
     if (dkv_mode >= 4 && !dkv4_ok) dkv_mode = 2;
-    if (!env && dkv_mode == 2 && PXA_ATTN_DKV4_DEFAULT && dkv4_ok) dkv_mode = 5;     // 5 = 4 + second products on 16-row tiles (-2.5 %, profiles/r4_19_*)
+    // default: the one-wave kernel with ALL products on the 32-row shape (4).  Its variant with the second products on 16-row tiles (5) is 2.5 % faster alone
+    // (profiles/r4_19_*) and 2-3 ms per step SLOWER inside the training step (profiles/r4_34_step_ab_attention.txt, one box, alternating: 411.6 / 412.2 ms
+    // against 415.2 / 413.3) - the step decides; 4 is also bit-identical to the two-wave kernel.
+    if (!env && dkv_mode == 2 && PXA_ATTN_DKV4_DEFAULT && dkv4_ok) dkv_mode = 4;
     p.nx = dkv_mode >= 3 ? (max_k + 255) / 256 : (max_k + 127) / 128;
     PXA_CHECK((long)p.nx * p.H * p.B < (1L << 31), "pxa_attn_bwd: grid too large");
     if (p.nx > 0) {
