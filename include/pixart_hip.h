@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define PXA_ABI_VERSION 5
+#define PXA_ABI_VERSION 6
 /* Kernels that fuse a bias-gradient column sum add into one of PXA_COLSUM_SLOTS partial rows ([slot][stride] fp32, caller-zeroed),
  * chosen per sample / row tile, so no address sees thousands of atomics; pxa_colsum_reduce folds the partials into the gradient. */
 #define PXA_COLSUM_SLOTS 16
@@ -85,6 +85,14 @@ typedef struct {
 /* Upper bound of the split-K workspace (in floats) pxa_gemm may use for an (M, N) fp32-accumulate output. */
 long pxa_gemm_splitk_ws_elems(int M, int N);
 int pxa_gemm(const pxa_gemm_args* args, hipStream_t stream);
+/* How the persistent 256 x 256 kernels of the token GEMMs (NT / NN, 16-bit output) hand their items to the workgroups:
+ *   0 (default)  static split - workgroup b takes items b, b + #CUs, ... : the fastest when the GEMM owns the GPU (training step on one GPU: -4.7 ms of 434,
+ *                profiles/r4_38_step_ab_gemm_sched.txt);
+ *   1            dynamic per-XCD cursors - a workgroup that starts late (a collective of the data-parallel all-reduce holds its CU: the reference overlaps
+ *                DDP's bucket all-reduce with the backward, train_scripts/train.py:128-133 through accelerate) leaves its items to the others instead of
+ *                doubling the kernel's time (profiles/r03*_contention*).  The data-parallel runtime (pixart_sigma_amd/dp.py) switches it on for world size > 1.
+ * Process-wide; returns the previous setting.  Environment overrides for A/B runs: PXA_GEMM_STATIC=1 / PXA_GEMM_DYNAMIC=1 (read at the first GEMM). */
+int pxa_gemm_set_dynamic_items(int on);
 
 /* ---------------------------------------------------------------------------------------------- adaLN-single rows
  * x' = x + gate*u (u bf16, gate per sample; either may be NULL), optional bf16 copy of x' (cross-attn input),

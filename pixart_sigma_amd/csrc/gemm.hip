@@ -1365,6 +1365,18 @@ __global__ __launch_bounds__(512) void gemm_pers_kernel(GemmParams p) {
     for (int k = 0; k < 9; k++) sched[k] = 0u;         // last workgroup out: the slot is clean for a later launch
 }
 
+// item hand-out of the persistent NT / NN kernels: pxa_gemm_set_dynamic_items (include/pixart_hip.h); -1 = not set yet -> the environment, else static
+static std::atomic<int> g_dynamic_items{-1};
+static inline bool dynamic_items() {
+  int v = g_dynamic_items.load(std::memory_order_relaxed);
+  if (v < 0) {
+    v = getenv("PXA_GEMM_DYNAMIC") != nullptr && getenv("PXA_GEMM_STATIC") == nullptr ? 1 : 0;
+    int expect = -1;
+    g_dynamic_items.compare_exchange_strong(expect, v);
+    v = g_dynamic_items.load(std::memory_order_relaxed);
+  }
+  return v != 0;
+}
 static std::atomic<unsigned> g_launch_seq{0};          // cursor-slot round robin, shared by every instantiation of the persistent kernel
 // work items of the persistent kernel per k-slice (must match the kernel's own count)
 static inline bool pers_pairing(int M, int N) { (void)M; return N % 256 > 0 && N % 256 <= 128; }
@@ -1392,8 +1404,7 @@ int launch_pers(GemmParams p, int split, hipStream_t s) {
     attr_set_pp = true;
   }
   const int tiles = pers_tiles(p.M, p.N, RM) * split;
-  static const bool force_static = getenv("PXA_GEMM_STATIC") != nullptr;   // A/B experiments (tools/contention_test.py)
-  p.sched_slot = force_static ? -1 : (int)(g_launch_seq.fetch_add(1u) & 63u);
+  p.sched_slot = dynamic_items() ? (int)(g_launch_seq.fetch_add(1u) & 63u) : -1;
   hipLaunchKernelGGL((gemm_pers_kernel<LAYOUT, EPI, RM, SEG>), dim3(tiles < n_cu ? tiles : n_cu), dim3(512), LDSP, s, p);
   PXA_LAUNCH_CHECK();
   return 0;
@@ -1599,6 +1610,12 @@ extern "C" int pxa_gemm(const pxa_gemm_args* a, hipStream_t stream) {
 }
 
 extern "C" long pxa_gemm_splitk_ws_elems(int M, int N) { return 16L * M * N; }
+
+extern "C" int pxa_gemm_set_dynamic_items(int on) {
+  const bool prev = dynamic_items();
+  if (getenv("PXA_GEMM_STATIC") == nullptr && getenv("PXA_GEMM_DYNAMIC") == nullptr) g_dynamic_items.store(on ? 1 : 0);     // (an A/B environment override wins)
+  return prev ? 1 : 0;
+}
 
 #if GEMM_TRACE
 extern "C" int pxa_gemm_trace(unsigned long long* host_out) {       // 12 x 8 counters of the last traced launch

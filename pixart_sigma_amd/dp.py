@@ -37,6 +37,11 @@ class GradReducer:
         # PXA_DP_FORCE_COLLECTIVES=1: run the bucket collectives even in a one-rank group (a real RCCL all-reduce of every bucket from
         # the engine's hooks on a single GPU - the only multi-GPU code path a one-GPU box can execute; tests/test_training_runtime_gpu.py::test_bench_under_torchrun_forced_collectives)
         self.active = self.world > 1 or (dist.is_available() and dist.is_initialized() and os.environ.get("PXA_DP_FORCE_COLLECTIVES") == "1")
+        if self.active:
+            # bucket all-reduces will run beside the backward's GEMMs: their persistent kernels hand items out dynamically, so that a workgroup kept off its CU
+            # by a collective does not double the kernel's time (include/pixart_hip.h: pxa_gemm_set_dynamic_items; one GPU alone keeps the faster static split)
+            from . import lib as _lib
+            _lib.load().pxa_gemm_set_dynamic_items(1)
         self.bucket_dtype = bucket_dtype
         self.stage = torch.empty(store.total, dtype=bucket_dtype, device=store.device) if bucket_dtype not in (None, torch.float32) and self.active else None
         self.pending = []

@@ -1,6 +1,6 @@
 """What happens to the persistent GEMM when another kernel holds some CUs (the situation of an RCCL all-reduce overlapping the
 backward)?  A long-running 'hog' (an attention-forward launch with 32 workgroups looping over 2M keys) runs on a side stream while
-a train of fc1-shaped GEMMs is timed on the main stream.  Run twice: default (dynamic per-XCD item cursors) and PXA_GEMM_STATIC=1."""
+a train of fc1-shaped GEMMs is timed on the main stream.  Run twice: PXA_GEMM_DYNAMIC=1 (dynamic per-XCD item cursors: what the data-parallel runtime switches on) and default (static split)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -41,4 +41,4 @@ print(f"hog alone        : {e0.elapsed_time(e1):.1f} ms ({Nq // 128} workgroups)
 hog()
 t = train(40)
 torch.cuda.synchronize()
-print(f"beside the hog   : {t:.3f} ms per GEMM  ({'static' if os.environ.get('PXA_GEMM_STATIC') else 'dynamic'} item assignment)")
+print(f"beside the hog   : {t:.3f} ms per GEMM  ({'dynamic' if os.environ.get('PXA_GEMM_DYNAMIC') and not os.environ.get('PXA_GEMM_STATIC') else 'static'} item assignment)")
