@@ -544,6 +544,27 @@ def test_gemm_nt4_one_wave_per_simd(ops, monkeypatch, M, N, K, bias, strided):
     assert e4 < BF16_TOL and torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
 
 
+@pytest.mark.parametrize("layout", ["NT", "NN"])
+def test_gemm_item_schedulers_agree(ops, layout):
+    """The persistent token GEMMs hand their items out by static split (default on one GPU) or from per-XCD cursors (pxa_gemm_set_dynamic_items: what dp.py turns
+    on beside the bucket all-reduces): same items, same arithmetic - bit-identical outputs, full and half-width items, more items than CUs."""
+    from pixart_sigma_amd import lib
+    M, N, K = 16384, 1152, 1152
+    a, b = bf(_gpu_rnd(M, K, seed=1)), _gpu_rnd(N, seed=3)
+    w = bf(_gpu_rnd(N, K, scale=K ** -0.5, seed=2)) if layout == "NT" else bf(_gpu_rnd(K, N, scale=K ** -0.5, seed=2))
+    L = lib.load()
+    prev = L.pxa_gemm_set_dynamic_items(0)
+    try:
+        o_static = ops.gemm(a, w, getattr(ops, layout), bias=b).clone()
+        assert L.pxa_gemm_set_dynamic_items(1) == 0
+        o_dyn = ops.gemm(a, w, getattr(ops, layout), bias=b).clone()
+        assert L.pxa_gemm_set_dynamic_items(0) == 1
+    finally:
+        L.pxa_gemm_set_dynamic_items(prev)
+    ref = a.float() @ (w.float().t() if layout == "NT" else w.float()) + b
+    assert rel_l2(o_static.float(), ref) < BF16_TOL and torch.equal(o_static, o_dyn)
+
+
 @pytest.mark.parametrize("K,N,flavour", [(3456, 1152, "plain"), (1152, 1152, "plain"), (4608, 1152, "plain"), (1152, 4608, "mul_aux_colsum")])
 def test_gemm_nn_headline_shapes(ops, K, N, flavour):
     """dX = dY W at M = 65,536: qkv / proj / fc1 input gradients and the fc2 input gradient times the saved GELU' with the fused fc1
