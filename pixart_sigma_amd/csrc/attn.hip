@@ -2741,6 +2741,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv4_kernel(AttnParams p) {
 // the shape the power limit favours (common.h mfma16).  Round 2 measured this 3-7 % SLOWER in the two-wave kernel - issue-bound: the 16-cycle MFMAs left the
 // partner wave's softmax too few slots; the one-wave kernel has them (ablation r4_17: its vector and LDS work fit with room).  P and dS take pack_xy's
 // lane exchange (4 v_permlane16_swap per 32 x 32 block), the A operands are trfrag16 reads; dK^T / dV^T leave through store_rows16 (PXA_ATTN_DKV=5).
+// Alone 2.5 % faster than attn_bwd_dkv4_kernel, inside the training step 2.4 ms per step slower (profiles/r4_34_step_ab_attention.txt): an A/B partner, not the default.
 __global__ __launch_bounds__(256, 1) void attn_bwd_dkv5_kernel(AttnParams p) {
   __shared__ __attribute__((aligned(16))) char smem[DKV4_STAGES * STAGE_B];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), hi = lane >> 5;
@@ -3480,7 +3481,7 @@ extern "C" int pxa_attn_bwd(const pxa_attn_args* a, hipStream_t stream) {
   }
   if (p.dK) {
     const int max_k = a->max_kv_len > 0 ? a->max_kv_len : p.Nk;
-    // 4 = one wave per SIMD, 64 keys per wave (dense keys in whole 256-key blocks, whole 64-query tiles); PXA_ATTN_DKV=4 asks for it, the default takes it
+    // 4 / 5 = one wave per SIMD, 64 keys per wave (dense keys in whole 64-key groups, whole 64-query tiles); PXA_ATTN_DKV=4 / 5 asks for them, the default takes 4
     // where it applies and falls back to 2 elsewhere
     const bool dkv4_ok = p.stats && !p.kv_start && p.Nk % BKV == 0 && p.Nk >= 256 && p.Nq % BKV == 0 && p.Nq >= 2 * BKV;
     if (dkv_mode >= 4 && !dkv4_ok) dkv_mode = 2;
