@@ -26,6 +26,20 @@ def test_library_builds_and_exports_every_declared_symbol():
     assert dll.pxa_abi_version() == lib.ABI_VERSION
 
 
+def test_gemm_item_hand_out_switch_round_trips():
+    """pxa_gemm_set_dynamic_items (ABI 6) is process state, no GPU needed: static split by default, returns the previous setting."""
+    import subprocess
+    import sys
+    code = ("from pixart_sigma_amd import lib; L = lib.load(); a = L.pxa_gemm_set_dynamic_items(1); b = L.pxa_gemm_set_dynamic_items(0); "
+            "c = L.pxa_gemm_set_dynamic_items(0); print(a, b, c)")
+    env = {k: v for k, v in os.environ.items() if k not in ("PXA_GEMM_STATIC", "PXA_GEMM_DYNAMIC")}
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert r.stdout.split()[-3:] == ["0", "1", "0"]
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=ROOT, env={**env, "PXA_GEMM_DYNAMIC": "1"})   # an A/B override wins
+    assert r.returncode == 0 and r.stdout.split()[-3:] == ["1", "1", "1"]
+
+
 def test_struct_layouts_match_header():
     """Field order of the ctypes structures follows the C structs (guards against silent ABI drift)."""
     from pixart_sigma_amd import lib
