@@ -40,13 +40,30 @@ class GradReducer:
         if self.active:
             # bucket all-reduces will run beside the backward's GEMMs: their persistent kernels hand items out dynamically, so that a workgroup kept off its CU
             # by a collective does not double the kernel's time (include/pixart_hip.h: pxa_gemm_set_dynamic_items; one GPU alone keeps the faster static split)
+            # The switch is process-wide: the previous setting is kept and put back by close() (a single-GPU engine built after a reducer in the
+            # same process otherwise keeps paying for the cursors).
             from . import lib as _lib
-            _lib.load().pxa_gemm_set_dynamic_items(1)
+            self._prev_dynamic = _lib.load().pxa_gemm_set_dynamic_items(1)
+        else:
+            self._prev_dynamic = None
         self.bucket_dtype = bucket_dtype
         self.stage = torch.empty(store.total, dtype=bucket_dtype, device=store.device) if bucket_dtype not in (None, torch.float32) and self.active else None
         self.pending = []
         self.launched = []          # bucket names in launch order (the order every rank must agree on)
         self._sync = True
+
+    def close(self):
+        """Tear-down: restores the GEMM item hand-out this reducer found when it was built (idempotent; also run when the reducer is collected)."""
+        prev, self._prev_dynamic = getattr(self, "_prev_dynamic", None), None
+        if prev is not None:
+            from . import lib as _lib
+            _lib.load().pxa_gemm_set_dynamic_items(prev)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:      # interpreter shutdown: the library may already be gone
+            pass
 
     class _NoSync:
         def __init__(self, r):

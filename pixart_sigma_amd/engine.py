@@ -277,7 +277,7 @@ class Engine:
         lse_c = torch.empty((B, H, N), dtype=F32, device=qkv.device)
         sc_str = ((N * D, D, 72), (0, 2 * D, 72), (0, 2 * D, 72), (N * D, D, 72))
         ops.attention_fwd(qc, kvc[:, :D], kvc[:, D:], cr, lse_c, B, H, N, ctx["max_len"], sc_str,
-                          kv_start=ctx["kv_start"], kv_len=ctx["kv_len"], max_kv_len=ctx["max_len"])
+                          kv_start=ctx["kv_start"], kv_len=ctx["kv_len"], max_kv_len=ctx["max_len"], kv_len_host=ctx.get("lens_host"))
         u2 = self._lin(cr, p + "cross_attn.proj")
         r = ops.ln_mod_fwd(x1, sl, scl, st, u=u2, x_out=x1, rows_per_batch=N, want_stats=True)
         x2, xn2, mean2, rstd2 = r["x"], r["xn"], r["mean"], r["rstd"]
@@ -326,7 +326,7 @@ class Engine:
         sc_str = ((N * D, D, 72), (0, 2 * D, 72), (0, 2 * D, 72), (N * D, D, 72))
         ops.attention_bwd(sv["qc"], sv["kvc"][:, :D], sv["kvc"][:, D:], sv["cr"], dc, sv["lse_c"], delta, dqc, dkvc[:, :D], dkvc[:, D:],
                           B, H, N, ctx["max_len"], sc_str, ((N * D, D, 72), (0, 2 * D, 72), (0, 2 * D, 72)),
-                          kv_start=ctx["kv_start"], kv_len=ctx["kv_len"], max_kv_len=ctx["max_len"])
+                          kv_start=ctx["kv_start"], kv_len=ctx["kv_len"], max_kv_len=ctx["max_len"], kv_len_host=ctx.get("lens_host"))
         gq = self._lin_bwd(dqc, sv["x1b"], p + "cross_attn.q_linear")
         # 4,800 text rows fill 95 of 256 CUs with 256 x 256 tiles: split_k = 0 lets the library's (tile, split) model choose (128 x 128 here: 72 -> 47 us)
         self._lin_bwd(dkvc, ctx["ye"], p + "cross_attn.kv_linear", dx_kw=dict(out_f32=ctx["dye"], accumulate=True, split_k=0))
@@ -395,7 +395,7 @@ class Engine:
             starts = np.concatenate([[0], np.cumsum(lens)[:-1]]).astype(np.int32)
             self._len_cache[lk] = (torch.tensor(lens, dtype=torch.int32, device=dev), torch.from_numpy(starts).to(dev))
         kv_len, kv_start = self._len_cache[lk]
-        ctx = dict(B=B, N=N, hw=(h, w), mod=mod, kv_len=kv_len, kv_start=kv_start, max_len=int(max(lens)), need_grad_aux=(save == "all"))
+        ctx = dict(B=B, N=N, hw=(h, w), mod=mod, kv_len=kv_len, kv_start=kv_start, max_len=int(max(lens)), lens_host=lk, need_grad_aux=(save == "all"))
         L = y.shape[0] // B
         tkey = None
         if save or torch.is_grad_enabled():

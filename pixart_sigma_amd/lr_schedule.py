@@ -66,13 +66,18 @@ class LRSchedule:
     def state_dict(self):
         return {"last_step": self.last_step, "base_lr": self.base_lr, "steps_per_call": self.steps_per_call}
 
-    def load_state_dict(self, sd):
+    def load_state_dict(self, sd, optimizer_step=None):
         """`last_step` counts scheduler steps = steps_per_call x applied optimizer steps (the reference's `last_epoch` on a `world`-GPU job, see the module
-        header).  A checkpoint that recorded another unit - round-2 checkpoints of this repo counted optimizer steps and carry no `steps_per_call`; a job
-        resumed on a different number of GPUs - is rescaled to this run's unit, so the schedule resumes at the same point of its warm-up / decay."""
+        header).  A checkpoint of this repo that RECORDED its unit (`steps_per_call`, round 4 on) and is resumed on another number of GPUs is rescaled to this
+        run's unit.  A checkpoint without the key is never guessed at (round-3 files already counted world x steps and carried no unit, so reading
+        every unit-less file as round 2's optimizer steps multiplied them by world a second time): the value is loaded as it stands - right for round 3
+        and for the reference's `last_epoch` - unless the caller passes the checkpoint's own `step` (`optimizer_step`) and the two say unambiguously that the
+        counter is in optimizer steps (last_step == step, world > 1): only then is it scaled by this run's steps_per_call."""
         last = int(sd.get("last_step", sd.get("last_epoch", 0)))             # 'last_epoch' = torch LambdaLR's name for the same counter
-        if "last_step" in sd:                                                 # this repo's format: the unit is known (absent = 1, the round-2 format)
-            saved_unit = int(sd.get("steps_per_call", 1))
+        if "steps_per_call" in sd:
+            saved_unit = max(1, int(sd["steps_per_call"]))
             if saved_unit != self.steps_per_call:
-                last = last * self.steps_per_call // max(1, saved_unit)
+                last = last * self.steps_per_call // saved_unit
+        elif optimizer_step and self.steps_per_call > 1 and last == int(optimizer_step):
+            last = last * self.steps_per_call
         self.last_step = last

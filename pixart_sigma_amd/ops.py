@@ -198,13 +198,14 @@ def attention_bwd(q, k, v, o, d_o, lse, delta, dq, dk, dv, B, H, Nq, Nk, strides
     """colsums: optional fp32 (H*72,) accumulators receiving the column sums of dq / dk / dv (bias gradients)."""
     _check_max_kv_len(kw)
     a = _attn_args(q, k, v, o, B, H, Nq, Nk, strides, **kw)
-    if dk is not None:
-        a.bwd_stats = ptr(attn_bwd_stats(B, H, Nq, q.device))
+    stats = attn_bwd_stats(B, H, Nq, q.device) if dk is not None else None     # held until the launch below: under graph capture it is a fresh allocation
+    a.bwd_stats = ptr(stats)
     a.dq_colsum, a.dk_colsum, a.dv_colsum = (ptr(t) for t in colsums)
     a.colsum_stride = next((t.stride(0) for t in colsums if t is not None), 0)
     a.lse, a.delta, a.d_o, a.dq, a.dk, a.dv = ptr(lse), ptr(delta), ptr(d_o), ptr(dq), ptr(dk), ptr(dv)
     (a.dq_bs, a.dq_ts, a.dq_hs), (a.dk_bs, a.dk_ts, a.dk_hs), (a.dv_bs, a.dv_ts, a.dv_hs) = dstrides
     call("pxa_attn_bwd", a)            # dq=None skips the dQ kernel, dk=dv=None the dK/dV kernel
+    del stats
 
 
 def patch_embed_fwd(x, w, bias, pos, out=None):

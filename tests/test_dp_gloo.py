@@ -168,3 +168,33 @@ def test_reducer_is_noop_single_process(monkeypatch):
     with red.no_sync():
         red.on_group_ready("final")
     assert red.finish() == 1.0 and red.pending == []
+
+
+def test_reducer_restores_the_gemm_item_hand_out(monkeypatch, tmp_path):
+    """an active reducer switches the persistent GEMMs to dynamic item cursors for the whole process; close() (or collection) puts back what it
+    found, so a single-GPU engine built afterwards keeps the faster static split.  One-rank gloo group + PXA_DP_FORCE_COLLECTIVES makes the reducer active."""
+    import subprocess
+    import sys
+    code = (
+        "import os, torch, torch.distributed as dist\n"
+        "from pixart_sigma_amd import lib\n"
+        "from pixart_sigma_amd.dp import GradReducer\n"
+        "L = lib.load()\n"
+        "class S: total = 8; device = 'cpu'; groups = {}\n"
+        f"dist.init_process_group('gloo', init_method='file://{tmp_path}/rdv', rank=0, world_size=1)\n"
+        "L.pxa_gemm_set_dynamic_items(0)\n"
+        "r = GradReducer(S())\n"
+        "assert r.active\n"
+        "a = L.pxa_gemm_set_dynamic_items(1)\n"          # dynamic while the reducer lives
+        "r.close(); r.close()\n"
+        "b = L.pxa_gemm_set_dynamic_items(0)\n"          # static again afterwards
+        "r2 = GradReducer(S()); del r2\n"
+        "import gc; gc.collect()\n"
+        "c = L.pxa_gemm_set_dynamic_items(0)\n"
+        "print(a, b, c)\n"
+        "dist.destroy_process_group()\n")
+    env = dict(os.environ, PXA_DP_FORCE_COLLECTIVES="1")
+    env.pop("PXA_GEMM_DYNAMIC", None); env.pop("PXA_GEMM_STATIC", None)
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert out.returncode == 0, out.stderr
+    assert out.stdout.strip().splitlines()[-1].split() == ["1", "0", "0"], out.stdout

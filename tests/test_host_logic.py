@@ -260,3 +260,19 @@ def test_iddpm_ancestral_sampler_host_math_matches_reference():
             out = diff.p_sample_loop(model, z.shape, z, clip_denoised=clip, device="cpu", step_noise=lambda x: torch.randn(x.shape))
         assert ((out - g[key]).norm() / g[key].norm()).item() < 5e-5, key
     assert seen[:5] == [999, 749, 500, 250, 0]          # the denoiser is called at the ORIGINAL timesteps (respace.py:128-134)
+
+
+def test_keys_resident_attention_refuses_a_sample_longer_than_max_kv_len():
+    """the keys-resident cross-attention kernels clamp to max_kv_len; the engine now hands its host copy of the lengths to ops.attention_fwd / _bwd,
+    whose guard fires before anything is launched (so this needs no GPU)."""
+    import pytest
+    from pixart_sigma_amd import ops
+    t = torch.zeros(1)
+    with pytest.raises(AssertionError, match="max_kv_len 64 < longest sample 77"):
+        ops.attention_fwd(t, t, t, t, t, 1, 1, 1, 64, ((0, 0, 0),) * 4, max_kv_len=64, kv_len_host=(12, 77))
+    with pytest.raises(AssertionError, match="max_kv_len"):
+        ops.attention_bwd(t, t, t, t, t, t, t, t, t, t, 1, 1, 1, 64, ((0, 0, 0),) * 4, ((0, 0, 0),) * 3, max_kv_len=64, kv_len_host=(65,))
+    import inspect
+    from pixart_sigma_amd import engine
+    src = inspect.getsource(engine.Engine)
+    assert src.count("kv_len_host=ctx.get(\"lens_host\")") == 2          # both cross-attention call sites pass the host lengths

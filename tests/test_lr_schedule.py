@@ -109,9 +109,20 @@ def test_state_dict_records_its_unit_and_rescales_on_load():
     c = LRSchedule(1e-4, "constant", num_warmup_steps=1000, steps_per_call=2)      # resumed on 2 GPUs: 50 optimizer steps = 100 scheduler steps there
     c.load_state_dict(sd)
     assert c.last_step == 100
+    # a checkpoint WITHOUT its unit is not guessed at: round-3 files already count world x steps ...
     d = LRSchedule(1e-4, "constant", num_warmup_steps=1000, steps_per_call=8)
-    d.load_state_dict({"last_step": 50, "base_lr": 1e-4})                           # round-2 format: optimizer steps
+    d.load_state_dict({"last_step": 400, "base_lr": 1e-4})
     assert d.last_step == 400
+    d.load_state_dict({"last_step": 400, "base_lr": 1e-4}, optimizer_step=50)        # ... also when the checkpoint's own step count is known
+    assert d.last_step == 400
+    # ... and a round-2 file (optimizer steps) is rescaled only when the checkpoint's own `step` proves the unit
+    d.load_state_dict({"last_step": 50, "base_lr": 1e-4}, optimizer_step=50)
+    assert d.last_step == 400
+    d.load_state_dict({"last_step": 50, "base_lr": 1e-4})
+    assert d.last_step == 50
+    one = LRSchedule(1e-4, "constant", num_warmup_steps=1000, steps_per_call=1)       # one GPU: both readings coincide
+    one.load_state_dict({"last_step": 50, "base_lr": 1e-4}, optimizer_step=50)
+    assert one.last_step == 50
     e = LRSchedule(1e-4, "constant", num_warmup_steps=1000, steps_per_call=8)
     e.load_state_dict({"last_epoch": 400})                                          # a reference checkpoint's LambdaLR state: already world x steps
     assert e.last_step == 400

@@ -214,7 +214,7 @@ def main():
         if load_optimizer_state(opt, sd, rank):
             start_step = int(sd.get("step", 0))
         if "lr_scheduler" in sd:
-            sched.load_state_dict(sd["lr_scheduler"])
+            sched.load_state_dict(sd["lr_scheduler"], optimizer_step=sd.get("step"))
         elif "scheduler" in sd:                                 # reference checkpoint: torch LambdaLR state (save_checkpoint)
             sched.load_state_dict(sd["scheduler"])
         if scaler is not None and "loss_scaler" in sd:
