@@ -588,6 +588,8 @@ __device__ __forceinline__ void wait_vm_upto(int n) {      // n (wave-uniform) i
 #ifndef GEMM_ABL
 #define GEMM_ABL 0          // ablation bits (tools/build_variant.py; wrong results on purpose): 1 = every k-unit re-fetches the item's FIRST unit (cache-hot DMA), 2 = no bf16 epilogue,
 #endif                      // 4 = the main loop's FLOPs issued as v_mfma_f32_16x16x32 on the quarters of each accumulator tile (what the other MFMA shape would buy)
+                            // round 5, the two heavy epilogues taken apart: 8 = no bias-gradient column sums, 16 = no aux loads (x 1), 32 = the second output is
+                            // computed and parked but never stored, 64 = no GELU arithmetic (both outputs carry the pre-activation)
 #if GEMM_ABL & 4
 __device__ __forceinline__ void mfma_abl16(f32x4 (&q)[4], bf16x8 b0, bf16x8 a0, bf16x8 b1, bf16x8 a1) {
   q[0] = mfma16(b0, a0, q[0]); q[1] = mfma16(b1, a1, q[1]); q[2] = mfma16(b0, a1, q[2]); q[3] = mfma16(b1, a0, q[3]);
@@ -607,6 +609,9 @@ __device__ __forceinline__ void mfma_abl16(f32x4 (&q)[4], bf16x8 b0, bf16x8 a0, 
 #ifndef GEMM_M16_PRIO
 #define GEMM_M16_PRIO 1     // s_setprio 1 around the 16-row matrix phases of the NT instances (0: none; A/B builds).  NN measured +1.2 % WITHOUT it (profiles/r03h_kbench_gemm_variants.txt)
 #endif
+#ifndef GEMM_STAGGER
+#define GEMM_STAGGER 0      // > 0 (A/B builds): workgroups on odd CU slots of their XCD start GEMM_STAGGER x 10 ns late (s_memrealtime, 100 MHz), so that the two halves
+#endif                      // of the chip reach their epilogues - 64 to 128 MB of stores chip-wide per round of items - half an item apart instead of together
 #ifndef GEMM_PHASE16
 #define GEMM_PHASE16 -1     // matrix phases per k-unit: -1 = per layout (below), 0 = two 8-MFMA phases everywhere, 1 = one 16-MFMA phase everywhere
 #endif
@@ -813,6 +818,12 @@ __global__ __launch_bounds__(512) void gemm_pers_kernel(GemmParams p) {
     return __builtin_amdgcn_readfirstlane(res);
   };
   int L = blockIdx.x;
+#if GEMM_STAGGER
+  if (LAYOUT != 2 && ((blockIdx.x >> 3) & 1)) {
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    while (__builtin_amdgcn_s_memrealtime() - t0 < (unsigned long long)GEMM_STAGGER) __builtin_amdgcn_s_sleep(32);
+  }
+#endif
   if (DYN) {
     fetch_issue();
     wait_vmcnt<0>();
@@ -1171,7 +1182,7 @@ __global__ __launch_bounds__(512) void gemm_pers_kernel(GemmParams p) {
     const int act = (EPI == 0 || EPI == 5) ? 0 : EPI == 1 ? 3 : EPI == 2 ? 4 : (EPI == 4 || EPI == 6) ? 5 : EPI == 7 ? 1 : p.act;   // EPI 4 / 6: + aux (residual connection)
     constexpr bool want_st = (EPI == 5 || EPI == 6);   // + GroupNorm statistics of the output (implicit convolutions of the VAE)
     const bool dual = EPI == 1 || (EPI == 3 && ((p.act == 1 && p.out2 != nullptr) || p.act == 3));
-    const bool want_cs = EPI == 2 || (EPI == 3 && p.colsum != nullptr);
+    const bool want_cs = !(GEMM_ABL & 8) && (EPI == 2 || (EPI == 3 && p.colsum != nullptr));
     // one column group of JW 32-wide tiles (JW = 2: 128-byte staging rows, 8 rows per store; JW = 1: 64-byte rows, 16 per store)
     auto emit = [&](int j0, auto jw_c) {
       constexpr int JW = decltype(jw_c)::value, RB = JW * 64;
@@ -1212,7 +1223,12 @@ __global__ __launch_bounds__(512) void gemm_pers_kernel(GemmParams p) {
       const bool want_aux = (act == 2 || act == 4 || act == 5);
       uint2 ax[2][JW][4];                              // M16: [slice parity][m tile of the slice][n tile]
       auto load_aux = [&](int i, uint2 (&dst)[JW][4]) {
-        if constexpr (M16) {
+        if constexpr ((GEMM_ABL & 16) != 0) {
+#pragma unroll
+          for (int a_ = 0; a_ < JW; a_++)
+#pragma unroll
+            for (int b_ = 0; b_ < 4; b_++) dst[a_][b_] = make_uint2(OPERAND_ONE_X2, OPERAND_ONE_X2);
+        } else if constexpr (M16) {
 #pragma unroll
           for (int mh = 0; mh < 2; mh++)
 #pragma unroll
@@ -1236,7 +1252,11 @@ __global__ __launch_bounds__(512) void gemm_pers_kernel(GemmParams p) {
         if (pass == 0 && act == 3) {                   // second output = GELU'(pre-activation); the activation itself replaces
           float g[4];                                  // the accumulator so that pass 1 only has to park it
 #pragma unroll
-          for (int e = 0; e < 4; e++) { put_back(e, gelu_tanh_both(v[e], g[e])); v[e] = g[e]; }
+          for (int e = 0; e < 4; e++) {
+            if (GEMM_ABL & 64) { g[e] = v[e]; put_back(e, v[e]); }
+            else put_back(e, gelu_tanh_both(v[e], g[e]));
+            v[e] = g[e];
+          }
         }
         if (pass == 1) {
           if (act == 1) {
@@ -1291,7 +1311,7 @@ __global__ __launch_bounds__(512) void gemm_pers_kernel(GemmParams p) {
             const int sw = JW == 2 ? (row & 7) : ((row >> 1) & 3);
             const uint4 v4 = *reinterpret_cast<const uint4*>(stg + row * RB + ((ch ^ sw) << 4));
             const int mm = mw + i * 32 + row, nn = nw + j0 * 32 + ch * 8;
-            if (mm < p.M && nn < p.N) {
+            if (mm < p.M && nn < p.N && !((GEMM_ABL & 32) && pass == 0)) {
               if (GEMM_NT_STORE) __builtin_nontemporal_store(nt_u4{v4.x, v4.y, v4.z, v4.w}, reinterpret_cast<nt_u4*>(dst + (size_t)mm * p.ldo + nn));
               else *reinterpret_cast<uint4*>(dst + (size_t)mm * p.ldo + nn) = v4;
             }
@@ -1356,7 +1376,7 @@ __global__ __launch_bounds__(512) void gemm_pers_kernel(GemmParams p) {
     {   // stores this wave has just issued, if every one of them was a full (unpredicated) 16-byte row segment
       const bool interior = mw + tm_eff * 32 <= p.M && nw + 64 <= p.N;
       // (the statistics / column-sum flavours issue 4 / 8 more vector-memory instructions behind the stores: their atomics)
-      prev_stores = (interior && p.out) ? tm_eff * 4 * (dual ? 2 : 1) + (want_st ? 4 : 0) + (want_cs ? 8 : 0) : 0;
+      prev_stores = (interior && p.out) ? tm_eff * 4 * ((dual && !(GEMM_ABL & 32)) ? 2 : 1) + (want_st ? 4 : 0) + (want_cs ? 8 : 0) : 0;
     }
     nk = nk_pf;
     if (!more) break;

@@ -1,5 +1,5 @@
 """A/B kernel builds: recompile ONE source of the library with extra -D flags and link it with the cached objects of the others.
-    python tools/build_variant.py <name> <source.hip> [-DFLAG ...]   ->  pixart_sigma_amd/variants/lib_<name>.so
+    python tools/build_variant.py <name> <source.hip>[,<source2.hip>...] [-DFLAG ...]   ->  pixart_sigma_amd/variants/lib_<name>.so
 Run a benchmark against it with PXA_LIB_PATH=pixart_sigma_amd/variants/lib_<name>.so (pixart_sigma_amd/lib.py)."""
 import os, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -15,7 +15,7 @@ os.makedirs(out_dir, exist_ok=True)
 objs = []
 for s in sorted(f for f in os.listdir(B.CSRC) if f.endswith(".hip")):
     path = os.path.join(B.CSRC, s)
-    if s == os.path.basename(src):
+    if s in [os.path.basename(x) for x in src.split(",")]:
         obj = os.path.join(out_dir, f"{s[:-4]}.{name}.o")
         subprocess.run([B._hipcc(), *B.FLAGS, *B.PER_FILE_FLAGS.get(s, []), *flags, "-I", B.INCLUDE, "-c", path, "-o", obj], check=True)
     else:
