@@ -6,14 +6,14 @@ O=gpurun_out
 export PYTHONUNBUFFERED=1 PXA_OPERAND_DTYPE=f16
 V=pixart_sigma_amd/variants
 { echo "# box $(hostname) $(date -u +%FT%TZ) operand f16"; rocm-smi --showproductname 2>/dev/null | grep -i "card series" | head -1; } > $O/r5_01_kbench_epi.txt
-for v in "" f16_abl8 f16_abl16 f16_abl24 f16_abl32 f16_abl64 f16_abl96 f16_stag9 f16_stag18 f16_gelu2 ""; do
+for v in "" f16_abl8 f16_abl16 f16_abl32 f16_abl64 f16_abl96 f16_stag9 f16_stag18 f16_gelu2; do
   if [ -z "$v" ]; then unset PXA_LIB_PATH; else export PXA_LIB_PATH=$V/lib_$v.so; fi
   timeout 120 python tools/kbench_epi.py 4 24 2>&1 | grep -v amdgpu >> $O/r5_01_kbench_epi.txt
 done
 unset PXA_LIB_PATH
 unset PXA_OPERAND_DTYPE      # bench.py selects fp16 itself
 cfgs=("default|A=1")
-for v in stag9 stag18 gelu2 ph16_0 ph16_1 prio0 sto0 opq0 opq2 nt0 nt1 nt2; do cfgs+=("$v|PXA_LIB_PATH=$V/lib_f16_$v.so"); done
+for v in stag9 stag18 gelu2 ph16_0 ph16_1 prio0 sto0 opq0 opq2 nt0; do cfgs+=("$v|PXA_LIB_PATH=$V/lib_f16_$v.so"); done
 cfgs+=("no_kvres|PXA_ATTN_NO_KVRES=1" "default_again|A=1")
 F=$O/r5_01_step_ab.txt
 echo "# box $(hostname) $(date -u +%FT%TZ) fp16 build, bench.py --steps 8 --warmup 3, one round" > $F
