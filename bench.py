@@ -61,6 +61,62 @@ def fwd_flops_per_sample(N, L=LTXT, n_kv=None):
     return DEPTH * per_layer + embed
 
 
+def _pad(n, m):
+    return (n + m - 1) // m * m
+
+
+def issued_flops_per_step(B, N, L=LTXT):
+    """Matrix FLOPs the step's kernels ISSUE on the MFMA pipe, computed from the launch shapes (not the algorithmic count `roofline.achieved` uses): what
+    a power-limited matrix pipe has to get through whatever surrounds it.  Differences from the algorithmic 2mnk:
+      * attention backward is two kernels that each recompute S and dP: dQ issues S, dP, dQ; dK/dV issues S, dP, dV, dK  (7 products for the 5 of a
+        single-kernel backward; the forward issues its 2);
+      * head_dim 72 pads to 80 wherever it is the reduction (S, dP: 5 k-steps of 16) or an output on 16-row tiles (O, dQ), and to 96 where it is an
+        output on 32-row tiles (dV, dK of the default dK/dV kernel, attn_bwd_dkv4_kernel);
+      * text keys pad to whole 64-key tiles in the keys-resident cross-attention kernels (300 -> 320) and to whole 128-key workgroups in the
+        cross-attention dK/dV kernel (300 -> 384);
+      * token GEMMs: M = B N is a multiple of 256 and every width a multiple of 128, so NT / NN issue exactly 2mnk; the weight-gradient (TN) kernel pads an
+        output side of 1152 to 1280 on the m side (5 tiles of 256; the n side is paired half tiles) - and the 4,800 text rows pad to 4,864."""
+    R, hd = B * N, 72
+    pr = lambda m, n, k: 2.0 * m * n * k                     # noqa: E731
+    # ---- token GEMMs per block: forward NT, dX NN, dW TN (m = output features of the layer, padded to 256; n = its input features)
+    lin = [(3 * D, D), (D, D), (D, D), (D, D), (DFF, D), (D, DFF)]     # (out, in): qkv, proj, q_linear, cross proj, fc1, fc2 on R rows
+    g = 0.0
+    for o, i in lin:
+        g += 2 * pr(R, o, i) + pr(_pad(o, 256), i, R)
+    Lt = B * L                                                         # packed text rows: kv_linear (forward, dX into the caption gradient, dW)
+    g += pr(_pad(Lt, 256), 2 * D, D) * 2 + pr(_pad(2 * D, 256), D, _pad(Lt, 64))
+    # ---- self-attention per block and head: 2 N^2 x (sum of the padded depth / width of each product)
+    sa = 2.0 * N * N * ((80 + 80) + (80 + 80 + 80) + (80 + 80 + 96 + 96))
+    # ---- cross-attention per block and head: forward / dQ on 64-key tiles, dK/dV on 128-key workgroups
+    ca = 2.0 * N * (_pad(L, 64) * ((80 + 80) + (80 + 80 + 80)) + _pad(L, 128) * (80 + 80 + 96 + 96))
+    per_block = g + B * H * (sa + ca)
+    # ---- outside the blocks: caption MLP (4096 -> 1152 -> 1152 on the text rows), final linear, patch embed: forward + dX + dW
+    embed = 3 * (pr(_pad(Lt, 256), D, 4096) + pr(_pad(Lt, 256), D, D) + pr(R, 128, D))
+    return DEPTH * per_block + embed
+
+
+def mfma_only_rate(seconds=2.0):
+    """Live: the library's MFMA-only probe (include/pixart_hip.h: pxa_mfma_rate_probe - 32 x 32 x 16 MFMAs on N(0,1) operands of the build's type, one wave per
+    SIMD, nothing else in the loop) run back to back for `seconds`, the rate taken over the SECOND half (the clock has settled under the power limit by then)."""
+    import ctypes
+    from pixart_sigma_amd import lib as L_, ops
+    lib = L_.load()
+    n = lib.pxa_mfma_rate_probe_bytes()
+    buf = torch.randn(n // 2, device="cuda").to(ops.BF16)
+    sink = torch.zeros(1, device="cuda")
+    fl = ctypes.c_double(0.0)
+    out = {}
+    for shape in (32, 16):
+        iters = 4096
+        launch = lambda: L_.check(lib.pxa_mfma_rate_probe(L_.ptr(buf), shape, iters, L_.ptr(sink), ctypes.byref(fl), L_.stream()), "pxa_mfma_rate_probe")  # noqa: E731
+        t1 = timed(launch, 3, warm=1)                        # size the run: launches for ~seconds/2 per half
+        k = max(4, int(seconds / 2 / t1))
+        timed(launch, k, warm=0)                             # first half: untimed ramp
+        t = timed(launch, k, warm=0)
+        out[shape] = fl.value / t
+    return out
+
+
 def timed(fn, iters, warm=2):
     for _ in range(warm):
         fn()
@@ -343,6 +399,22 @@ def main():
                     "step": {"achieved": flops_step / sec_per_step / 1e12, "frac": flops_step / sec_per_step / MFMA_PEAK,
                              "scope": "whole training step (algorithmic FLOPs / wall time)"},
                     "kernels": {k: {"TFLOP/s": round(v["tflops"], 1), "frac": round(v["frac"], 4), "ms": round(v["seconds"] * 1e3, 3)} for k, v in ks.items()}}
+        # the ceiling argument, driver-visible: FLOPs the step issues (from the launch shapes) and the rate an MFMA-only stream sustains
+        # on THIS box under its power limit, measured now; `peak` stays the sheet's 2.5 PFLOP/s
+        issued = issued_flops_per_step(B, N)
+        roof["issued_flops_per_step"] = issued
+        roof["issued_over_algorithmic"] = issued / flops_step
+        if not a.no_kernel_roofline and a.image_size == 1024 and world == 1:
+            try:
+                mr = mfma_only_rate()
+                roof["mfma_only_rate"] = {"TFLOP/s": round(mr[32] / 1e12, 1), "frac_of_peak": round(mr[32] / MFMA_PEAK, 4),
+                                          "TFLOP/s_16x16x32": round(mr[16] / 1e12, 1),
+                                          "what": "pxa_mfma_rate_probe: v_mfma_f32_32x32x16 only, N(0,1) operands in registers, one wave per SIMD on every CU, "
+                                                  "2 s back to back, rate of the second half (second figure: the same FLOPs as 16x16x32)"}
+                roof["issued_time_floor_ms"] = issued / mr[32] * 1e3          # the issued matrix work alone at that rate
+                roof["step_frac_of_mfma_only_rate"] = (issued / sec_per_step) / mr[32]
+            except Exception as e:   # noqa: BLE001 - a measurement leg must never take the headline number down
+                roof["mfma_only_rate"] = {"error": f"{type(e).__name__}: {e}"[:300]}
         out["roofline"] = roof
         if world == 1 and not (a.no_other_dtype and a.no_torch_baseline):
             del opt

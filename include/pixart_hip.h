@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define PXA_ABI_VERSION 6
+#define PXA_ABI_VERSION 7
 /* Kernels that fuse a bias-gradient column sum add into one of PXA_COLSUM_SLOTS partial rows ([slot][stride] fp32, caller-zeroed),
  * chosen per sample / row tile, so no address sees thousands of atomics; pxa_colsum_reduce folds the partials into the gradient. */
 #define PXA_COLSUM_SLOTS 16
@@ -283,6 +283,15 @@ int pxa_vae_softmax_rows(const float* s, long ld, void* p_bf16, long ldp, int ro
 /* fp32 NCHW (B, C, H, W) image / latent -> bf16 grid scaled by mul, channels C..grid.C-1 zero; and back (first C channels). */
 int pxa_vae_nchw_to_grid(const float* img, int C, float mul, const pxa_grid* y, hipStream_t stream);
 int pxa_vae_grid_to_nchw(const pxa_grid* x, int C, float* img, hipStream_t stream);
+
+/* ---------------------------------------------------------------------------------------------- measurement
+ * The part's matrix rate under its power limit, for the `roofline` object of bench.py (no reference counterpart: the reference reports no roofline).
+ * One launch = `iters` x 32 v_mfma_f32_32x32x16 (shape 32) or 64 v_mfma_f32_16x16x32 (shape 16) per wave on register-resident operand data, one wave per
+ * SIMD on every CU, nothing else in the loop.  `operands`: pxa_mfma_rate_probe_bytes() bytes of operand-type values (the caller fills them, e.g. N(0,1):
+ * the multiplier inputs' toggle rate sets the power draw and with it the clock); `sink`: one float, never written on such data; *flops_per_launch (optional)
+ * receives the FLOPs the launch issues.  The caller times the launches with events on `stream`. */
+long pxa_mfma_rate_probe_bytes(void);
+int pxa_mfma_rate_probe(const void* operands, int shape, int iters, float* sink, double* flops_per_launch, hipStream_t stream);
 
 #ifdef __cplusplus
 }

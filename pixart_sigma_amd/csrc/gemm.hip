@@ -612,6 +612,9 @@ __device__ __forceinline__ void mfma_abl16(f32x4 (&q)[4], bf16x8 b0, bf16x8 a0, 
 #ifndef GEMM_STAGGER
 #define GEMM_STAGGER 0      // > 0 (A/B builds): workgroups on odd CU slots of their XCD start GEMM_STAGGER x 10 ns late (s_memrealtime, 100 MHz), so that the two halves
 #endif                      // of the chip reach their epilogues - 64 to 128 MB of stores chip-wide per round of items - half an item apart instead of together
+#ifndef GEMM_EPI_EARLY
+#define GEMM_EPI_EARLY 1    // bias add in front of the prefetch + asm aux loads with counted waits (see the hand-over of gemm_pers_kernel); 0 = the round-4 order (A/B builds)
+#endif
 #ifndef GEMM_PHASE16
 #define GEMM_PHASE16 -1     // matrix phases per k-unit: -1 = per layout (below), 0 = two 8-MFMA phases everywhere, 1 = one 16-MFMA phase everywhere
 #endif
@@ -803,9 +806,18 @@ __global__ __launch_bounds__(512) void gemm_pers_kernel(GemmParams p) {
   };
   unsigned pend = 0u;                                  // wave 0 / lane 0: cursor value of the fetch in flight
   int nxt = -1;                                        // the item after the current one (position in the order), -1: none
-  auto fetch_issue = [&]() { if (wave == 0 && lane == 0) pend = atomicAdd(&sched[myx], 1u); };
-  auto fetch_resolve = [&]() -> int {                  // wave 0 only; the own-XCD fetch has returned (vmcnt(0) was waited)
+  // (asm: the compiler put `s_waitcnt vmcnt(0)` right behind its own atomic - wave 0 then waited for the whole prefetch it had just issued; the value is
+  // only read in fetch_resolve, behind the top-of-loop wait that covers it: the fetch is older than every epilogue store that wait leaves in flight)
+  auto fetch_issue = [&]() {
+    if (wave == 0 && lane == 0) {
+      unsigned* cur = &sched[myx];
+      const unsigned one = 1u;
+      asm volatile("global_atomic_add %0, %1, %2, off sc0" : "=v"(pend) : "v"(cur), "v"(one) : "memory");
+    }
+  };
+  auto fetch_resolve = [&]() -> int {                  // wave 0 only; the own-XCD fetch has returned (a vmcnt wait that covers it was executed)
     int res = -1;
+    asm volatile("" : "+v"(pend));
     if (lane == 0) {
       if ((int)pend < xc(myx)) res = xs(myx) + (int)pend;
       else
@@ -888,7 +900,7 @@ __global__ __launch_bounds__(512) void gemm_pers_kernel(GemmParams p) {
     const long k0 = (long)z_ * p.k_per_split;
     const bool vq = PAIR && vt, hq = HALF && vt;
     const int rla = vq ? 9 : 8, rlb = (vq || hq) ? 7 : 8;   // log2 of the A / B image row (column) counts
-    const int ln = opaque<LAYOUT == 1 || (EPI >= 2 && EPI != 7)>(lane);
+    const int ln = opaque<LAYOUT == 1 || (EPI >= 2 && EPI != 7) || (GEMM_EPI_EARLY && RM == 2)>(lane);
 #pragma unroll
     for (int i = 0; i < 5; i++) {
       const int id = wave + NW * i;                    // full tile: 16 A + 16 B pieces; paired: 32 A + 8 B
@@ -946,6 +958,7 @@ __global__ __launch_bounds__(512) void gemm_pers_kernel(GemmParams p) {
     // behind them (K = 1152 tiles: the store drain was most of a 16 % epilogue cost).  Anything else waits for everything.
     if (GEMM_STORE_OVERLAP && LAYOUT != 2 && EPI != 3) {
       if (prev_stores == 32) wait_vmcnt<32>();
+      else if (prev_stores == 28) wait_vmcnt<28>();
       else if (prev_stores == 24) wait_vmcnt<24>();
       else if (prev_stores == 20) wait_vmcnt<20>();
       else if (prev_stores == 16) wait_vmcnt<16>();
@@ -1113,28 +1126,36 @@ __global__ __launch_bounds__(512) void gemm_pers_kernel(GemmParams p) {
     PXA_TR(3);
 
     // ---- hand-over: prefetch the next item's first units, then this item's epilogue
-    bool more;
-    if (DYN) {
-      more = nxt >= 0;
-      if (more) {
-        locate_g(nxt);
-        nk_pf = units_of(z_);
-        prefetch();
-        fetch_issue();                                 // cursor fetch for the item after the next; resolved after the next vmcnt(0)
+    bool more = false;
+    int pf_ops = 0;                                    // LDS-DMA instructions this wave issues in the prefetch below (wave-uniform)
+    auto hand_over = [&]() {
+      if (DYN) {
+        more = nxt >= 0;
+        if (more) {
+          locate_g(nxt);
+          nk_pf = units_of(z_);
+          prefetch();
+          fetch_issue();                               // cursor fetch for the item after the next; resolved after the next vmcnt(0)
+        }
+      } else {
+        L += gridDim.x;
+        more = L < T;
+        if (more) {
+          locate(L);
+          nk_pf = units_of(z_);
+          prefetch();
+        }
       }
-    } else {
-      L += gridDim.x;
-      more = L < T;
       if (more) {
-        locate(L);
-        nk_pf = units_of(z_);
-        prefetch();
+        const int hi_ops = 1 + ((HALF && vt_pf) ? 0 : 1) + ((PAIR && vt_pf) ? 1 : 0);
+        pf_ops = 2 * (H1 + hi_ops) + (nk_pf > 2 ? H1 + (PH16 ? hi_ops : 0) : 0);
       }
-    }
-    PXA_TR(4);
-    const int le = opaque<LAYOUT == 1 || (EPI >= 2 && EPI != 7)>(lane);          // NN: epilogue-only lane constants are rebuilt per item (see opaque())
+    };
+    const int le = opaque<LAYOUT == 1 || (EPI >= 2 && EPI != 7) || (GEMM_EPI_EARLY && RM == 2)>(lane);          // NN: epilogue-only lane constants are rebuilt per item (see opaque())
     const int srow = le & 31;
     if constexpr (LAYOUT == 2) {
+      hand_over();
+      PXA_TR(4);
       // fp32 weight-gradient tile: each 32 x 32 accumulator tile is parked in the wave's staging slice (128-byte rows, 16-byte
       // chunk XOR (row & 7)) and leaves as full 128-byte row segments: split-K slab store, read-modify-write into the gradient
       // (single k-slice: this workgroup owns the element) or plain store
@@ -1183,6 +1204,114 @@ __global__ __launch_bounds__(512) void gemm_pers_kernel(GemmParams p) {
     constexpr bool want_st = (EPI == 5 || EPI == 6);   // + GroupNorm statistics of the output (implicit convolutions of the VAE)
     const bool dual = EPI == 1 || (EPI == 3 && ((p.act == 1 && p.out2 != nullptr) || p.act == 3));
     const bool want_cs = !(GEMM_ABL & 8) && (EPI == 2 || (EPI == 3 && p.colsum != nullptr));
+    // Round 5: what the epilogue LOADS must not queue behind the next item's prefetch.  vmcnt retires in issue order and the compiler does not see
+    // the asm LDS-DMA: a compiler-visible load issued behind the prefetch is waited for with `s_waitcnt vmcnt(0)` - i.e. every item's epilogue began
+    // by waiting for the NEXT item's first k-units to land (the bias loads of every flavour; profiles/r5_01: the x aux flavour, whose four row slices
+    // each waited like that, cost fc2's dX 240 us per launch over its plain twin, 215 of them gone with the aux loads ablated).  So (GEMM_EPI_EARLY):
+    //   * the bias is added BEFORE the prefetch is issued (its wait then covers only itself), for every 16-bit flavour;
+    //   * the aux flavours with a compiled-in activation (x aux: EPI 2; + aux: EPI 4 / 6) load aux through asm statements with hand-counted waits:
+    //     issue order  L0 L1 | wait(L0) apply(0) | L2 | PREFETCH (pf_ops) | S0 | wait(L1) apply(1) | L3 | S1 | wait(L2) apply(2) | S2 | wait(L3) apply(3) | S3
+    //     (L = the 8 loads of a 32-row slice, S = its 4 stores): a slice's aux is two slices ahead of its use and no wait reaches back over the
+    //     prefetch.  Half items (2 slices): L0 L1 | wait apply(0) | PREFETCH | S0 | wait(L1) apply(1) | S1.
+    constexpr bool AUXA = GEMM_EPI_EARLY && M16 && (EPI == 2 || EPI == 4 || EPI == 6) && !(GEMM_ABL & 16);
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    u32x2 axa[2][2][4];                                // AUXA: [slice parity][m tile of the slice][n tile]
+    constexpr bool EARLY = GEMM_EPI_EARLY && M16;      // (the 32-row accumulator layout exists for A/B builds only and keeps the round-4 order)
+    f32x4 bq[2 * TN];                                  // EARLY: the wave's 64 bias values in accumulator layout, loaded through asm (no compiler-made wait)
+    auto bias_issue = [&]() {
+      const int R4b = le >> 4;
+#pragma unroll
+      for (int jn = 0; jn < 2 * TN; jn++) {
+        const float* src = p.bias + min(nw + jn * 16 + 4 * R4b, p.N - 4);      // columns beyond N: clamped, never stored
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(bq[jn]) : "v"(src) : "memory");
+      }
+    };
+    auto bias_apply = [&]() {                          // behind a counted wait that covers the four loads
+      asm volatile("" : "+v"(bq[0]), "+v"(bq[1]), "+v"(bq[2]), "+v"(bq[3]));
+#pragma unroll
+      for (int jn = 0; jn < 2 * TN; jn++)
+#pragma unroll
+        for (int mt = 0; mt < 2 * TM; mt++) acc4[mt][jn] += bq[jn];
+    };
+    auto bias_add = [&]() {                            // round-4 form: compiler-visible loads, waited for with vmcnt(0) wherever they are issued
+      const int R4b = le >> 4;
+      if constexpr (M16) {
+#pragma unroll
+        for (int jn = 0; jn < 2 * TN; jn++) {
+          const int n = nw + jn * 16 + 4 * R4b;
+          const float4 b4 = (p.bias && n < p.N) ? *reinterpret_cast<const float4*>(p.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+          for (int mt = 0; mt < 2 * TM; mt++) { acc4[mt][jn][0] += b4.x; acc4[mt][jn][1] += b4.y; acc4[mt][jn][2] += b4.z; acc4[mt][jn][3] += b4.w; }
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < TN; j++)
+#pragma unroll
+          for (int q = 0; q < 4; q++) {
+            const int n = nw + j * 32 + 8 * q + 4 * hi;
+            const float4 b4 = (p.bias && n < p.N) ? *reinterpret_cast<const float4*>(p.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int i = 0; i < TM; i++) { acc[i][j][q * 4] += b4.x; acc[i][j][q * 4 + 1] += b4.y; acc[i][j][q * 4 + 2] += b4.z; acc[i][j][q * 4 + 3] += b4.w; }
+          }
+      }
+    };
+    auto wait_allow = [&](int allowed) {               // at most `allowed` (wave-uniform) younger vector-memory operations stay in flight
+      if (allowed >= 28) wait_vmcnt<28>();
+      else if (allowed >= 26) wait_vmcnt<26>();
+      else if (allowed >= 24) wait_vmcnt<24>();
+      else if (allowed >= 22) wait_vmcnt<22>();
+      else if (allowed >= 20) wait_vmcnt<20>();
+      else if (allowed >= 16) wait_vmcnt<16>();
+      else if (allowed >= 12) wait_vmcnt<12>();
+      else if (allowed >= 10) wait_vmcnt<10>();
+      else if (allowed >= 9) wait_vmcnt<9>();
+      else if (allowed >= 8) wait_vmcnt<8>();
+      else if (allowed >= 4) wait_vmcnt<4>();
+      else wait_vmcnt<0>();
+    };
+    auto aux_issue = [&](int i, u32x2 (&dst)[2][4]) {  // rows / columns beyond M / N are clamped: their products are never stored or summed
+      const int R4a = le >> 4, c16a = le & 15;
+#pragma unroll
+      for (int mh = 0; mh < 2; mh++)
+#pragma unroll
+        for (int jn = 0; jn < 4; jn++) {
+          const int m = min(mw + i * 32 + 16 * mh + c16a, p.M - 1), n = min(nw + jn * 16 + 4 * R4a, p.N - 4);
+          const bf16_t* src = p.aux + (size_t)m * p.ldaux + n;
+          asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(dst[mh][jn]) : "v"(src) : "memory");
+        }
+    };
+    auto aux_ready = [&](int allowed, u32x2 (&a)[2][4]) {
+      wait_allow(allowed);
+      // (the registers pass through an asm statement behind the wait: no use of them can be scheduled in front of it)
+      asm volatile("" : "+v"(a[0][0]), "+v"(a[0][1]), "+v"(a[0][2]), "+v"(a[0][3]), "+v"(a[1][0]), "+v"(a[1][1]), "+v"(a[1][2]), "+v"(a[1][3]));
+    };
+    auto aux_apply = [&](int i, const u32x2 (&a)[2][4]) {
+#pragma unroll
+      for (int mh = 0; mh < 2; mh++)
+#pragma unroll
+        for (int jn = 0; jn < 4; jn++) {
+          float a0, a1, a2f, a3;
+          unpack_bf16x2(a[mh][jn][0], a0, a1); unpack_bf16x2(a[mh][jn][1], a2f, a3);
+          f32x4& v = acc4[2 * i + mh][jn];
+          if (act == 5) { v[0] += a0; v[1] += a1; v[2] += a2f; v[3] += a3; }
+          else { v[0] *= a0; v[1] *= a1; v[2] *= a2f; v[3] *= a3; }
+        }
+    };
+    const bool has_bias = EARLY && p.bias != nullptr;  // wave-uniform
+    if (has_bias) bias_issue();
+    if constexpr (AUXA) {
+      aux_issue(0, axa[0]);
+      aux_issue(1, axa[1]);
+      aux_ready(8, axa[0]);                            // the bias (older) and slice 0 have landed
+      if (has_bias) bias_apply();
+      aux_apply(0, axa[0]);
+      if (tm_eff > 2) aux_issue(2, axa[0]);
+    }
+    hand_over();
+    if constexpr (!AUXA) {
+      if (has_bias) { wait_allow(pf_ops); bias_apply(); }      // the prefetch, issued behind the bias loads, stays in flight
+    }
+    PXA_TR(4);
     // one column group of JW 32-wide tiles (JW = 2: 128-byte staging rows, 8 rows per store; JW = 1: 64-byte rows, 16 per store)
     auto emit = [&](int j0, auto jw_c) {
       constexpr int JW = decltype(jw_c)::value, RB = JW * 64;
@@ -1192,25 +1321,8 @@ __global__ __launch_bounds__(512) void gemm_pers_kernel(GemmParams p) {
       // a lane's 4 values are 8 bytes of staging chunk 2 jn + (R4 >> 1).  Everything behind the staging slice is shared with the 32 x 32 form.
       const int R4 = le >> 4, c16 = le & 15;
       // bias goes into the accumulators first, unconditionally (zero when absent), so nothing extra stays live across the row loop
-      if constexpr (M16) {
-#pragma unroll
-        for (int jn = 0; jn < 2 * TN; jn++) {
-          const int n = nw + jn * 16 + 4 * R4;
-          const float4 b4 = (p.bias && n < p.N) ? *reinterpret_cast<const float4*>(p.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-          for (int mt = 0; mt < 2 * TM; mt++) { acc4[mt][jn][0] += b4.x; acc4[mt][jn][1] += b4.y; acc4[mt][jn][2] += b4.z; acc4[mt][jn][3] += b4.w; }
-        }
-      } else {
-#pragma unroll
-      for (int jj = 0; jj < JW; jj++)
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-          const int n = nw + (j0 + jj) * 32 + 8 * q + 4 * hi;
-          const float4 b4 = (p.bias && n < p.N) ? *reinterpret_cast<const float4*>(p.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-          for (int i = 0; i < TM; i++) { acc[i][j0 + jj][q * 4] += b4.x; acc[i][j0 + jj][q * 4 + 1] += b4.y; acc[i][j0 + jj][q * 4 + 2] += b4.z; acc[i][j0 + jj][q * 4 + 3] += b4.w; }
-        }
-      }
+      // (GEMM_EPI_EARLY: already done in front of the prefetch)
+      if (!EARLY) bias_add();
       // bias-gradient column sums are taken from the read-back (row-wise) copy of the bf16 output: a lane keeps 8 running sums
       // for its 8-column chunk over all row slices; one 3-step lane tree at the end
       float cs[8], sq[2] = {0.f, 0.f};                 // statistics flavours: cs[0..1] / sq[0..1] = the chunk's two channel quads
@@ -1220,7 +1332,8 @@ __global__ __launch_bounds__(512) void gemm_pers_kernel(GemmParams p) {
       // position is an interior pixel.  floor((pix + 0.5) / rp) in fp32 is exact for pix < 2^22.
       const int st_img = want_st ? mw / p.gn_img_rows : 0, st_base = st_img * p.gn_img_rows;
       // aux (saved pre-activation / saved GELU') of the NEXT row slice is requested before this slice is processed
-      const bool want_aux = (act == 2 || act == 4 || act == 5);
+      const bool want_aux = !AUXA && (act == 2 || act == 4 || act == 5);
+      const bool interior_a = mw + tm_eff * 32 <= p.M && nw + 64 <= p.N;      // AUXA: every store of this wave is issued -> the counted waits hold
       uint2 ax[2][JW][4];                              // M16: [slice parity][m tile of the slice][n tile]
       auto load_aux = [&](int i, uint2 (&dst)[JW][4]) {
         if constexpr ((GEMM_ABL & 16) != 0) {
@@ -1262,7 +1375,7 @@ __global__ __launch_bounds__(512) void gemm_pers_kernel(GemmParams p) {
           if (act == 1) {
 #pragma unroll
             for (int e = 0; e < 4; e++) v[e] = gelu_tanh(v[e]);
-          } else if (act == 2 || act == 4 || act == 5) {
+          } else if (!AUXA && (act == 2 || act == 4 || act == 5)) {
             float a0, a1, a2f, a3;
             unpack_bf16x2(a2.x, a0, a1); unpack_bf16x2(a2.y, a2f, a3);
             if (act == 2) { a0 = gelu_tanh_grad(a0); a1 = gelu_tanh_grad(a1); a2f = gelu_tanh_grad(a2f); a3 = gelu_tanh_grad(a3); }
@@ -1276,6 +1389,19 @@ __global__ __launch_bounds__(512) void gemm_pers_kernel(GemmParams p) {
       for (int i = 0; i < TM; i++) {
         if (i >= tm_eff) break;                        // half items: two row tiles per wave
         if (want_aux && i + 1 < tm_eff) load_aux(i + 1, ax[(i + 1) & 1]);
+        if constexpr (AUXA) {                          // issue order and counts: see the hand-over
+          if (i == 1) {
+            aux_ready(interior_a ? (tm_eff > 2 ? 8 : 0) + pf_ops + 4 : 0, axa[1]);
+            aux_apply(1, axa[1]);
+            if (tm_eff > 3) aux_issue(3, axa[1]);
+          } else if (i == 2) {
+            aux_ready(interior_a ? pf_ops + 16 : 0, axa[0]);
+            aux_apply(2, axa[0]);
+          } else if (i == 3) {
+            aux_ready(interior_a ? 8 : 0, axa[1]);
+            aux_apply(3, axa[1]);
+          }
+        }
 #pragma unroll
         for (int pass = 0; pass < 2; pass++) {         // pass 0: second output (dual-output flavours only); pass 1: final values
           if (pass == 0 && !dual) continue;
@@ -1376,7 +1502,7 @@ __global__ __launch_bounds__(512) void gemm_pers_kernel(GemmParams p) {
     {   // stores this wave has just issued, if every one of them was a full (unpredicated) 16-byte row segment
       const bool interior = mw + tm_eff * 32 <= p.M && nw + 64 <= p.N;
       // (the statistics / column-sum flavours issue 4 / 8 more vector-memory instructions behind the stores: their atomics)
-      prev_stores = (interior && p.out) ? tm_eff * 4 * ((dual && !(GEMM_ABL & 32)) ? 2 : 1) + (want_st ? 4 : 0) + (want_cs ? 8 : 0) : 0;
+      prev_stores = (interior && p.out) ? tm_eff * 4 * ((dual && !(GEMM_ABL & 32)) ? 2 : 1) + (want_st ? 4 : 0) + (want_cs ? 8 : 0) + ((AUXA && tm_eff > 3) ? 8 : 0) : 0;
     }
     nk = nk_pf;
     if (!more) break;

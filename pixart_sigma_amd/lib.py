@@ -13,7 +13,7 @@ OPERAND = os.environ.get("PXA_OPERAND_DTYPE", "bf16").lower()
 assert OPERAND in ("bf16", "f16"), f"PXA_OPERAND_DTYPE must be bf16 or f16, got {OPERAND!r}"
 OPERAND_DTYPE = torch.float16 if OPERAND == "f16" else torch.bfloat16
 LIB_PATH = os.environ.get("PXA_LIB_PATH") or os.path.join(_HERE, "libpixart_hip_f16.so" if OPERAND == "f16" else "libpixart_hip.so")   # env override: A/B kernel builds
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 c_void_p, c_int, c_long, c_float = C.c_void_p, C.c_int, C.c_long, C.c_float
 
@@ -108,7 +108,8 @@ SIGNATURES = {
     "pxa_vae_nchw_to_grid": [_P, _I, _F, _G, _P],
     "pxa_vae_grid_to_nchw": [_G, _I, _P, _P],
 }
-OTHER_SYMBOLS = ["pxa_last_error", "pxa_abi_version", "pxa_operand_dtype", "pxa_device_info", "pxa_gemm_splitk_ws_elems", "pxa_came_scratch_elems", "pxa_attn_bwd_stats_bytes", "pxa_gemm_set_dynamic_items"]
+OTHER_SYMBOLS = ["pxa_last_error", "pxa_abi_version", "pxa_operand_dtype", "pxa_device_info", "pxa_gemm_splitk_ws_elems", "pxa_came_scratch_elems", "pxa_attn_bwd_stats_bytes", "pxa_gemm_set_dynamic_items",
+                 "pxa_mfma_rate_probe_bytes", "pxa_mfma_rate_probe"]
 
 _lib = None
 
@@ -135,6 +136,8 @@ def load():
     lib.pxa_device_info.argtypes, lib.pxa_device_info.restype = [C.POINTER(c_int), C.POINTER(c_int)], c_int
     lib.pxa_attn_bwd_stats_bytes.argtypes, lib.pxa_attn_bwd_stats_bytes.restype = [c_int, c_int, c_int], c_long
     lib.pxa_gemm_set_dynamic_items.argtypes, lib.pxa_gemm_set_dynamic_items.restype = [c_int], c_int
+    lib.pxa_mfma_rate_probe_bytes.argtypes, lib.pxa_mfma_rate_probe_bytes.restype = [], c_long
+    lib.pxa_mfma_rate_probe.argtypes, lib.pxa_mfma_rate_probe.restype = [c_void_p, c_int, c_int, c_void_p, C.POINTER(C.c_double), c_void_p], c_int
     if lib.pxa_abi_version() != ABI_VERSION:
         raise PixartHipError(f"ABI mismatch: library {lib.pxa_abi_version()} vs binding {ABI_VERSION}")
     lib.pxa_operand_dtype.restype = c_int
