@@ -957,7 +957,9 @@ __global__ __launch_bounds__(512) void gemm_pers_kernel(GemmParams p) {
     // `prev_stores` of them per wave (4 per 32-row slice and output), so the main loop starts while 128 KiB of stores drain instead of
     // behind them (K = 1152 tiles: the store drain was most of a 16 % epilogue cost).  Anything else waits for everything.
     if (GEMM_STORE_OVERLAP && LAYOUT != 2 && EPI != 3) {
-      if (prev_stores == 32) wait_vmcnt<32>();
+      if (prev_stores == 40) wait_vmcnt<40>();
+      else if (prev_stores == 36) wait_vmcnt<36>();
+      else if (prev_stores == 32) wait_vmcnt<32>();
       else if (prev_stores == 28) wait_vmcnt<28>();
       else if (prev_stores == 24) wait_vmcnt<24>();
       else if (prev_stores == 20) wait_vmcnt<20>();
@@ -975,6 +977,33 @@ __global__ __launch_bounds__(512) void gemm_pers_kernel(GemmParams p) {
     if (DYN) nxt = receive();
     if (late) __builtin_amdgcn_s_barrier();            // stagger the second wave of each SIMD by one barrier interval
     PXA_TR(1);
+    // ---- epilogue operands loaded through asm statements with counted waits (round 5; the reasons are at the hand-over below.  Requesting them two k-units
+    // before the end of the main loop was tried and dropped: 36 more live registers there spill 46-82 registers in every aux flavour)
+    constexpr bool EARLY = GEMM_EPI_EARLY && M16 && LAYOUT != 2;      // (the 32-row accumulator layout exists for A/B builds only and keeps the round-4 order)
+    constexpr bool AUXA = EARLY && (EPI == 2 || EPI == 4 || EPI == 6) && !(GEMM_ABL & 16);
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    u32x2 axa[2][2][4];                                // AUXA: aux of two 32-row slices, [slice parity][m tile of the slice][n tile]
+    f32x4 bq[2 * TN];                                  // EARLY: the wave's 64 bias values in accumulator layout
+    const bool has_bias = EARLY && p.bias != nullptr;  // wave-uniform
+    auto bias_issue = [&]() {                          // asm: no compiler-made wait; bias_apply runs behind a counted one
+      const int R4b = lane >> 4;
+#pragma unroll
+      for (int jn = 0; jn < 2 * TN; jn++) {
+        const float* src = p.bias + min(nw + jn * 16 + 4 * R4b, p.N - 4);      // columns beyond N: clamped, never stored
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(bq[jn]) : "v"(src) : "memory");
+      }
+    };
+    auto aux_issue = [&](int i, u32x2 (&dst)[2][4]) {  // rows / columns beyond M / N are clamped: their products are never stored or summed
+      const int R4a = lane >> 4, c16a = lane & 15;
+#pragma unroll
+      for (int mh = 0; mh < 2; mh++)
+#pragma unroll
+        for (int jn = 0; jn < 4; jn++) {
+          const int m = min(mw + i * 32 + 16 * mh + c16a, p.M - 1), n = min(nw + jn * 16 + 4 * R4a, p.N - 4);
+          const bf16_t* src = p.aux + (size_t)m * p.ldaux + n;
+          asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(dst[mh][jn]) : "v"(src) : "memory");
+        }
+    };
     // one k-unit = ONE read phase + ONE matrix phase of 16 MFMAs (two barriers per unit instead of four: half as many hand-overs of the
     // matrix pipe between the two waves of a SIMD).  R: all 12 fragment reads of unit t, the 4 (5 / 3) LDS-DMA pieces of unit t+3, the
     // counted wait (unit t+1 landed; t+2, t+3 in flight) and lgkmcnt(0) - reads are COMPLETE at the barrier, so one barrier separates
@@ -1122,6 +1151,10 @@ __global__ __launch_bounds__(512) void gemm_pers_kernel(GemmParams p) {
         for (int g = 0; g < 16; g++) acc[i][j][g] = a4[i][j][g >> 2][g & 3];
 #endif
     PXA_TR(2);
+    if constexpr (LAYOUT != 2) {                       // the epilogue's own loads go out as soon as this wave's last matrix phase is issued (see the hand-over)
+      if (has_bias) bias_issue();
+      if constexpr (AUXA) { aux_issue(0, axa[0]); aux_issue(1, axa[1]); }
+    }
     if (!late) __builtin_amdgcn_s_barrier();           // every wave has executed the same number of barriers; the ring is idle
     PXA_TR(3);
 
@@ -1210,22 +1243,9 @@ __global__ __launch_bounds__(512) void gemm_pers_kernel(GemmParams p) {
     // each waited like that, cost fc2's dX 240 us per launch over its plain twin, 215 of them gone with the aux loads ablated).  So (GEMM_EPI_EARLY):
     //   * the bias is added BEFORE the prefetch is issued (its wait then covers only itself), for every 16-bit flavour;
     //   * the aux flavours with a compiled-in activation (x aux: EPI 2; + aux: EPI 4 / 6) load aux through asm statements with hand-counted waits:
-    //     issue order  L0 L1 | wait(L0) apply(0) | L2 | PREFETCH (pf_ops) | S0 | wait(L1) apply(1) | L3 | S1 | wait(L2) apply(2) | S2 | wait(L3) apply(3) | S3
-    //     (L = the 8 loads of a 32-row slice, S = its 4 stores): a slice's aux is two slices ahead of its use and no wait reaches back over the
-    //     prefetch.  Half items (2 slices): L0 L1 | wait apply(0) | PREFETCH | S0 | wait(L1) apply(1) | S1.
-    constexpr bool AUXA = GEMM_EPI_EARLY && M16 && (EPI == 2 || EPI == 4 || EPI == 6) && !(GEMM_ABL & 16);
-    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-    u32x2 axa[2][2][4];                                // AUXA: [slice parity][m tile of the slice][n tile]
-    constexpr bool EARLY = GEMM_EPI_EARLY && M16;      // (the 32-row accumulator layout exists for A/B builds only and keeps the round-4 order)
-    f32x4 bq[2 * TN];                                  // EARLY: the wave's 64 bias values in accumulator layout, loaded through asm (no compiler-made wait)
-    auto bias_issue = [&]() {
-      const int R4b = le >> 4;
-#pragma unroll
-      for (int jn = 0; jn < 2 * TN; jn++) {
-        const float* src = p.bias + min(nw + jn * 16 + 4 * R4b, p.N - 4);      // columns beyond N: clamped, never stored
-        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(bq[jn]) : "v"(src) : "memory");
-      }
-    };
+    //     issue order  L0 L1 | PREFETCH (pf_ops) | wait(L0) apply(0) | L2 | S0 | wait(L1) apply(1) | L3 | S1 | wait(L2) apply(2) | S2 | wait(L3) apply(3) | S3
+    //     (L = the 8 loads of a 32-row slice, S = its 4 stores): a slice's aux is two slices ahead of its use, every wait names how many YOUNGER requests
+    //     may stay in flight, and none of them makes the prefetch land.  Half items (2 slices): L0 L1 | PREFETCH | wait(L0) apply(0) | S0 | wait(L1) apply(1) | S1.
     auto bias_apply = [&]() {                          // behind a counted wait that covers the four loads
       asm volatile("" : "+v"(bq[0]), "+v"(bq[1]), "+v"(bq[2]), "+v"(bq[3]));
 #pragma unroll
@@ -1269,17 +1289,6 @@ __global__ __launch_bounds__(512) void gemm_pers_kernel(GemmParams p) {
       else if (allowed >= 4) wait_vmcnt<4>();
       else wait_vmcnt<0>();
     };
-    auto aux_issue = [&](int i, u32x2 (&dst)[2][4]) {  // rows / columns beyond M / N are clamped: their products are never stored or summed
-      const int R4a = le >> 4, c16a = le & 15;
-#pragma unroll
-      for (int mh = 0; mh < 2; mh++)
-#pragma unroll
-        for (int jn = 0; jn < 4; jn++) {
-          const int m = min(mw + i * 32 + 16 * mh + c16a, p.M - 1), n = min(nw + jn * 16 + 4 * R4a, p.N - 4);
-          const bf16_t* src = p.aux + (size_t)m * p.ldaux + n;
-          asm volatile("global_load_dwordx2 %0, %1, off" : "=v"(dst[mh][jn]) : "v"(src) : "memory");
-        }
-    };
     auto aux_ready = [&](int allowed, u32x2 (&a)[2][4]) {
       wait_allow(allowed);
       // (the registers pass through an asm statement behind the wait: no use of them can be scheduled in front of it)
@@ -1297,18 +1306,13 @@ __global__ __launch_bounds__(512) void gemm_pers_kernel(GemmParams p) {
           else { v[0] *= a0; v[1] *= a1; v[2] *= a2f; v[3] *= a3; }
         }
     };
-    const bool has_bias = EARLY && p.bias != nullptr;  // wave-uniform
-    if (has_bias) bias_issue();
+    hand_over();                                       // (the prefetch's address arithmetic and its 10-12 issues run under the latency of the bias / slice 0, requested above)
     if constexpr (AUXA) {
-      aux_issue(0, axa[0]);
-      aux_issue(1, axa[1]);
-      aux_ready(8, axa[0]);                            // the bias (older) and slice 0 have landed
+      aux_ready(8 + pf_ops, axa[0]);                   // the bias (older) and slice 0 have landed; slice 1 and the prefetch may still be in flight
       if (has_bias) bias_apply();
       aux_apply(0, axa[0]);
       if (tm_eff > 2) aux_issue(2, axa[0]);
-    }
-    hand_over();
-    if constexpr (!AUXA) {
+    } else {
       if (has_bias) { wait_allow(pf_ops); bias_apply(); }      // the prefetch, issued behind the bias loads, stays in flight
     }
     PXA_TR(4);
@@ -1395,7 +1399,7 @@ __global__ __launch_bounds__(512) void gemm_pers_kernel(GemmParams p) {
             aux_apply(1, axa[1]);
             if (tm_eff > 3) aux_issue(3, axa[1]);
           } else if (i == 2) {
-            aux_ready(interior_a ? pf_ops + 16 : 0, axa[0]);
+            aux_ready(interior_a ? 16 : 0, axa[0]);
             aux_apply(2, axa[0]);
           } else if (i == 3) {
             aux_ready(interior_a ? 8 : 0, axa[1]);
@@ -1502,7 +1506,7 @@ __global__ __launch_bounds__(512) void gemm_pers_kernel(GemmParams p) {
     {   // stores this wave has just issued, if every one of them was a full (unpredicated) 16-byte row segment
       const bool interior = mw + tm_eff * 32 <= p.M && nw + 64 <= p.N;
       // (the statistics / column-sum flavours issue 4 / 8 more vector-memory instructions behind the stores: their atomics)
-      prev_stores = (interior && p.out) ? tm_eff * 4 * ((dual && !(GEMM_ABL & 32)) ? 2 : 1) + (want_st ? 4 : 0) + (want_cs ? 8 : 0) + ((AUXA && tm_eff > 3) ? 8 : 0) : 0;
+      prev_stores = (interior && p.out) ? tm_eff * 4 * ((dual && !(GEMM_ABL & 32)) ? 2 : 1) + (want_st ? 4 : 0) + (want_cs ? 8 : 0) + ((AUXA && tm_eff > 2) ? 16 : 0) : 0;
     }
     nk = nk_pf;
     if (!more) break;
