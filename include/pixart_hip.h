@@ -150,6 +150,11 @@ typedef struct {
   long colsum_stride;
   void* bwd_stats;   /* optional (bwd) workspace of pxa_attn_bwd_stats_bytes(B, H, Nq) bytes, 16-byte aligned: lse / delta as operand-type rows, which the
                         dK/dV kernel takes through its matrix products (round 3).  NULL: the round-2 dK/dV kernel runs. */
+  int q_prescaled;   /* 0: q holds the queries as the reference's qkv linear produces them (PixArt_blocks.py:130-131).  1 (round 5): q holds
+                        (scale * log2 e) * queries - the caller folded the softmax scale into the projection that produced q (engine.py: a copy of the
+                        qkv weight's q rows times that constant, ONE rounding of the scaled query) - so the kernels exponentiate q k^T as it comes out of
+                        the matrix product; lse keeps its meaning, dq is still the gradient with respect to the UNSCALED queries (what the projection's
+                        backward needs), dk / dv are unchanged.  Same results up to the rounding point of q. */
 } pxa_attn_args;
 int pxa_attn_fwd(const pxa_attn_args* args, hipStream_t stream);
 /* backward: delta pre-pass, then the dQ kernel (skipped when dq == NULL) and the dK/dV kernel (skipped when dk == dv == NULL) */
@@ -193,6 +198,11 @@ int pxa_clip_coef(const float* sumsq, float* out2, float max_norm, float inv_wor
 int pxa_adamw_step(float* p, const float* g, float* m, float* v, void* p_bf16, long n, float lr, float beta1, float beta2,
                    float eps, float weight_decay, int step, const float* gscale, hipStream_t stream);
 int pxa_cast_f32_bf16(const float* x, void* y_bf16, long n, hipStream_t stream);
+/* nblocks strided copies of n_total fp32 values each (block b at src + b * src_stride -> dst + b * dst_stride), the first n_scaled of every block times
+ * `scale`, rounded ONCE to the operand type (y_bf16) and / or kept fp32 (y_f32); either output may be NULL.  The forward-only copy of every block's
+ * attn.qkv weight / bias whose q rows carry the softmax scale (pxa_attn_args.q_prescaled): one launch for all blocks after each optimizer step. */
+int pxa_scale_copy_f32(const float* src, long src_stride, void* y_bf16, float* y_f32, long dst_stride, int nblocks, long n_scaled, long n_total,
+                       float scale, hipStream_t stream);
 /* Loss-scaled (fp16-operand) training: the reference's mixed_precision='fp16' (configs/PixArt_xl2_internal.py:57) runs accelerate's
  * torch.cuda.amp.GradScaler around loss.backward() / clip_grad_norm_ / optimizer.step() (train_scripts/train.py:180-184).  Here the
  * same protocol lives on the device in a 5-float record `scaler`:

@@ -57,7 +57,8 @@ struct AttnParams {
   int dq_hs, dk_hs, dv_hs;
   int B, H, Nq, Nk;
   const int* kv_start; const int* kv_len;  // optional per-batch varlen (rows into the packed K/V)
-  float scale, scale_log2;
+  float scale, scale_log2;      // softmax scale (the dq stores); the factor in front of q k^T inside exp2: scale * log2 e, or 1 when q arrives prescaled
+  float dk_scale;               // what the dk stores multiply by: scale, or ln 2 = scale / (scale * log2 e) when the q operand of dS^T q already carries the rest
   int nx;              // blocks per (batch, head) of the launch: the grid is the flat nx * H * B, see block_coords()
   const bf16_t* stats; // dK/dV kernel, round 3: [2][B][H][Nq64] rows of 8 operands {hi, lo, 0 x 6}: lse / scale_log2 and delta, see "stats rows"
   int Nq64;            // Nq rounded up to the 64-query tile
@@ -1079,10 +1080,10 @@ __global__ __launch_bounds__(256, ATTN_BWD_WAVES) void attn_bwd_dkv_kernel(AttnP
     }
   }
   if (kvvalid) {
-    store_rows(p.dK + dkbase + (long)kv * p.dk_ts + (long)h * p.dk_hs, dk, p.scale, hi);
+    store_rows(p.dK + dkbase + (long)kv * p.dk_ts + (long)h * p.dk_hs, dk, p.dk_scale, hi);
     store_rows(p.dV + dvbase + (long)kv * p.dv_ts + (long)h * p.dv_hs, dv, 1.f, hi);
   }
-  if (p.dk_colsum) colsum_rows(p.dk_colsum + (b % PXA_COLSUM_SLOTS) * p.colsum_stride + h * DH, dk, p.scale, kvvalid, hi, lane);
+  if (p.dk_colsum) colsum_rows(p.dk_colsum + (b % PXA_COLSUM_SLOTS) * p.colsum_stride + h * DH, dk, p.dk_scale, kvvalid, hi, lane);
   if (p.dv_colsum) colsum_rows(p.dv_colsum + (b % PXA_COLSUM_SLOTS) * p.colsum_stride + h * DH, dv, 1.f, kvvalid, hi, lane);
 }
 
@@ -1385,10 +1386,10 @@ __global__ __launch_bounds__(256, DKV2_WAVES) void attn_bwd_dkv2_kernel(AttnPara
     phaseC(smem + (prv - lds0), smem + (prv - lds0) + TILE_B + STAT_B, 1, pb1, db1);
   }
   if (kvvalid) {
-    store_rows(p.dK + dkbase + (long)kv * p.dk_ts + (long)h * p.dk_hs, dk, p.scale, hi);
+    store_rows(p.dK + dkbase + (long)kv * p.dk_ts + (long)h * p.dk_hs, dk, p.dk_scale, hi);
     store_rows(p.dV + dvbase + (long)kv * p.dv_ts + (long)h * p.dv_hs, dv, 1.f, hi);
   }
-  if (p.dk_colsum) colsum_rows(p.dk_colsum + (b % PXA_COLSUM_SLOTS) * p.colsum_stride + h * DH, dk, p.scale, kvvalid, hi, lane);
+  if (p.dk_colsum) colsum_rows(p.dk_colsum + (b % PXA_COLSUM_SLOTS) * p.colsum_stride + h * DH, dk, p.dk_scale, kvvalid, hi, lane);
   if (p.dv_colsum) colsum_rows(p.dv_colsum + (b % PXA_COLSUM_SLOTS) * p.colsum_stride + h * DH, dv, 1.f, kvvalid, hi, lane);
 }
 
@@ -1935,10 +1936,10 @@ __global__ __launch_bounds__(512, 2) void attn_bwd_dkv3_kernel(AttnParams p) {
   }
   if (grp == 0) bar();                                      // group 1's last phase
   if (kvvalid) {
-    store_rows(p.dK + dkbase + (long)kv * p.dk_ts + (long)h * p.dk_hs, dk, p.scale, hi);
+    store_rows(p.dK + dkbase + (long)kv * p.dk_ts + (long)h * p.dk_hs, dk, p.dk_scale, hi);
     store_rows(p.dV + dvbase + (long)kv * p.dv_ts + (long)h * p.dv_hs, dv, 1.f, hi);
   }
-  if (p.dk_colsum) colsum_rows(p.dk_colsum + (b % PXA_COLSUM_SLOTS) * p.colsum_stride + h * DH, dk, p.scale, kvvalid, hi, lane);
+  if (p.dk_colsum) colsum_rows(p.dk_colsum + (b % PXA_COLSUM_SLOTS) * p.colsum_stride + h * DH, dk, p.dk_scale, kvvalid, hi, lane);
   if (p.dv_colsum) colsum_rows(p.dv_colsum + (b % PXA_COLSUM_SLOTS) * p.colsum_stride + h * DH, dv, 1.f, kvvalid, hi, lane);
 }
 
@@ -2437,6 +2438,7 @@ template <int W = -1> __device__ __forceinline__ void mfma32_acc(f32x16& d, cons
 #endif
 constexpr int DKV4_STAGES = 4;
 constexpr int dkv4_nreads(int i) { const int k = ((i % 22) + 22) % 22; return k < 10 ? 1 : 2; }   // fragment i of a step: 10 row fragments, 12 transposed ones
+template <bool PRE>     // PRE: q arrives as (scale log2 e) x queries (pxa_attn_args.q_prescaled): S needs no multiply in front of exp2
 __global__ __launch_bounds__(256, 1) void attn_bwd_dkv4_kernel(AttnParams p) {
   __shared__ __attribute__((aligned(16))) char smem[DKV4_STAGES * STAGE_B];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), hi = lane >> 5;
@@ -2595,7 +2597,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv4_kernel(AttnParams p) {
 #pragma unroll
     for (int kb = 0; kb < 2; kb++)
 #pragma unroll
-      for (int g = 0; g < 16; g++) S[0][kb][g] *= c;               // (inside the loop the next step's scores are scaled under the dK MFMAs)
+      for (int g = 0; g < 16; g++) if (!PRE) S[0][kb][g] *= c;     // (inside the loop the next step's scores are scaled under the dK MFMAs)
     static_for<4>([&](auto ic) { rd_frag(IntC<0>{}, ic, f[decltype(ic)::value], cb, cb); });   // step 0 (tile 0, sub 0): fragments 0..3 = Q rows of (0, sub 1)
   }
 
@@ -2665,7 +2667,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv4_kernel(AttnParams p) {
         constexpr int e0 = (32 * (gi - 32)) / 12, e1 = (32 * (gi - 31)) / 12;
         static_for<e1 - e0>([&](auto ec) {
           constexpr int e = e0 + decltype(ec)::value;
-          if (!(DKV4_ABL & 4)) S[NXT][e >> 4][e & 15] *= c;
+          if (!PRE && !(DKV4_ABL & 4)) S[NXT][e >> 4][e & 15] *= c;     // (a plain `if` on the template constant: `if constexpr` here loses the lambda's capture of S)
           asm volatile("" : "+v"(S[NXT][e >> 4][e & 15]));
         });
       }
@@ -2728,10 +2730,10 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv4_kernel(AttnParams p) {
   for (int kb = 0; kb < 2; kb++) {
     const bool kvok = kv[kb] < p.Nk;
     if (kvok) {
-      store_rows(p.dK + dkbase + (long)kv[kb] * p.dk_ts + (long)h * p.dk_hs, dk[kb], p.scale, hi);
+      store_rows(p.dK + dkbase + (long)kv[kb] * p.dk_ts + (long)h * p.dk_hs, dk[kb], p.dk_scale, hi);
       store_rows(p.dV + dvbase + (long)kv[kb] * p.dv_ts + (long)h * p.dv_hs, dv[kb], 1.f, hi);
     }
-    if (p.dk_colsum) colsum_rows(p.dk_colsum + (b % PXA_COLSUM_SLOTS) * p.colsum_stride + h * DH, dk[kb], p.scale, kvok, hi, lane);
+    if (p.dk_colsum) colsum_rows(p.dk_colsum + (b % PXA_COLSUM_SLOTS) * p.colsum_stride + h * DH, dk[kb], p.dk_scale, kvok, hi, lane);
     if (p.dv_colsum) colsum_rows(p.dv_colsum + (b % PXA_COLSUM_SLOTS) * p.colsum_stride + h * DH, dv[kb], 1.f, kvok, hi, lane);
   }
 }
@@ -2742,6 +2744,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv4_kernel(AttnParams p) {
 // partner wave's softmax too few slots; the one-wave kernel has them (ablation r4_17: its vector and LDS work fit with room).  P and dS take pack_xy's
 // lane exchange (4 v_permlane16_swap per 32 x 32 block), the A operands are trfrag16 reads; dK^T / dV^T leave through store_rows16 (PXA_ATTN_DKV=5).
 // Alone 2.5 % faster than attn_bwd_dkv4_kernel, inside the training step 2.4 ms per step slower (profiles/r4_34_step_ab_attention.txt): an A/B partner, not the default.
+template <bool PRE>     // PRE: q arrives as (scale log2 e) x queries (pxa_attn_args.q_prescaled): S needs no multiply in front of exp2
 __global__ __launch_bounds__(256, 1) void attn_bwd_dkv5_kernel(AttnParams p) {
   __shared__ __attribute__((aligned(16))) char smem[DKV4_STAGES * STAGE_B];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), hi = lane >> 5;
@@ -2902,7 +2905,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv5_kernel(AttnParams p) {
 #pragma unroll
     for (int kb = 0; kb < 2; kb++)
 #pragma unroll
-      for (int g = 0; g < 16; g++) S[0][kb][g] *= c;               // (inside the loop the next step's scores are scaled under the dK MFMAs)
+      for (int g = 0; g < 16; g++) if (!PRE) S[0][kb][g] *= c;     // (inside the loop the next step's scores are scaled under the dK MFMAs)
     static_for<4>([&](auto ic) { rd_frag(IntC<0>{}, ic, f[decltype(ic)::value], cb, cb); });   // step 0 (tile 0, sub 0): fragments 0..3 = Q rows of (0, sub 1)
   }
 
@@ -2961,7 +2964,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv5_kernel(AttnParams p) {
       } else if constexpr (gi < 56) {
         static_for<2>([&](auto ec) {
           constexpr int e = 2 * (gi - 40) + decltype(ec)::value;
-          if (!(DKV4_ABL & 4)) S[NXT][e >> 4][e & 15] *= c;
+          if (!PRE && !(DKV4_ABL & 4)) S[NXT][e >> 4][e & 15] *= c;     // (a plain `if` on the template constant: `if constexpr` here loses the lambda's capture of S)
           asm volatile("" : "+v"(S[NXT][e >> 4][e & 15]));
         });
       }
@@ -3042,9 +3045,9 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv5_kernel(AttnParams p) {
   for (int kb = 0; kb < 2; kb++) {
     const long k0 = (long)bx * 256 + wave * 64 + kb * 32;          // first key of the block: lane (R, c) stores rows k0 + c and k0 + 16 + c
     const bool kvok = k0 < p.Nk;                                   // whole block or none (Nk % 64 == 0)
-    store_rows16(p.dK + dkbase + k0 * p.dk_ts + (long)h * p.dk_hs, p.dk_ts, dk[kb], p.scale, p.scale, kvok, kvok, lane);
+    store_rows16(p.dK + dkbase + k0 * p.dk_ts + (long)h * p.dk_hs, p.dk_ts, dk[kb], p.dk_scale, p.dk_scale, kvok, kvok, lane);
     store_rows16(p.dV + dvbase + k0 * p.dv_ts + (long)h * p.dv_hs, p.dv_ts, dv[kb], 1.f, 1.f, kvok, kvok, lane);
-    if (p.dk_colsum) colsum_rows16(p.dk_colsum + (b % PXA_COLSUM_SLOTS) * p.colsum_stride + h * DH, dk[kb], p.scale, kvok, kvok, lane);
+    if (p.dk_colsum) colsum_rows16(p.dk_colsum + (b % PXA_COLSUM_SLOTS) * p.colsum_stride + h * DH, dk[kb], p.dk_scale, kvok, kvok, lane);
     if (p.dv_colsum) colsum_rows16(p.dv_colsum + (b % PXA_COLSUM_SLOTS) * p.colsum_stride + h * DH, dv[kb], 1.f, kvok, kvok, lane);
   }
 }
@@ -3357,7 +3360,8 @@ int fill(AttnParams& p, const pxa_attn_args* a) {
   p.dv_bs = a->dv_bs; p.dv_ts = a->dv_ts; p.dv_hs = a->dv_hs;
   p.B = a->B; p.H = a->H; p.Nq = a->Nq; p.Nk = a->Nk;
   p.kv_start = a->kv_start; p.kv_len = a->kv_len;
-  p.scale = a->scale; p.scale_log2 = a->scale * 1.4426950408889634f;
+  p.scale = a->scale; p.scale_log2 = a->scale * 1.4426950408889634f; p.dk_scale = a->scale;
+  if (a->q_prescaled) { p.scale_log2 = 1.0f; p.dk_scale = 0.6931471805599453f; }      // q = (scale log2 e) x queries: see pxa_attn_args.q_prescaled
   p.stats = (const bf16_t*)a->bwd_stats; p.Nq64 = (a->Nq + BKV - 1) / BKV * BKV;
   const long strides[] = {p.q_ts, p.k_ts, p.v_ts, p.o_ts, p.q_hs, p.k_hs, p.v_hs, p.o_hs, p.q_bs, p.k_bs, p.v_bs, p.o_bs};
   for (long s : strides) PXA_CHECK(s % 8 == 0, "attn: strides must be multiples of 8 elements (16-byte rows)");
@@ -3492,8 +3496,10 @@ extern "C" int pxa_attn_bwd(const pxa_attn_args* a, hipStream_t stream) {
     p.nx = dkv_mode >= 3 ? (max_k + 255) / 256 : (max_k + 127) / 128;
     PXA_CHECK((long)p.nx * p.H * p.B < (1L << 31), "pxa_attn_bwd: grid too large");
     if (p.nx > 0) {
-      if (dkv_mode == 5) hipLaunchKernelGGL(attn_bwd_dkv5_kernel, dim3(p.nx * p.H * p.B), dim3(256), 0, stream, p);
-      else if (dkv_mode == 4) hipLaunchKernelGGL(attn_bwd_dkv4_kernel, dim3(p.nx * p.H * p.B), dim3(256), 0, stream, p);
+      if (dkv_mode == 5 && a->q_prescaled) hipLaunchKernelGGL(attn_bwd_dkv5_kernel<true>, dim3(p.nx * p.H * p.B), dim3(256), 0, stream, p);
+      else if (dkv_mode == 5) hipLaunchKernelGGL(attn_bwd_dkv5_kernel<false>, dim3(p.nx * p.H * p.B), dim3(256), 0, stream, p);
+      else if (dkv_mode == 4 && a->q_prescaled) hipLaunchKernelGGL(attn_bwd_dkv4_kernel<true>, dim3(p.nx * p.H * p.B), dim3(256), 0, stream, p);
+      else if (dkv_mode == 4) hipLaunchKernelGGL(attn_bwd_dkv4_kernel<false>, dim3(p.nx * p.H * p.B), dim3(256), 0, stream, p);
       else if (dkv_mode == 3) hipLaunchKernelGGL(attn_bwd_dkv3_kernel<2>, dim3(p.nx * p.H * p.B), dim3(512), 0, stream, p);   // prefetch distances 3 / 4 / 6 measured the same
       else if (dkv_mode == 2) hipLaunchKernelGGL(attn_bwd_dkv2_kernel<1>, dim3(p.nx * p.H * p.B), dim3(256), 0, stream, p);
       else if (dkv_mode == 1) hipLaunchKernelGGL(attn_bwd_dkv2_kernel<0>, dim3(p.nx * p.H * p.B), dim3(256), 0, stream, p);

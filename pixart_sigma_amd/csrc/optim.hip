@@ -140,6 +140,30 @@ extern "C" int pxa_adamw_step_scaled(float* p, const float* g, float* m, float* 
   PXA_LAUNCH_CHECK();
   return 0;
 }
+namespace {
+__global__ __launch_bounds__(256) void scale_copy_kernel(const float* __restrict__ x, long xs, bf16_t* __restrict__ yb, float* __restrict__ yf, long ys, long n_scaled,
+                                                        long n_total, float scale) {
+  const float* xb = x + (long)blockIdx.y * xs;
+  const long n4 = n_total / 4;                         // (checked by the entry point: n_scaled and n_total are multiples of 4)
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+    float4 v = reinterpret_cast<const float4*>(xb)[i];
+    if (4 * i < n_scaled) { v.x *= scale; v.y *= scale; v.z *= scale; v.w *= scale; }
+    if (yb) reinterpret_cast<uint2*>(yb + (long)blockIdx.y * ys)[i] = pxa::pack_bf16x4(v.x, v.y, v.z, v.w);
+    if (yf) reinterpret_cast<float4*>(yf + (long)blockIdx.y * ys)[i] = v;
+  }
+}
+}  // namespace
+extern "C" int pxa_scale_copy_f32(const float* src, long src_stride, void* y_bf16, float* y_f32, long dst_stride, int nblocks, long n_scaled, long n_total,
+                                  float scale, hipStream_t stream) {
+  PXA_CHECK(src && (y_bf16 || y_f32) && nblocks > 0 && n_total > 0 && n_scaled >= 0 && n_scaled <= n_total, "pxa_scale_copy_f32: bad args");
+  PXA_CHECK(n_total % 4 == 0 && n_scaled % 4 == 0 && src_stride % 4 == 0 && dst_stride % 4 == 0 && ((uintptr_t)src % 16) == 0 &&
+            ((uintptr_t)y_bf16 % 8) == 0 && ((uintptr_t)y_f32 % 16) == 0, "pxa_scale_copy_f32: counts / strides must be multiples of 4 elements, pointers 16-byte aligned");
+  const long per = (n_total / 4 + 255) / 256;
+  hipLaunchKernelGGL(scale_copy_kernel, dim3((unsigned)(per < 2048 ? per : 2048), nblocks), dim3(256), 0, stream, src, src_stride, (bf16_t*)y_bf16, y_f32, dst_stride,
+                     n_scaled, n_total, scale);
+  PXA_LAUNCH_CHECK();
+  return 0;
+}
 extern "C" int pxa_cast_f32_bf16(const float* x, void* y_bf16, long n, hipStream_t stream) {
   PXA_CHECK(x && y_bf16 && n > 0, "pxa_cast_f32_bf16: bad args");
   PXA_CHECK(((uintptr_t)x % 16) == 0 && ((uintptr_t)y_bf16 % 8) == 0, "pxa_cast_f32_bf16: unaligned");

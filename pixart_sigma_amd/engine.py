@@ -174,6 +174,14 @@ class Engine:
         # Key = identity + version of y / the drop mask / y_null and the lengths; any training forward (save != None) clears it - weights may change.
         self._text_cache = None
         self.grad_ready_hook = None   # callable(prefix) fired when a parameter group's gradients are complete
+        # Round 5: the softmax scale rides in the qkv projection.  The forward multiplies by a COPY of every block's attn.qkv weight / bias whose q rows
+        # carry scale * log2 e (cast from the fp32 master in one rounding; ops.scale_copy, one launch per run of equally spaced blocks after each optimizer
+        # step), so q leaves the GEMM as the exponent's argument: the attention kernels take q k^T straight into exp2 (pxa_attn_args.q_prescaled) - one
+        # multiply per score less in the dK/dV kernel, and the fp16 forward's folded first product loses its second rounding of q.  The backward is
+        # untouched: dq comes out with respect to the unscaled queries and the dX / dW GEMMs read the true weights.  Off under qk_norm (the LayerNorm behind
+        # the projection would normalise the factor away) and with PXA_Q_PRESCALE=0 (A/B).
+        self.prescale = (not cfg.get("qk_norm")) and os.environ.get("PXA_Q_PRESCALE", "1") != "0" and cfg["hidden_size"] // cfg["num_heads"] == 72
+        self._qs = None
 
     # ------------------------------------------------------------------ helpers
     def pos_table(self, h, w):
@@ -197,6 +205,31 @@ class Engine:
         if need_dx:
             return ops.gemm(dy, S.w(name + ".weight"), NN, **(dx_kw or {}))
         return None
+
+    def _qkv_prescaled(self, l):
+        """(weight (3D, D) in the operand type, bias (3D,) fp32) of block l with the q rows times scale * log2 e; rebuilt when the weights changed."""
+        S, D = self.S, self.cfg["hidden_size"]
+        qs = self._qs
+        if qs is None or qs["gen"] != S.generation:
+            depth = self.cfg["depth"]
+            w = torch.empty((depth, 3 * D, D), dtype=BF16, device=S.device)
+            b = torch.empty((depth, 3 * D), dtype=F32, device=S.device)
+            offw = [S.offset[f"blocks.{i}.attn.qkv.weight"] for i in range(depth)]
+            offb = [S.offset[f"blocks.{i}.attn.qkv.bias"] for i in range(depth)]
+            i = 0
+            while i < depth:                                  # runs of equally spaced blocks (KV-compressed blocks carry extra parameters): one launch per run
+                n, st = 1, 0
+                if i + 1 < depth:
+                    st = offw[i + 1] - offw[i]
+                    while i + n < depth and offw[i + n] - offw[i + n - 1] == st and offb[i + n] - offb[i + n - 1] == st:
+                        n += 1
+                ops.scale_copy(S.master[offw[i]:], st if n > 1 else 0, n, D * D, 3 * D * D, ops.Q_PRESCALE, out_bf16=w[i:i + n])
+                ops.scale_copy(S.master[offb[i]:], st if n > 1 else 0, n, D, 3 * D, ops.Q_PRESCALE, out_f32=b[i:i + n])
+                i += n
+            qs = dict(gen=S.generation, w=w, b=b)
+            if not _capturing():                              # a buffer first allocated during graph capture lives in the graph's pool: not cached
+                self._qs = qs
+        return qs["w"][l], qs["b"][l]
 
     # ------------------------------------------------------------------ caption branch
     def caption_fwd(self, y, row_idx, L, drop, y_null):
@@ -227,7 +260,12 @@ class Engine:
         st = 6 * D
         r = ops.ln_mod_fwd(x_prev, sm, scm, st, u=u_prev, gate=gate_prev, gate_stride=st, rows_per_batch=N, want_stats=True)
         x_in, xn1, mean1, rstd1 = r["x"], r["xn"], r["mean"], r["rstd"]
-        qkv = self._lin(xn1, p + "attn.qkv")
+        pre = dict(q_prescaled=True) if self.prescale else {}
+        if self.prescale:
+            wq, bq = self._qkv_prescaled(l)
+            qkv = ops.gemm(xn1, wq, NT, bias=bq)
+        else:
+            qkv = self._lin(xn1, p + "attn.qkv")
         qkn = None
         if c.get("qk_norm"):        # q_norm / k_norm on the full-resolution q, k column blocks, in place (PixArt_blocks.py:133-134)
             qkn = (ops.ln_affine_fwd(qkv[:, :D], S.f(p + "attn.q_norm.weight"), S.f(p + "attn.q_norm.bias")),
@@ -246,11 +284,11 @@ class Engine:
                 vc = ops.kv_compress_fwd(qkv[:, 2 * D:], N * 3 * D, 3 * D, cw, cb, lw, lb, B, hh, ww, D, sr)
                 Nk = kc.shape[1]
                 sk = (Nk * D, D, 72)
-                ops.attention_fwd(qkv[:, :D], kc, vc, a, lse, B, H, N, Nk, (s3, sk, sk, (N * D, D, 72)))
+                ops.attention_fwd(qkv[:, :D], kc, vc, a, lse, B, H, N, Nk, (s3, sk, sk, (N * D, D, 72)), **pre)
             elif c["kv_sampling"] == "uniform_every":
                 Nk = (N + sr - 1) // sr
                 sk = (N * 3 * D, 3 * D * sr, 72)
-                ops.attention_fwd(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], a, lse, B, H, N, Nk, (s3, sk, sk, (N * D, D, 72)))
+                ops.attention_fwd(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], a, lse, B, H, N, Nk, (s3, sk, sk, (N * D, D, 72)), **pre)
             elif c["kv_sampling"] in ("uniform", "ave"):      # 'ave' = nearest interpolation = the same strided pick (PixArt_blocks.py:110-115)
                 Nk = (hh // sr) * (ww // sr)
                 kc = torch.empty((B, Nk, D), dtype=BF16, device=qkv.device)
@@ -258,11 +296,11 @@ class Engine:
                 ops.kv_pick(qkv[:, D:2 * D], kc, N * 3 * D, 3 * D, B, hh, ww, D, sr)
                 ops.kv_pick(qkv[:, 2 * D:], vc, N * 3 * D, 3 * D, B, hh, ww, D, sr)
                 sk = (Nk * D, D, 72)
-                ops.attention_fwd(qkv[:, :D], kc, vc, a, lse, B, H, N, Nk, (s3, sk, sk, (N * D, D, 72)))
+                ops.attention_fwd(qkv[:, :D], kc, vc, a, lse, B, H, N, Nk, (s3, sk, sk, (N * D, D, 72)), **pre)
             else:
                 raise ValueError(f"unknown kv sampling mode {c['kv_sampling']!r}")
         else:
-            ops.attention_fwd(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], a, lse, B, H, N, N, (s3, s3, s3, (N * D, D, 72)))
+            ops.attention_fwd(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], a, lse, B, H, N, N, (s3, s3, s3, (N * D, D, 72)), **pre)
         u1 = self._lin(a, p + "attn.proj")
         r = ops.ln_mod_fwd(x_in, u=u1, gate=gm, gate_stride=st, want_xn=False, want_xb=True, rows_per_batch=N)
         x1, x1b = r["x"], r["xb"]
@@ -338,16 +376,17 @@ class Engine:
         s3 = (N * 3 * D, 3 * D, 72)
         so = (N * D, D, 72)
         sr = sv["sr"]
+        pre = dict(q_prescaled=True) if self.prescale else {}
         if sr == 1:
             dqkv = torch.empty_like(qkv)
             ops.attention_bwd(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], sv["a"], da, sv["lse"], delta, dqkv[:, :D], dqkv[:, D:2 * D], dqkv[:, 2 * D:],
-                              B, H, N, N, (s3, s3, s3, so), (s3, s3, s3))
+                              B, H, N, N, (s3, s3, s3, so), (s3, s3, s3), **pre)
         elif c["kv_sampling"] == "uniform_every":          # strided keys: gradients land on the picked tokens, the rest stay zero
             dqkv = torch.zeros_like(qkv)
             Nk = (N + sr - 1) // sr
             sk = (N * 3 * D, 3 * D * sr, 72)
             ops.attention_bwd(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], sv["a"], da, sv["lse"], delta, dqkv[:, :D], dqkv[:, D:2 * D], dqkv[:, 2 * D:],
-                              B, H, N, Nk, (s3, sk, sk, so), (s3, sk, sk))
+                              B, H, N, Nk, (s3, sk, sk, so), (s3, sk, sk), **pre)
         else:                                               # compressed K/V buffers: attention backward, then the compression's backward
             hh, ww = ctx["hw"]
             kc, vc = sv["kc"], sv["vc"]
@@ -356,7 +395,7 @@ class Engine:
             covered = (hh % sr == 0) and (ww % sr == 0) and c["kv_sampling"] == "conv"
             dqkv = torch.empty_like(qkv) if covered else torch.zeros_like(qkv)
             dkc, dvc = torch.empty_like(kc), torch.empty_like(vc)
-            ops.attention_bwd(qkv[:, :D], kc, vc, sv["a"], da, sv["lse"], delta, dqkv[:, :D], dkc, dvc, B, H, N, Nk, (s3, sk, sk, so), (s3, sk, sk))
+            ops.attention_bwd(qkv[:, :D], kc, vc, sv["a"], da, sv["lse"], delta, dqkv[:, :D], dkc, dvc, B, H, N, Nk, (s3, sk, sk, so), (s3, sk, sk), **pre)
             if c["kv_sampling"] == "conv":
                 cw, cb, lw = S.f(p + "attn.sr.weight"), S.f(p + "attn.sr.bias"), S.f(p + "attn.norm.weight")
                 gcw, gcb = S.g(p + "attn.sr.weight"), S.g(p + "attn.sr.bias")

@@ -65,7 +65,7 @@ class AttnArgs(C.Structure):
                 ("B", c_int), ("H", c_int), ("Nq", c_int), ("Nk", c_int), ("head_dim", c_int),
                 ("kv_start", c_void_p), ("kv_len", c_void_p), ("max_kv_len", c_int), ("scale", c_float),
                 ("dq_colsum", c_void_p), ("dk_colsum", c_void_p), ("dv_colsum", c_void_p), ("colsum_stride", c_long),
-                ("bwd_stats", c_void_p)]
+                ("bwd_stats", c_void_p), ("q_prescaled", c_int)]
 
 
 # name -> argtypes (all return int); must list every symbol include/pixart_hip.h declares
@@ -94,6 +94,7 @@ SIGNATURES = {
     "pxa_clip_coef": [_P, _P, _F, _F, _P],
     "pxa_adamw_step": [_P, _P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _I, _P, _P],
     "pxa_cast_f32_bf16": [_P, _P, _L, _P],
+    "pxa_scale_copy_f32": [_P, _L, _P, _P, _L, _I, _L, _L, _F, _P],
     "pxa_clip_coef_scaled": [_P, _P, _F, _F, _P, _F, _F, _I, _P],
     "pxa_adamw_step_scaled": [_P, _P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _P, _P, _P],
     "pxa_came_step": [C.POINTER(CameArgs), _P],

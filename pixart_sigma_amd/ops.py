@@ -149,13 +149,17 @@ def colsum(dy, out):
     return out
 
 
-def _attn_args(q, k, v, o, B, H, Nq, Nk, strides, kv_start=None, kv_len=None, max_kv_len=0, scale=None, head_dim=72):
+Q_PRESCALE = 72 ** -0.5 * 1.4426950408889634      # scale * log2 e of the denoiser's heads: what a prescaled q carries (pxa_attn_args.q_prescaled)
+
+
+def _attn_args(q, k, v, o, B, H, Nq, Nk, strides, kv_start=None, kv_len=None, max_kv_len=0, scale=None, head_dim=72, q_prescaled=False):
     a = AttnArgs()
     a.q, a.k, a.v, a.o = ptr(q), ptr(k), ptr(v), ptr(o)
     (a.q_bs, a.q_ts, a.q_hs), (a.k_bs, a.k_ts, a.k_hs), (a.v_bs, a.v_ts, a.v_hs), (a.o_bs, a.o_ts, a.o_hs) = strides
     a.B, a.H, a.Nq, a.Nk, a.head_dim = B, H, Nq, Nk, head_dim
     a.kv_start, a.kv_len, a.max_kv_len = ptr(kv_start), ptr(kv_len), max_kv_len
     a.scale = scale if scale is not None else head_dim ** -0.5
+    a.q_prescaled = int(bool(q_prescaled))
     return a
 
 
@@ -292,6 +296,13 @@ def adamw_step_scaled(p, g, m, v, p_bf16, lr, beta1, beta2, eps, weight_decay, g
 
 def adamw_step(p, g, m, v, p_bf16, lr, beta1, beta2, eps, weight_decay, step, gscale=None):
     call("pxa_adamw_step", ptr(p), ptr(g), ptr(m), ptr(v), ptr(p_bf16), p.numel(), lr, beta1, beta2, eps, weight_decay, step, ptr(gscale))
+
+
+def scale_copy(src, src_stride, nblocks, n_scaled, n_total, scale, out_bf16=None, out_f32=None):
+    """nblocks strided blocks of a flat fp32 buffer -> (nblocks, n_total) copies whose first n_scaled elements carry `scale` (one rounding)."""
+    out = out_bf16 if out_bf16 is not None else out_f32
+    assert out.is_contiguous() and out.shape[0] == nblocks and out[0].numel() == n_total
+    call("pxa_scale_copy_f32", ptr(src), src_stride, ptr(out_bf16), ptr(out_f32), n_total, nblocks, n_scaled, n_total, float(scale))
 
 
 def cast_bf16(x, out=None):

@@ -787,3 +787,55 @@ def test_fused_iddpm_loss_matches_torch_expressions(ops, monkeypatch):
         assert e < 2e-5, name
     assert (res["1"][2][:, C:].abs().sum() > 0) and (res["1"][2][:, :C].abs().sum() > 0)
     assert float(res["1"][1][0]) != float(res["0"][1][1])                  # the t = 0 (NLL) sample differs from the KL samples
+
+
+# ------------------------------------------------------------------------------------------------ round 5: softmax scale folded into q
+@pytest.mark.parametrize("logit_std", [1.0, 8.0, 24.0])
+@pytest.mark.parametrize("B,H,Nq,Nk,dkv,fwd4", [(2, 16, 1024, 1024, "4", "1"), (1, 2, 1024, 256, "5", "1"), (2, 3, 130, 77, "2", "0"), (1, 2, 200, 40, "0", "0"),
+                                              (1, 4, 2048, 1024, "4", "0")])
+def test_attention_q_prescaled(ops, monkeypatch, B, H, Nq, Nk, dkv, fwd4, logit_std):
+    """pxa_attn_args.q_prescaled: q carries scale * log2 e (what engine.py's copy of the qkv weight produces in ONE rounding).  Forward, lse and all three
+    gradients against fp32 attention on the queries the operand stands for (q~ / (scale log2 e)), through the one-wave kernels (dkv 4 / 5, whose PRE
+    instances drop the multiply in front of exp2; the folded forward) and the two-wave / ragged ones - at N(0,1) scores and at the score levels of a
+    trained model (|scale q k| of 8 and 24 standard deviations: ADVICE r04 on the folded forward, whose second rounding of q this mode removes), with
+    the SAME bounds at every level."""
+    monkeypatch.setenv("PXA_ATTN_DKV", dkv)
+    monkeypatch.setenv("PXA_ATTN_FWD4", fwd4)
+    C = H * 72
+    cpre = ops.Q_PRESCALE
+    # queries whose scores have the requested spread: q k^T / sqrt(72) ~ logit_std for unit-variance k
+    qraw = rnd(B, Nq, C, seed=1) * logit_std
+    qt = bf(qraw * cpre)                                      # the operand: one rounding of the scaled query
+    k, v, do = bf(rnd(B, Nk, C, seed=2)), bf(rnd(B, Nk, C, seed=3)), bf(rnd(B, Nq, C, seed=4))
+    o = torch.empty(B, Nq, C, dtype=_opd(), device="cuda")
+    lse = torch.empty(B, H, Nq, device="cuda")
+    sq, sk = (Nq * C, C, 72), (Nk * C, C, 72)
+    ops.attention_fwd(qt, k, v, o, lse, B, H, Nq, Nk, (sq, sk, sk, sq), q_prescaled=True)
+    dq, dk, dv = torch.empty_like(qt), torch.empty_like(k), torch.empty_like(v)
+    delta = torch.empty(B, H, Nq, device="cuda")
+    ops.attention_bwd(qt, k, v, o, do, lse, delta, dq, dk, dv, B, H, Nq, Nk, (sq, sk, sk, sq), (sq, sk, sk), q_prescaled=True)
+    qeff = (qt.float() / cpre).view(B, Nq, H, 72)             # the unscaled queries the operand stands for (exact in fp32 up to 1 ulp)
+    ro, rdq, rdk, rdv = _attn_ref_heads(qeff, k.view(B, Nk, H, 72), v.view(B, Nk, H, 72), do.view(B, Nq, H, 72))
+    sref = torch.einsum("bqhd,bkhd->bhqk", qeff, k.float().view(B, Nk, H, 72)) * 72 ** -0.5
+    dl = (lse - torch.logsumexp(sref, -1) / math.log(2)).abs().max().item()
+    errs = {n: rel_l2(t.float().view_as(r), r) for n, t, r in (("o", o, ro), ("dq", dq, rdq), ("dk", dk, rdk), ("dv", dv, rdv))}
+    print(f"\n[q prescaled B{B} H{H} Nq{Nq} Nk{Nk} dkv{dkv} fwd4={fwd4} logit std {logit_std}] " + " ".join(f"{n} {e:.2e}" for n, e in errs.items()) + f" |dlse| {dl:.1e}")
+    for n, e in errs.items():
+        record_parity(f"attention q_prescaled B{B} H{H} Nq{Nq} Nk{Nk} dkv{dkv} logit_std {logit_std}: {n}", e, BF16_TOL if n == "o" else 2 * BF16_TOL)
+    assert errs["o"] < BF16_TOL and dl < (2e-2 if F16_BUILD else 1.5e-1) * max(1.0, logit_std / 8)
+    assert max(errs["dq"], errs["dk"], errs["dv"]) < 2 * BF16_TOL
+
+
+def test_scale_copy_blocks(ops):
+    """pxa_scale_copy_f32: strided blocks of a flat fp32 buffer -> operand-type / fp32 copies whose leading part carries the factor (one rounding)."""
+    nb, n_total, n_scaled, stride = 3, 3456 * 16, 1152 * 16, 3456 * 16 + 256
+    src = rnd(nb * stride + 64, seed=9)
+    out = torch.empty(nb, n_total, dtype=_opd(), device="cuda")
+    outf = torch.empty(nb, n_total, device="cuda")
+    ops.scale_copy(src, stride, nb, n_scaled, n_total, ops.Q_PRESCALE, out_bf16=out)
+    ops.scale_copy(src, stride, nb, n_scaled, n_total, ops.Q_PRESCALE, out_f32=outf)
+    for b in range(nb):
+        ref = src[b * stride:b * stride + n_total].clone()
+        ref[:n_scaled] *= torch.tensor(ops.Q_PRESCALE, dtype=torch.float32, device="cuda")
+        assert torch.equal(outf[b], ref)
+        assert torch.equal(out[b], ref.to(_opd()))
