@@ -149,16 +149,21 @@ def kernel_rooflines(B, N):
     dw = torch.zeros(DFF, D, device=dev)
     t = timed(lambda: ops.gemm(dy, x, ops.TN, out_f32=dw, accumulate=True, split_k=0), 40, warm=5)
     res["gemm_tn_fc1_dw"] = dict(flops=2.0 * R * DFF * D, seconds=t)
-    qkv = torch.randn(R, 3 * D, device=dev).to(ops.BF16)
+    # the self-attention operands as the step presents them: q carries scale * log2 e (engine.py folds it into the qkv projection: pxa_attn_args.q_prescaled)
+    qkv32 = torch.randn(R, 3 * D, device=dev)
+    qkv32[:, :D] *= ops.Q_PRESCALE
+    qkv = qkv32.to(ops.BF16)
+    del qkv32
+    pre = dict(q_prescaled=True)
     a = torch.empty(R, D, dtype=ops.BF16, device=dev)
     lse = torch.empty(B, H, N, device=dev)
     s3 = (N * 3 * D, 3 * D, 72)
     st = (s3, s3, s3, (N * D, D, 72))
-    t = timed(lambda: ops.attention_fwd(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], a, lse, B, H, N, N, st), 30, warm=5)
+    t = timed(lambda: ops.attention_fwd(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], a, lse, B, H, N, N, st, **pre), 30, warm=5)
     res["attn_fwd_self"] = dict(flops=4.0 * B * N * N * D, seconds=t)
     da, dqkv, delta = torch.randn(R, D, device=dev).to(ops.BF16), torch.empty_like(qkv), torch.empty(B, H, N, device=dev)
     t = timed(lambda: ops.attention_bwd(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], a, da, lse, delta, dqkv[:, :D], dqkv[:, D:2 * D],
-                                        dqkv[:, 2 * D:], B, H, N, N, st, (s3, s3, s3)), 15, warm=3)
+                                        dqkv[:, 2 * D:], B, H, N, N, st, (s3, s3, s3), **pre), 15, warm=3)
     res["attn_bwd_self"] = dict(flops=10.0 * B * N * N * D, seconds=t)     # delta + dQ + dK/dV kernels, algorithmic 2.5x forward
     # The dominant kernel by itself, one event pair around EACH launch (no subtraction).  PXA_ATTN_BWD_NO_PREPASS makes
     # pxa_attn_bwd skip its delta / stats pre-pass - the workspace still holds this input's rows from the call above - and dq = NULL skips the dQ
@@ -166,7 +171,7 @@ def kernel_rooflines(B, N):
     os.environ["PXA_ATTN_BWD_NO_PREPASS"] = "1"
     try:
         one = lambda: ops.attention_bwd(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], a, da, lse, delta, None, dqkv[:, D:2 * D], dqkv[:, 2 * D:],  # noqa: E731
-                                        B, H, N, N, st, (s3, s3, s3))
+                                        B, H, N, N, st, (s3, s3, s3), **pre)
         for _ in range(5):
             one()
         evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(40)]

@@ -294,6 +294,13 @@ int pxa_vae_softmax_rows(const float* s, long ld, void* p_bf16, long ldp, int ro
 int pxa_vae_nchw_to_grid(const float* img, int C, float mul, const pxa_grid* y, hipStream_t stream);
 int pxa_vae_grid_to_nchw(const pxa_grid* x, int C, float* img, hipStream_t stream);
 
+/* ---------------------------------------------------------------------------------------------- conditioning linears (fp32)
+ * y = x W^T + b and its backward for the O(batch) conditioning path: TimestepEmbedder / SizeEmbedder MLPs and t_block (PixArt_blocks.py:267-344,
+ * PixArtMS.py:134-137,193).  fp32 in, fp32 out (their outputs modulate every token of every block); x (M, K), W (N, K), y / dy (M, N), K a multiple of 4.
+ * bwd: dx_zeroed (M, K) += dy W (caller-zeroed; NULL skips it), dw (N, K) = dy^T x and db (N) = column sums of dy (plain stores; NULL skips both). */
+int pxa_linear_f32_fwd(const float* x, const float* w, const float* bias, float* y, int M, int N, int K, hipStream_t stream);
+int pxa_linear_f32_bwd(const float* dy, const float* x, const float* w, float* dx_zeroed, float* dw, float* db, int M, int N, int K, hipStream_t stream);
+
 /* ---------------------------------------------------------------------------------------------- measurement
  * The part's matrix rate under its power limit, for the `roofline` object of bench.py (no reference counterpart: the reference reports no roofline).
  * One launch = `iters` x 32 v_mfma_f32_32x32x16 (shape 32) or 64 v_mfma_f32_16x16x32 (shape 16) per wave on register-resident operand data, one wave per

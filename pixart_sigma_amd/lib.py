@@ -95,6 +95,8 @@ SIGNATURES = {
     "pxa_adamw_step": [_P, _P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _I, _P, _P],
     "pxa_cast_f32_bf16": [_P, _P, _L, _P],
     "pxa_scale_copy_f32": [_P, _L, _P, _P, _L, _I, _L, _L, _F, _P],
+    "pxa_linear_f32_fwd": [_P, _P, _P, _P, _I, _I, _I, _P],
+    "pxa_linear_f32_bwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P],
     "pxa_clip_coef_scaled": [_P, _P, _F, _F, _P, _F, _F, _I, _P],
     "pxa_adamw_step_scaled": [_P, _P, _P, _P, _P, _L, _F, _F, _F, _F, _F, _P, _P, _P],
     "pxa_came_step": [C.POINTER(CameArgs), _P],

@@ -3,8 +3,9 @@
 HIP kernels through pixart_sigma_amd.engine.  nn.Linear / nn.Conv2d / nn.LayerNorm submodules below are *parameter
 containers only* (they give the reference's state_dict names and init); their forward is never called on the hot path.
 
-What stays in PyTorch (fp32, autograd): the per-sample conditioning vectors — sinusoidal timestep features,
-t_embedder MLP, t_block, and the (scale_shift_table + t) broadcasts — i.e. O(B*D) work, <1e-5 of the step FLOPs.
+What stays in PyTorch (fp32, autograd): the per-sample conditioning vectors — sinusoidal timestep features, SiLU and the
+(scale_shift_table + t) broadcasts — i.e. O(B*D) elementwise work.  Their LINEAR layers (t_embedder / csize / ar MLPs, t_block) run on the fp32
+HIP kernels of csrc/condlin.hip behind `_CondLinear` (round 5: no vendor-library GEMM is left in the step).
 """
 import math
 
@@ -16,6 +17,36 @@ from ..builder import MODELS
 from ..utils import to_2tuple
 
 F32 = torch.float32
+
+
+# ----------------------------------------------------------------------------- conditioning linears (fp32, HIP)
+class _CondLinearFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, b):
+        from ... import ops
+        x2 = x.reshape(-1, x.shape[-1]).contiguous()
+        y = ops.linear_f32_fwd(x2, w, b)
+        ctx.save_for_backward(x2, w)
+        ctx.has_bias, ctx.xshape = b is not None, x.shape
+        return y.reshape(*x.shape[:-1], w.shape[0])
+
+    @staticmethod
+    def backward(ctx, dy):
+        from ... import ops
+        x2, w = ctx.saved_tensors
+        dy2 = dy.reshape(-1, dy.shape[-1]).contiguous()
+        dx, dw, db = ops.linear_f32_bwd(dy2, x2, w, need_dx=ctx.needs_input_grad[0], need_dw=ctx.needs_input_grad[1], need_db=ctx.has_bias)
+        return (dx.reshape(ctx.xshape) if dx is not None else None), dw, db
+
+
+class _CondLinear(nn.Linear):
+    """nn.Linear by name, state-dict keys and init (TimestepEmbedder.mlp / t_block of the reference); on the GPU its product runs on pxa_linear_f32_fwd / _bwd
+    in fp32.  On the CPU (host-logic tests, state-dict handling) it is the plain nn.Linear."""
+
+    def forward(self, x):
+        if x.is_cuda and x.dtype == F32 and self.weight.dtype == F32:
+            return _CondLinearFn.apply(x, self.weight, self.bias)
+        return super().forward(x)
 
 
 # ----------------------------------------------------------------------------- parameter containers
@@ -40,8 +71,8 @@ class TimestepEmbedder(nn.Module):
 
     def __init__(self, hidden_size, frequency_embedding_size=256):
         super().__init__()
-        self.mlp = nn.Sequential(nn.Linear(frequency_embedding_size, hidden_size, bias=True), nn.SiLU(),
-                                 nn.Linear(hidden_size, hidden_size, bias=True))
+        self.mlp = nn.Sequential(_CondLinear(frequency_embedding_size, hidden_size, bias=True), nn.SiLU(),
+                                 _CondLinear(hidden_size, hidden_size, bias=True))
         self.frequency_embedding_size = frequency_embedding_size
 
     @staticmethod
@@ -245,7 +276,7 @@ class PixArtMS(nn.Module):
         self.register_buffer("pos_embed", torch.zeros(1, (input_size // patch_size) ** 2, hidden_size))  # state-dict compat (dropped on load)
         self.x_embedder = PatchEmbed(patch_size, in_channels, hidden_size, bias=True)
         self.t_embedder = TimestepEmbedder(hidden_size)
-        self.t_block = nn.Sequential(nn.SiLU(), nn.Linear(hidden_size, 6 * hidden_size, bias=True))
+        self.t_block = nn.Sequential(nn.SiLU(), _CondLinear(hidden_size, 6 * hidden_size, bias=True))
         self.y_embedder = CaptionEmbedder(in_channels=caption_channels, hidden_size=hidden_size, uncond_prob=class_dropout_prob,
                                           token_num=model_max_length)
         self.micro_conditioning = micro_condition

@@ -305,6 +305,29 @@ def scale_copy(src, src_stride, nblocks, n_scaled, n_total, scale, out_bf16=None
     call("pxa_scale_copy_f32", ptr(src), src_stride, ptr(out_bf16), ptr(out_f32), n_total, nblocks, n_scaled, n_total, float(scale))
 
 
+def linear_f32_fwd(x, w, b=None):
+    """y = x W^T + b, fp32 (conditioning linears: csrc/condlin.hip)."""
+    _chk(x, F32, "x"); _chk(w, F32, "w")
+    M, K = x.shape
+    N = w.shape[0]
+    assert x.is_contiguous() and w.is_contiguous() and w.shape[1] == K
+    y = torch.empty((M, N), dtype=F32, device=x.device)
+    call("pxa_linear_f32_fwd", ptr(x), ptr(w), ptr(b), ptr(y), M, N, K)
+    return y
+
+
+def linear_f32_bwd(dy, x, w, need_dx=True, need_dw=True, need_db=True):
+    _chk(dy, F32, "dy"); _chk(x, F32, "x"); _chk(w, F32, "w")
+    M, K = x.shape
+    N = w.shape[0]
+    assert dy.is_contiguous() and x.is_contiguous() and w.is_contiguous() and dy.shape == (M, N)
+    dx = torch.zeros((M, K), dtype=F32, device=x.device) if need_dx else None
+    dw = torch.empty((N, K), dtype=F32, device=x.device) if (need_dw or need_db) else None
+    db = torch.empty((N,), dtype=F32, device=x.device) if need_db else None
+    call("pxa_linear_f32_bwd", ptr(dy), ptr(x), ptr(w), ptr(dx), ptr(dw), ptr(db), M, N, K)
+    return dx, (dw if need_dw else None), db
+
+
 def cast_bf16(x, out=None):
     if out is None:
         out = torch.empty(x.shape, dtype=BF16, device=x.device)

@@ -839,3 +839,27 @@ def test_scale_copy_blocks(ops):
         ref[:n_scaled] *= torch.tensor(ops.Q_PRESCALE, dtype=torch.float32, device="cuda")
         assert torch.equal(outf[b], ref)
         assert torch.equal(out[b], ref.to(_opd()))
+
+
+@pytest.mark.parametrize("M,K,N", [(16, 256, 1152), (16, 1152, 6912), (64, 1152, 1152), (3, 1152, 1152), (33, 256, 1152)])
+def test_cond_linear_f32(ops, M, K, N):
+    """pxa_linear_f32_fwd / _bwd (csrc/condlin.hip: the t_embedder / t_block / size-embedder linears, fp32 end to end) against torch's fp32 linear and
+    its autograd, through the module the model uses (_CondLinear keeps nn.Linear's names and init)."""
+    from pixart_sigma_amd.model.nets.PixArtMS import _CondLinear
+    torch.manual_seed(0)
+    lin = _CondLinear(K, N).cuda()
+    x = rnd(M, K, seed=1).requires_grad_(True)
+    g = rnd(M, N, seed=2)
+    y = lin(x)
+    y.backward(g)
+    got = (y.detach(), x.grad.clone(), lin.weight.grad.clone(), lin.bias.grad.clone())
+    x2 = x.detach().double().requires_grad_(True)
+    w2, b2 = lin.weight.detach().double().requires_grad_(True), lin.bias.detach().double().requires_grad_(True)
+    y2 = F.linear(x2, w2, b2)
+    y2.backward(g.double())
+    for name, a, b in zip(("y", "dx", "dw", "db"), got, (y2.detach(), x2.grad, w2.grad, b2.grad)):
+        e = rel_l2(a.double(), b)
+        assert e < 2e-6, (name, e)
+    # a second backward accumulates into .grad like any nn.Linear
+    lin(x).backward(g)
+    assert rel_l2(lin.weight.grad.double(), 2 * w2.grad) < 2e-6
