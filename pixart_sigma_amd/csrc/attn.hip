@@ -3069,7 +3069,15 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv5_kernel(AttnParams p) {
 #define PXA_ATTN_DQ4_DEFAULT 1
 #endif
 constexpr int DQ4_STAGES = 5;
+// PRE (round 5): q arrives as (scale log2 e) x queries (pxa_attn_args.q_prescaled), so S^T = K Q~^T is already the exponent's argument up to - lse - and
+// that rides in the matrix product too, the way delta rides in dP: the lane's Q~ row carries lse in slots 72 .. 74 (split3) against -1.0 in the K tiles'
+// pad columns.  E(j) is then the exp2 alone: one vector instruction per score less (the fma S c - lse) in a kernel whose limit is vector issue.
+#ifndef DQ4_FOLD_LSE
+#define DQ4_FOLD_LSE 1      // 0 (A/B builds): the prescaled instance keeps the fma in front of exp2
+#endif
+template <bool PRE_>
 __global__ __launch_bounds__(256, 1) void attn_bwd_dq4_kernel(AttnParams p) {
+  constexpr bool PRE = PRE_ && DQ4_FOLD_LSE;
   constexpr int STG = 2 * TILE_B;
   __shared__ __attribute__((aligned(16))) char smem[DQ4_STAGES * STG];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), hi = lane >> 5;
@@ -3117,7 +3125,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq4_kernel(AttnParams p) {
   struct Bases { unsigned r0, r1, t00, t01, t10, t11; };
   auto bases = [&](unsigned st) -> Bases { return Bases{st + (unsigned)fa.rb[0], st + (unsigned)fa.rb[1], st + (unsigned)ta.tb[0][0], st + (unsigned)ta.tb[0][1],
                                                         st + (unsigned)ta.tb[1][0], st + (unsigned)ta.tb[1][1]}; };
-  for (int st = 0; st < 2 * DQ4_STAGES; st++) init_pads(smem + st * TILE_B, (st & 1) ? 2 : 0, tid);   // odd tiles = V: -1.0 in slots 72 .. 74
+  for (int st = 0; st < 2 * DQ4_STAGES; st++) init_pads(smem + st * TILE_B, ((st & 1) || PRE) ? 2 : 0, tid);   // odd tiles = V: -1.0 in slots 72 .. 74 (PRE: the K tiles too)
 
   Acc16 dq[2];
 #pragma unroll
@@ -3175,6 +3183,12 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq4_kernel(AttnParams p) {
       const uint2 d3 = split3(delta);
       w[0] = d3.x; w[1] = d3.y;
       dof[qb][KSTEPS - 1] = __builtin_bit_cast(bf16x8, w);
+      if constexpr (PRE) {                                         // slots 72 .. 74 of this lane's Q~ row: lse (x -1.0 of the K tiles' pads)
+        u32x4 wq = __builtin_bit_cast(u32x4, qf[qb][KSTEPS - 1]);
+        const uint2 l3 = split3(lse[qb]);
+        wq[0] = l3.x; wq[1] = l3.y;
+        qf[qb][KSTEPS - 1] = __builtin_bit_cast(bf16x8, wq);
+      }
     }
 #pragma unroll
     for (int ks = 0; ks < KSTEPS; ks++) { to_agpr(qf[qb][ks]); to_agpr(dof[qb][ks]); }
@@ -3210,7 +3224,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq4_kernel(AttnParams p) {
         constexpr int e0 = (32 * ge) / 20, e1 = (32 * (ge + 1)) / 20;
         static_for<e1 - e0>([&](auto ec) {
           constexpr int e = e0 + decltype(ec)::value, qb = e >> 4, g = e & 15;
-          S[CUR][qb][g] = fmaf(S[CUR][qb][g], c, -lse[qb]);
+          if (!PRE) S[CUR][qb][g] = fmaf(S[CUR][qb][g], c, -lse[qb]);   // (PRE: S' = S~ - lse came out of the matrix product)
           asm volatile("" : "+v"(S[CUR][qb][g]));
         });
       }
@@ -3478,7 +3492,8 @@ extern "C" int pxa_attn_bwd(const pxa_attn_args* a, hipStream_t stream) {
     if (!dqe && dq_mode == 1 && PXA_ATTN_DQ4_DEFAULT && dq4_ok) dq_mode = 4;
     if (dq_mode == 4) {
       p.nx = (p.Nq + 255) / 256;
-      hipLaunchKernelGGL(attn_bwd_dq4_kernel, dim3(p.nx * p.H * p.B), dim3(256), 0, stream, p);
+      if (a->q_prescaled) hipLaunchKernelGGL(attn_bwd_dq4_kernel<true>, dim3(p.nx * p.H * p.B), dim3(256), 0, stream, p);
+      else hipLaunchKernelGGL(attn_bwd_dq4_kernel<false>, dim3(p.nx * p.H * p.B), dim3(256), 0, stream, p);
     } else if (dq_mode) hipLaunchKernelGGL(attn_bwd_dq2_kernel, dim3(p.nx * p.H * p.B), dim3(256), 0, stream, p);
     else hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3(p.nx * p.H * p.B), dim3(256), 0, stream, p);
     PXA_LAUNCH_CHECK();
