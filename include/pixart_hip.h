@@ -103,10 +103,12 @@ int pxa_gemm_set_dynamic_items(int on);
 int pxa_ln_mod_fwd(const float* x, const void* u_bf16, const float* gate, int gate_stride, const float* shift, const float* scale, int mod_stride,
                    float* x_out, void* xn_bf16, void* xb_bf16, float* mean, float* rstd,
                    int R, int D, int rows_per_batch, float eps, hipStream_t stream);
-/* dx_out = dx_in + dLN(dy*(1+scale)) (optionally also as bf16);  dshift[b] += sum dy;  dscale[b] += sum dy*xhat  (atomic; caller zeroes). */
+/* dx_out = dx_in + dLN(dy*(1+scale)) (optionally also as bf16);  dshift[b] += sum dy;  dscale[b] += sum dy*xhat  (atomic; caller zeroes).
+ * dbias (optional, round 5): slotted partials (PXA_COLSUM_SLOTS x dbias_stride fp32, caller-zeroed) += column sums of dx_out - the bias gradient of the Linear
+ * that dx_bf16 is the output gradient of (x2 = x1 + cross_attn.proj(...), PixArtMS.py:76): replaces a column-sum pass over dx_bf16. */
 int pxa_ln_mod_bwd(const void* dy_bf16, const float* x, const float* mean, const float* rstd, const float* scale, int mod_stride,
                    const float* dx_in, float* dx_out, void* dx_bf16, float* dshift, float* dscale, int dmod_stride,
-                   int R, int D, int rows_per_batch, hipStream_t stream);
+                   float* dbias, long dbias_stride, int R, int D, int rows_per_batch, hipStream_t stream);
 
 /* q / k LayerNorm of AttentionKVCompress(qk_norm=True) (reference PixArt_blocks.py:90-92,133-134): nn.LayerNorm(D), affine, over bf16 rows
  * with an element stride (the q / k column blocks of the qkv buffer, in place when y == x).  fwd also copies the un-normalised rows to

@@ -123,7 +123,7 @@ template <int NV>
 __global__ __launch_bounds__(256) void ln_mod_bwd_kernel(
     const bf16_t* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ rstd,
     const float* __restrict__ scale, int mod_stride, const float* dx_in, float* dx_out, bf16_t* __restrict__ dx_bf16,
-    float* __restrict__ dshift, float* __restrict__ dscale, int dmod_stride, int R, int D, int rows_per_batch) {
+    float* __restrict__ dshift, float* __restrict__ dscale, int dmod_stride, float* __restrict__ dbias, long dbias_stride, int R, int D, int rows_per_batch) {
   // Per-sample column sums (dshift / dscale): every 16-row chunk used to fire 72 global atomics per lane at the SAME 2 x D words
   // of its sample - ~1000 serialised read-modify-writes per cache line and call.  When the block's 128 rows belong to one sample
   // (always, unless a sample's token count is not a multiple of 128) the 8 half-waves first combine in LDS, then the block adds
@@ -133,9 +133,11 @@ __global__ __launch_bounds__(256) void ln_mod_bwd_kernel(
   const int blk_first = blockIdx.x * 8 * BWD_ROWS, blk_last = min(R, blk_first + 8 * BWD_ROWS) - 1;
   const int r_beg = bwd_row(blk_first, threadIdx.x >> 5, 0);
   const bool one_sample = (blk_first / rows_per_batch) == (blk_last / rows_per_batch);   // block-uniform
-  float4 ash[NV], asc[NV];
+  // (round 5) dbias: column sums of dx_out - the bias gradient of the Linear whose output gradient dx_bf16 is (cross_attn.proj) - into slotted partials like
+  // gate_bwd's: the rows are in registers anyway, the separate colsum pass over dx_bf16 (151 MB read per block) goes
+  float4 ash[NV], asc[NV], adb[NV];
 #pragma unroll
-  for (int j = 0; j < NV; j++) { ash[j] = make_float4(0, 0, 0, 0); asc[j] = make_float4(0, 0, 0, 0); }
+  for (int j = 0; j < NV; j++) { ash[j] = make_float4(0, 0, 0, 0); asc[j] = make_float4(0, 0, 0, 0); adb[j] = make_float4(0, 0, 0, 0); }
   int cur_b = r_beg / rows_per_batch;
   auto flush = [&](int b) {
 #pragma unroll
@@ -146,6 +148,11 @@ __global__ __launch_bounds__(256) void ln_mod_bwd_kernel(
       atomicAdd(ps + 0, ash[j].x); atomicAdd(ps + 1, ash[j].y); atomicAdd(ps + 2, ash[j].z); atomicAdd(ps + 3, ash[j].w);
       atomicAdd(pc + 0, asc[j].x); atomicAdd(pc + 1, asc[j].y); atomicAdd(pc + 2, asc[j].z); atomicAdd(pc + 3, asc[j].w);
       ash[j] = make_float4(0, 0, 0, 0); asc[j] = make_float4(0, 0, 0, 0);
+      if (dbias) {
+        float* pb = dbias + (size_t)(b % PXA_COLSUM_SLOTS) * dbias_stride + c;
+        atomicAdd(pb + 0, adb[j].x); atomicAdd(pb + 1, adb[j].y); atomicAdd(pb + 2, adb[j].z); atomicAdd(pb + 3, adb[j].w);
+        adb[j] = make_float4(0, 0, 0, 0);
+      }
     }
   };
   for (int i = 0; i < BWD_ROWS; i++) {
@@ -203,6 +210,7 @@ __global__ __launch_bounds__(256) void ln_mod_bwd_kernel(
       }
       st_f4(dx_out + base + c, o);
       if (dx_bf16) st_u2(dx_bf16 + base + c, pack_bf16x4(o.x, o.y, o.z, o.w));
+      if (dbias) { adb[j].x += o.x; adb[j].y += o.y; adb[j].z += o.z; adb[j].w += o.w; }
     }
   }
   if (one_sample) {
@@ -211,6 +219,15 @@ __global__ __launch_bounds__(256) void ln_mod_bwd_kernel(
     for (int i = threadIdx.x; i < D; i += 256) {
       atomicAdd(dshift + (size_t)b * dmod_stride + i, red[i] + red[2 * D + i]);
       atomicAdd(dscale + (size_t)b * dmod_stride + i, red[D + i] + red[3 * D + i]);
+    }
+    if (dbias) {                                       // block-uniform: a second trip through the same LDS slots
+      __syncthreads();
+      float4 zz[NV];
+#pragma unroll
+      for (int j = 0; j < NV; j++) zz[j] = make_float4(0, 0, 0, 0);
+      block_colsum_combine<NV>(red, adb, zz, D);
+      for (int i = threadIdx.x; i < D; i += 256)
+        atomicAdd(dbias + (size_t)(b % PXA_COLSUM_SLOTS) * dbias_stride + i, (red[i] + red[2 * D + i]) + (red[D + i] + red[3 * D + i]));
     }
   } else if (r_beg < R) {
     flush(cur_b);
@@ -490,12 +507,12 @@ extern "C" int pxa_ln_affine_bwd(const void* dy_bf16, long dy_stride, const void
 
 extern "C" int pxa_ln_mod_bwd(const void* dy_bf16, const float* x, const float* mean, const float* rstd, const float* scale,
                               int mod_stride, const float* dx_in, float* dx_out, void* dx_bf16, float* dshift, float* dscale, int dmod_stride,
-                              int R, int D, int rows_per_batch, hipStream_t stream) {
+                              float* dbias, long dbias_stride, int R, int D, int rows_per_batch, hipStream_t stream) {
   PXA_CHECK(dy_bf16 && x && mean && rstd && scale && dx_out && dshift && dscale, "pxa_ln_mod_bwd: null pointer");
   PXA_CHECK(R > 0 && D % 128 == 0 && rows_per_batch > 0, "pxa_ln_mod_bwd: bad shape");
   const int chunks = (R + BWD_ROWS - 1) / BWD_ROWS;
   DISPATCH_NV(D, hipLaunchKernelGGL(ln_mod_bwd_kernel<NV>, dim3((chunks + 7) / 8), dim3(256), 4 * D * sizeof(float), stream, (const bf16_t*)dy_bf16, x, mean, rstd,
-                                     scale, mod_stride, dx_in, dx_out, (bf16_t*)dx_bf16, dshift, dscale, dmod_stride, R, D, rows_per_batch));
+                                     scale, mod_stride, dx_in, dx_out, (bf16_t*)dx_bf16, dshift, dscale, dmod_stride, dbias, dbias_stride, R, D, rows_per_batch));
   PXA_LAUNCH_CHECK();
   return 0;
 }

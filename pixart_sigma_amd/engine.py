@@ -356,8 +356,11 @@ class Engine:
         dxn = self._lin_bwd(dh, sv["xn2"], p + "mlp.fc1", bias_done=True)
         del dh
         # ---- cross attention: x2 = x1 + u2 (no gate, no norm): du2 = bf16(G2) comes out of the LN backward pass itself
-        ops.ln_mod_bwd(dxn, sv["x2"], sv["mean2"], sv["rstd2"], mod[:, 4], st, G, G, dmod[:, 3], dmod[:, 4], st, N, dx_bf16=du)
-        dc = self._lin_bwd(du, sv["cr"], p + "cross_attn.proj")
+        # (round 5: cross_attn.proj's bias gradient = column sums of G2 ride in this pass; PXA_FUSED_CPROJ_BIAS=0: the separate colsum pass, A/B)
+        fused_cb = os.environ.get("PXA_FUSED_CPROJ_BIAS", "1") != "0"
+        ops.ln_mod_bwd(dxn, sv["x2"], sv["mean2"], sv["rstd2"], mod[:, 4], st, G, G, dmod[:, 3], dmod[:, 4], st, N, dx_bf16=du,
+                       dbias=pb("cross_attn.proj.bias") if fused_cb else None)
+        dc = self._lin_bwd(du, sv["cr"], p + "cross_attn.proj", bias_done=fused_cb)
         dqc = torch.empty((R, D), dtype=BF16, device=dev)
         dkvc = torch.empty_like(sv["kvc"])
         delta = torch.empty((B, H, N), dtype=F32, device=dev)

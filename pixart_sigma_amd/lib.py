@@ -74,7 +74,7 @@ _G = C.POINTER(GridArg)
 SIGNATURES = {
     "pxa_gemm": [C.POINTER(GemmArgs), _P],
     "pxa_ln_mod_fwd": [_P, _P, _P, _I, _P, _P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _F, _P],
-    "pxa_ln_mod_bwd": [_P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P],
+    "pxa_ln_mod_bwd": [_P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _I, _P, _L, _I, _I, _I, _P],
     "pxa_ln_affine_fwd": [_P, _L, _P, _P, _P, _L, _P, _P, _P, _I, _I, _F, _P],
     "pxa_ln_affine_bwd": [_P, _L, _P, _P, _P, _P, _P, _L, _P, _P, _I, _I, _P],
     "pxa_gate_bwd": [_P, _P, _P, _P, _I, _P, _P, _P, _I, _P, _L, _I, _I, _I, _P],

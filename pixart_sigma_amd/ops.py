@@ -102,10 +102,11 @@ def ln_mod_fwd(x, shift=None, scale=None, mod_stride=0, u=None, gate=None, gate_
     return {"x": x_out if x_out is not None else x, "xn": xn, "xb": xb, "mean": mean, "rstd": rstd}
 
 
-def ln_mod_bwd(dy, x, mean, rstd, scale, mod_stride, dx_in, dx_out, dshift, dscale, dmod_stride, rows_per_batch, dx_bf16=None):
+def ln_mod_bwd(dy, x, mean, rstd, scale, mod_stride, dx_in, dx_out, dshift, dscale, dmod_stride, rows_per_batch, dx_bf16=None, dbias=None):
+    """dbias: optional (COLSUM_SLOTS, >= D) fp32 partials view receiving the column sums of dx_out (the bias gradient of the Linear behind dx_bf16)."""
     R, D = x.shape
     call("pxa_ln_mod_bwd", ptr(dy), ptr(x), ptr(mean), ptr(rstd), ptr(scale), mod_stride, ptr(dx_in), ptr(dx_out), ptr(dx_bf16),
-         ptr(dshift), ptr(dscale), dmod_stride, R, D, rows_per_batch)
+         ptr(dshift), ptr(dscale), dmod_stride, ptr(dbias), dbias.stride(0) if dbias is not None else 0, R, D, rows_per_batch)
     return dx_out
 
 

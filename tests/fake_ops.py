@@ -13,6 +13,7 @@ NT, NN, TN = real.NT, real.NN, real.TN
 ACT_NONE, ACT_GELU, ACT_GELU_GRAD, ACT_GELU_SAVE_GRAD, ACT_MUL_AUX, ACT_ADD_AUX = (real.ACT_NONE, real.ACT_GELU, real.ACT_GELU_GRAD,
                                                                                    real.ACT_GELU_SAVE_GRAD, real.ACT_MUL_AUX, real.ACT_ADD_AUX)
 COLSUM_SLOTS = real.COLSUM_SLOTS
+Q_PRESCALE = real.Q_PRESCALE
 
 RANK, STEP, JITTER = 0, 0, 0.0       # set by the test worker
 CALLS = []                           # (op, detail) trace
@@ -60,7 +61,7 @@ def ln_mod_fwd(x, shift=None, scale=None, mod_stride=0, u=None, gate=None, gate_
             "xb": z(BF16, R, D) if want_xb else None, "mean": z(F32, R) if want_stats else None, "rstd": z(F32, R) if want_stats else None}
 
 
-def ln_mod_bwd(dy, x, mean, rstd, scale, mod_stride, dx_in, dx_out, dshift, dscale, dmod_stride, rows_per_batch, dx_bf16=None):
+def ln_mod_bwd(dy, x, mean, rstd, scale, mod_stride, dx_in, dx_out, dshift, dscale, dmod_stride, rows_per_batch, dx_bf16=None, dbias=None):
     return dx_out
 
 
@@ -130,6 +131,13 @@ def kv_compress_bwd(dyc, inp, in_bs, in_ts, conv_w, conv_b, ln_w, din, din_bs, d
 
 def kv_pick(*a, **kw):
     return None
+
+
+def scale_copy(src, src_stride, nblocks, n_scaled, n_total, scale, out_bf16=None, out_f32=None):
+    CALLS.append(("scale_copy", nblocks, n_total))
+    for o in (out_bf16, out_f32):
+        if o is not None:
+            o.zero_()
 
 
 def cast_bf16(x, out=None):

@@ -182,6 +182,13 @@ def test_ln_mod_bwd(ops, B, N):
     assert rel_l2(dx, xr.grad + dxin) < 1e-5
     assert rel_l2(dmod[:, 0], sh.grad) < 1e-5 and rel_l2(dmod[:, 1], sc.grad) < 1e-5
     assert dmod[:, 2:].abs().max() == 0
+    # round 5: the bias gradient of the Linear behind dx (column sums of dx) into slotted partials, with the 16-bit copy of dx
+    part = torch.zeros(ops.COLSUM_SLOTS, D + 128, device="cuda")
+    dmod2, dx2 = torch.zeros(B, 6, D, device="cuda"), torch.empty_like(x)
+    dxb = torch.empty(R, D, dtype=_opd(), device="cuda")
+    ops.ln_mod_bwd(dy, x, st["mean"], st["rstd"], scale, 6 * D, dxin, dx2, dmod2[:, 0], dmod2[:, 1], 6 * D, N, dx_bf16=dxb, dbias=part[:, 64:64 + D])
+    assert torch.equal(dx2, dx) and rel_l2(dmod2, dmod) < 1e-6 and rel_l2(dxb.float(), dx) < BF16_TOL
+    assert rel_l2(part.sum(0)[64:64 + D], dx.sum(0)) < 1e-5 and part[:, :64].abs().max() == 0 and part[:, 64 + D:].abs().max() == 0
 
 
 def test_ln_affine_fwd_bwd(ops):
