@@ -1,9 +1,9 @@
 #!/bin/bash
-# After `gpurun -- 'bash tools/sessions/r4_18.sh'` (the validation bundle, tag r4final): copy what the judge reads from gpurun_out/ (scratch) into profiles/ (tracked).
+# After `gpurun -- 'bash tools/sessions/r5_bundle.sh [tag]'` (the validation bundle, default tag r5final): copy what the judge reads from gpurun_out/ (scratch) into profiles/ (tracked).
 #   usage (this container, repo root):  bash tools/collect_bundle.sh [tag]
-tag=${1:-r4final}
+tag=${1:-r5final}
 cd "$(dirname "$0")/.." || exit 1
-for f in pytest_gpu.txt smoke.txt bench_default.json step_kernel_stats.csv pmc_attention.txt pmc_attention.json pmc_gemm.txt bench_infer.txt profile_round.log; do
+for f in pytest_gpu.txt smoke.txt bench_default.json step_kernel_stats.csv pmc_attention.txt pmc_attention.json pmc_gemm.txt bench_infer.txt profile_round.log pmc_step_gemm_table.txt; do
   [ -f gpurun_out/${tag}_$f ] && cp gpurun_out/${tag}_$f profiles/${tag}_$f
 done
 # (the per-session parity summaries are overwritten by EVERY GPU pytest session: take them only when they are the full tier's)

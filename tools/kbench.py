@@ -27,25 +27,25 @@ LIBREF = bool(int(os.environ.get("KBENCH_LIBREF", "0")))
 
 
 def rb(*s):
-    return torch.randn(*s, device=dev).to(torch.bfloat16)
+    return torch.randn(*s, device=dev).to(ops.BF16)
 
 
 def gemm():
     x = rb(R, D)
     for name, n_out, k in (("qkv", 3 * D, D), ("proj", D, D), ("fc1", DFF, D), ("fc2", D, DFF)):
         a = rb(R, k)
-        w = (torch.randn(n_out, k, device=dev) * k ** -0.5).to(torch.bfloat16)
+        w = (torch.randn(n_out, k, device=dev) * k ** -0.5).to(ops.BF16)
         bias = torch.zeros(n_out, device=dev)
-        out = torch.empty(R, n_out, dtype=torch.bfloat16, device=dev)
+        out = torch.empty(R, n_out, dtype=ops.BF16, device=dev)
         t = timed(lambda: ops.gemm(a, w, ops.NT, bias=bias, out=out))
         fl = 2.0 * R * n_out * k
         print(f"gemm NT {name:5s} M={R} N={n_out} K={k}: {t*1e3:7.3f} ms {fl/t/1e12:7.1f} TF/s")
         dy = rb(R, n_out)
         if LIBREF:          # the vendor library (hipBLASLt through torch) on the same shapes: a yardstick for the report, never the product path
-            tl = [timed(lambda: torch.matmul(a, w.t(), out=out)), timed(lambda: torch.matmul(dy, w, out=torch.empty(R, k, dtype=torch.bfloat16, device=dev))),
+            tl = [timed(lambda: torch.matmul(a, w.t(), out=out)), timed(lambda: torch.matmul(dy, w, out=torch.empty(R, k, dtype=ops.BF16, device=dev))),
                   timed(lambda: torch.matmul(dy.t(), a))]
             print("   hipBLASLt NT/NN/TN: " + " ".join(f"{fl/x/1e12:7.1f}" for x in tl) + " TF/s")
-        dx = torch.empty(R, k, dtype=torch.bfloat16, device=dev)
+        dx = torch.empty(R, k, dtype=ops.BF16, device=dev)
         t = timed(lambda: ops.gemm(dy, w, ops.NN, out=dx))
         print(f"gemm NN {name:5s} (dX)                      : {t*1e3:7.3f} ms {fl/t/1e12:7.1f} TF/s")
         dw = torch.zeros(n_out, k, device=dev)
@@ -55,17 +55,21 @@ def gemm():
 
 
 def attn():
-    qkv = rb(R, 3 * D)
-    a = torch.empty(R, D, dtype=torch.bfloat16, device=dev)
+    qkv32 = torch.randn(R, 3 * D, device=dev)
+    qkv32[:, :D] *= ops.Q_PRESCALE                   # the step's operands: q carries scale * log2 e (pxa_attn_args.q_prescaled)
+    qkv = qkv32.to(ops.BF16)
+    del qkv32
+    pre = dict(q_prescaled=True)
+    a = torch.empty(R, D, dtype=ops.BF16, device=dev)
     lse = torch.empty(B, H, N, device=dev)
     s3 = (N * 3 * D, 3 * D, 72)
     st = (s3, s3, s3, (N * D, D, 72))
-    t = timed(lambda: ops.attention_fwd(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], a, lse, B, H, N, N, st))
+    t = timed(lambda: ops.attention_fwd(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], a, lse, B, H, N, N, st, **pre))
     fl = 4.0 * B * N * N * D
     print(f"attn fwd self : {t*1e3:7.3f} ms {fl/t/1e12:7.1f} TF/s")
     da, dqkv, delta = rb(R, D), torch.empty_like(qkv), torch.empty(B, H, N, device=dev)
     t = timed(lambda: ops.attention_bwd(qkv[:, :D], qkv[:, D:2 * D], qkv[:, 2 * D:], a, da, lse, delta, dqkv[:, :D], dqkv[:, D:2 * D],
-                                        dqkv[:, 2 * D:], B, H, N, N, st, (s3, s3, s3)))
+                                        dqkv[:, 2 * D:], B, H, N, N, st, (s3, s3, s3), **pre))
     print(f"attn bwd self : {t*1e3:7.3f} ms {2.5*fl/t/1e12:7.1f} TF/s (algorithmic 2.5x fwd)")
     if LIBREF:
         import torch.nn.functional as F
