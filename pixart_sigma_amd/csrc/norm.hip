@@ -119,7 +119,7 @@ __device__ __forceinline__ void block_colsum_combine(float* red, float4 (&a0)[NV
 #define LNB_VARIANT 1          // 1 = the row's dx_in loads are issued with its other loads (dx_out may alias dx_in, so a load placed behind the
 #endif                         //     previous chunk's store cannot be hoisted: 0 = that order, 312 us; 1: 250 us; 3 = all dx_in loads after the reduction: 407 us)
 
-template <int NV>
+template <int NV, bool DB>
 __global__ __launch_bounds__(256) void ln_mod_bwd_kernel(
     const bf16_t* __restrict__ dy, const float* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ rstd,
     const float* __restrict__ scale, int mod_stride, const float* dx_in, float* dx_out, bf16_t* __restrict__ dx_bf16,
@@ -128,16 +128,24 @@ __global__ __launch_bounds__(256) void ln_mod_bwd_kernel(
   // of its sample - ~1000 serialised read-modify-writes per cache line and call.  When the block's 128 rows belong to one sample
   // (always, unless a sample's token count is not a multiple of 128) the 8 half-waves first combine in LDS, then the block adds
   // once: 8x fewer, fully coalesced atomics (block_colsum_combine: no LDS atomics either).
-  extern __shared__ float red[];                       // [2 slots][2][D]
+  extern __shared__ float red[];                       // [2 slots][2][D] (+ DB: [8 half-waves][D] column sums of dx_out)
   const int hl = threadIdx.x & 31;
   const int blk_first = blockIdx.x * 8 * BWD_ROWS, blk_last = min(R, blk_first + 8 * BWD_ROWS) - 1;
   const int r_beg = bwd_row(blk_first, threadIdx.x >> 5, 0);
   const bool one_sample = (blk_first / rows_per_batch) == (blk_last / rows_per_batch);   // block-uniform
-  // (round 5) dbias: column sums of dx_out - the bias gradient of the Linear whose output gradient dx_bf16 is (cross_attn.proj) - into slotted partials like
-  // gate_bwd's: the rows are in registers anyway, the separate colsum pass over dx_bf16 (151 MB read per block) goes
-  float4 ash[NV], asc[NV], adb[NV];
+  // (round 5) DB: column sums of dx_out - the bias gradient of the Linear whose output gradient dx_bf16 is (cross_attn.proj) - into slotted partials like
+  // gate_bwd's: the rows are in registers anyway, the separate colsum pass over dx_bf16 (151 MB read per block) goes.  The sums live in LDS, one private
+  // float4 slot per lane and column group (plain read-add-write, 9 KB per row of a CU that streams 256 rows: nothing beside the HBM time): a third register
+  // accumulator set took the kernel from 284 to 334 registers and from 204 to 345 us for EVERY call (session 7 step profile); instances without DB
+  // compile to the round-4 kernel.
+  float4* adb = reinterpret_cast<float4*>(red + 4 * D + (threadIdx.x >> 5) * D);
+  float4 ash[NV], asc[NV];
 #pragma unroll
-  for (int j = 0; j < NV; j++) { ash[j] = make_float4(0, 0, 0, 0); asc[j] = make_float4(0, 0, 0, 0); adb[j] = make_float4(0, 0, 0, 0); }
+  for (int j = 0; j < NV; j++) { ash[j] = make_float4(0, 0, 0, 0); asc[j] = make_float4(0, 0, 0, 0); }
+  if constexpr (DB) {
+#pragma unroll
+    for (int j = 0; j < NV; j++) adb[hl + 32 * j] = make_float4(0, 0, 0, 0);
+  }
   int cur_b = r_beg / rows_per_batch;
   auto flush = [&](int b) {
 #pragma unroll
@@ -148,10 +156,11 @@ __global__ __launch_bounds__(256) void ln_mod_bwd_kernel(
       atomicAdd(ps + 0, ash[j].x); atomicAdd(ps + 1, ash[j].y); atomicAdd(ps + 2, ash[j].z); atomicAdd(ps + 3, ash[j].w);
       atomicAdd(pc + 0, asc[j].x); atomicAdd(pc + 1, asc[j].y); atomicAdd(pc + 2, asc[j].z); atomicAdd(pc + 3, asc[j].w);
       ash[j] = make_float4(0, 0, 0, 0); asc[j] = make_float4(0, 0, 0, 0);
-      if (dbias) {
+      if constexpr (DB) {
         float* pb = dbias + (size_t)(b % PXA_COLSUM_SLOTS) * dbias_stride + c;
-        atomicAdd(pb + 0, adb[j].x); atomicAdd(pb + 1, adb[j].y); atomicAdd(pb + 2, adb[j].z); atomicAdd(pb + 3, adb[j].w);
-        adb[j] = make_float4(0, 0, 0, 0);
+        const float4 a = adb[hl + 32 * j];
+        atomicAdd(pb + 0, a.x); atomicAdd(pb + 1, a.y); atomicAdd(pb + 2, a.z); atomicAdd(pb + 3, a.w);
+        adb[hl + 32 * j] = make_float4(0, 0, 0, 0);
       }
     }
   };
@@ -210,7 +219,7 @@ __global__ __launch_bounds__(256) void ln_mod_bwd_kernel(
       }
       st_f4(dx_out + base + c, o);
       if (dx_bf16) st_u2(dx_bf16 + base + c, pack_bf16x4(o.x, o.y, o.z, o.w));
-      if (dbias) { adb[j].x += o.x; adb[j].y += o.y; adb[j].z += o.z; adb[j].w += o.w; }
+      if constexpr (DB) { float4 a = adb[hl + 32 * j]; a.x += o.x; a.y += o.y; a.z += o.z; a.w += o.w; adb[hl + 32 * j] = a; }
     }
   }
   if (one_sample) {
@@ -220,14 +229,11 @@ __global__ __launch_bounds__(256) void ln_mod_bwd_kernel(
       atomicAdd(dshift + (size_t)b * dmod_stride + i, red[i] + red[2 * D + i]);
       atomicAdd(dscale + (size_t)b * dmod_stride + i, red[D + i] + red[3 * D + i]);
     }
-    if (dbias) {                                       // block-uniform: a second trip through the same LDS slots
-      __syncthreads();
-      float4 zz[NV];
-#pragma unroll
-      for (int j = 0; j < NV; j++) zz[j] = make_float4(0, 0, 0, 0);
-      block_colsum_combine<NV>(red, adb, zz, D);
+    if constexpr (DB) {                                // the 8 half-waves' rows of sums (every lane's last write is in front of the combine's barriers)
+      const float* hw = red + 4 * D;
       for (int i = threadIdx.x; i < D; i += 256)
-        atomicAdd(dbias + (size_t)(b % PXA_COLSUM_SLOTS) * dbias_stride + i, (red[i] + red[2 * D + i]) + (red[D + i] + red[3 * D + i]));
+        atomicAdd(dbias + (size_t)(b % PXA_COLSUM_SLOTS) * dbias_stride + i,
+                  ((hw[i] + hw[D + i]) + (hw[2 * D + i] + hw[3 * D + i])) + ((hw[4 * D + i] + hw[5 * D + i]) + (hw[6 * D + i] + hw[7 * D + i])));
     }
   } else if (r_beg < R) {
     flush(cur_b);
@@ -511,8 +517,13 @@ extern "C" int pxa_ln_mod_bwd(const void* dy_bf16, const float* x, const float* 
   PXA_CHECK(dy_bf16 && x && mean && rstd && scale && dx_out && dshift && dscale, "pxa_ln_mod_bwd: null pointer");
   PXA_CHECK(R > 0 && D % 128 == 0 && rows_per_batch > 0, "pxa_ln_mod_bwd: bad shape");
   const int chunks = (R + BWD_ROWS - 1) / BWD_ROWS;
-  DISPATCH_NV(D, hipLaunchKernelGGL(ln_mod_bwd_kernel<NV>, dim3((chunks + 7) / 8), dim3(256), 4 * D * sizeof(float), stream, (const bf16_t*)dy_bf16, x, mean, rstd,
-                                     scale, mod_stride, dx_in, dx_out, (bf16_t*)dx_bf16, dshift, dscale, dmod_stride, dbias, dbias_stride, R, D, rows_per_batch));
+  if (dbias) {
+    DISPATCH_NV(D, hipLaunchKernelGGL((ln_mod_bwd_kernel<NV, true>), dim3((chunks + 7) / 8), dim3(256), 12 * D * sizeof(float), stream, (const bf16_t*)dy_bf16, x, mean, rstd,
+                                       scale, mod_stride, dx_in, dx_out, (bf16_t*)dx_bf16, dshift, dscale, dmod_stride, dbias, dbias_stride, R, D, rows_per_batch));
+  } else {
+    DISPATCH_NV(D, hipLaunchKernelGGL((ln_mod_bwd_kernel<NV, false>), dim3((chunks + 7) / 8), dim3(256), 4 * D * sizeof(float), stream, (const bf16_t*)dy_bf16, x, mean, rstd,
+                                       scale, mod_stride, dx_in, dx_out, (bf16_t*)dx_bf16, dshift, dscale, dmod_stride, dbias, dbias_stride, R, D, rows_per_batch));
+  }
   PXA_LAUNCH_CHECK();
   return 0;
 }
