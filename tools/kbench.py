@@ -56,10 +56,12 @@ def gemm():
 
 def attn():
     qkv32 = torch.randn(R, 3 * D, device=dev)
-    qkv32[:, :D] *= ops.Q_PRESCALE                   # the step's operands: q carries scale * log2 e (pxa_attn_args.q_prescaled)
+    noscale = os.environ.get("PXA_KBENCH_NO_PRESCALE") == "1"     # A/B: the kernel instances that multiply by scale * log2 e themselves (round 4's operands)
+    if not noscale:
+        qkv32[:, :D] *= ops.Q_PRESCALE               # the step's operands: q carries scale * log2 e (pxa_attn_args.q_prescaled)
     qkv = qkv32.to(ops.BF16)
     del qkv32
-    pre = dict(q_prescaled=True)
+    pre = {} if noscale else dict(q_prescaled=True)
     a = torch.empty(R, D, dtype=ops.BF16, device=dev)
     lse = torch.empty(B, H, N, device=dev)
     s3 = (N * 3 * D, 3 * D, 72)
