@@ -30,7 +30,7 @@ sys.path.insert(0, ROOT)
 
 D, H, DFF, DEPTH, LTXT = 1152, 16, 4608, 28, 300
 MFMA_PEAK = 2.5e15   # dense bf16, MI355X (MI355X_MICROARCH.md)
-PMC_FILES = ["profiles/r5final_pmc_attention.json", "profiles/r4final_pmc_attention.json", "profiles/r4_18_pmc_attention.json", "profiles/r03s_pmc_attention.json", "profiles/r03l_pmc_attention.json", "profiles/r03c_pmc_attention.json", "profiles/r02f_pmc_attention.json", "profiles/r02_pmc_attention.json"]   # newest first (tools/pmc_query.py --json)
+PMC_FILES = ["profiles/r5final_pmc_attention.json", "profiles/r5_07_pmc_attention.json", "profiles/r4final_pmc_attention.json", "profiles/r4_18_pmc_attention.json", "profiles/r03s_pmc_attention.json", "profiles/r03l_pmc_attention.json", "profiles/r03c_pmc_attention.json", "profiles/r02f_pmc_attention.json", "profiles/r02_pmc_attention.json"]   # newest first (tools/pmc_query.py --json)
 DOMINANT = "attn_bwd_dkv4_kernel"     # the step's largest kernel by total time (profiles/r4final_step_kernel_stats.csv: 28 self-attention launches; round 4: the
                                       # one-wave-per-SIMD dK/dV kernel, 256 keys per workgroup - attn_bwd_dkv2_kernel<1> until round 3; its 16-row variant dkv5 is
                                       # faster alone and slower in the step, profiles/r4_34_step_ab_attention.txt)
