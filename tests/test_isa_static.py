@@ -129,3 +129,25 @@ def test_m0_has_no_other_user(asm):
             if re.search(r"\bm0\b", c):
                 assert re.match(r"\s+s_(mov_b32|add_u32) m0,", c), (key, l.strip())
             assert not re.match(r"\s+(s_movrel|v_movrel|s_sendmsg|ds_gws|v_interp)", c), (key, l.strip())
+
+
+def test_row_kernels_keep_their_register_budget(tmp_path):
+    """Round 5: a third register accumulator set took ln_mod_bwd_kernel<9> from 284 to 334 registers and every call of it from 204 to 345 us (+8 ms per training step),
+    unnoticed by an A/B whose two sides ran the same kernel.  The instance without the fused bias gradient must stay the round-4 kernel (284 registers incl. the
+    accumulator-half spill space), the one with it may add its LDS addressing only; gate_bwd_kernel<9> leaves room for two waves per SIMD; nothing spills to scratch."""
+    from pixart_sigma_amd import build as B
+    o = str(tmp_path / "norm.s")
+    subprocess.run([B._hipcc(), *B.FLAGS, "-DPXA_OPERAND_F16", "-I", B.INCLUDE, "-S", "--cuda-device-only", os.path.join(B.CSRC, "norm.hip"), "-o", o], check=True, capture_output=True)
+    text = open(o).read()
+    meta = {}
+    for blk in re.split(r"\n  - \.agpr_count", text[text.find("amdhsa.kernels"):])[1:]:
+        g = lambda k: re.search(r"\." + k + r":\s+(\S+)", blk).group(1)
+        meta[g("name")] = (int(g("vgpr_count")), int(g("private_segment_fixed_size")))
+    def of(sub):
+        hits = [v for k, v in meta.items() if sub in k]
+        assert len(hits) == 1, (sub, [k for k in meta if sub in k])
+        return hits[0]
+    plain, fused, gate = of("ln_mod_bwd_kernelILi9ELb0E"), of("ln_mod_bwd_kernelILi9ELb1E"), of("gate_bwd_kernelILi9E")
+    assert plain[0] <= 288 and fused[0] <= plain[0] + 24, (plain, fused)
+    assert gate[0] <= 256, gate
+    assert plain[1] == 0 and fused[1] == 0 and gate[1] == 0, (plain, fused, gate)
