@@ -82,7 +82,8 @@ def test_gemm_nn_gelu_grad(ops):
     assert rel_l2(part.sum(0)[:N], (dy[:, :72].float() @ w[:72].float()).to(_opd()).float().sum(0)) < 1e-4
 
 
-@pytest.mark.parametrize("M,N,K", [(1100, 1152, 256), (2048, 1280, 128), (1024, 4608, 64), (2300, 1096, 192), (4096, 1152, 96)])
+@pytest.mark.parametrize("M,N,K", [(1100, 1152, 256), (2048, 1280, 128), (1024, 4608, 64), (2300, 1096, 192), (4096, 1152, 96),
+                                   (2300, 1096, 640), (1100, 1152, 512)])     # the last two: 20 / 16 k-units - long enough for the aux flavours' L2 touch window (GEMM_AUX_TOUCH)
 def test_gemm_persistent_kernel_epilogues(ops, M, N, K):
     """M, N >= 1024: the persistent 256x256 kernel (ragged last tiles in both directions; N % 256 <= 128: half-width remainder items)
     with every epilogue flavour."""
