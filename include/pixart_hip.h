@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define PXA_ABI_VERSION 7
+#define PXA_ABI_VERSION 8
 /* Kernels that fuse a bias-gradient column sum add into one of PXA_COLSUM_SLOTS partial rows ([slot][stride] fp32, caller-zeroed),
  * chosen per sample / row tile, so no address sees thousands of atomics; pxa_colsum_reduce folds the partials into the gradient. */
 #define PXA_COLSUM_SLOTS 16
@@ -81,6 +81,11 @@ typedef struct {
                                  /*  gn_part[slot][image][N/4][2] fp32 (PXA_COLSUM_SLOTS slots, caller-zeroed);                    */
                                  /*  pxa_vae_gn_finalize turns the partials into mean / rstd (groups are multiples of 4 channels).  */
                                  /*  Replaces the separate statistics pass over the output.                                        */
+  int items_descending;          /* (ABI 8, round 5) persistent NT / NN kernels: 1 = every XCD walks its range of output tiles from the  */
+                                 /*  LAST row tile to the first.  For a launch whose A operand was written by a kernel that swept the   */
+                                 /*  token rows in ascending order: the rows written last are the ones still in the 256 MB Infinity     */
+                                 /*  Cache, and this launch's own output then ends with the FIRST rows - fresh for an ascending         */
+                                 /*  consumer.  Results are bit-identical either way.  0 = ascending.                                   */
 } pxa_gemm_args;
 /* Upper bound of the split-K workspace (in floats) pxa_gemm may use for an (M, N) fp32-accumulate output. */
 long pxa_gemm_splitk_ws_elems(int M, int N);

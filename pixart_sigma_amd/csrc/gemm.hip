@@ -788,7 +788,12 @@ __global__ __launch_bounds__(512) void gemm_pers_kernel(GemmParams p) {
     else if (PAIR) { vt = true; m0a = (first_m + 2 * (in_g - nfull)) * 256; m0b = m0a + 256; n0 = ntf * 256; }
     else if (HALF) { vt = true; m0a = (first_m + (in_g - nfull)) * 256; m0b = m0a; n0 = ntf * 256; }
   };
-  auto locate = [&](int L) { locate_g(xs(L % 8) + L / 8); };   // static order: workgroup-strided index
+  // static order: workgroup-strided index.  p.desc (round 5): every XCD walks its contiguous range from the END - the grouped order puts the token rows' tiles in
+  // ascending order, so a launch behind a producer that swept the rows upwards starts on the rows still in the Infinity Cache (-1.7 ms per training step,
+  // profiles/r5_16_step_ab_reverse.txt); the same for the dynamic cursors
+  const bool rev = LAYOUT != 2 && p.desc != 0;
+  auto pos_of = [&](int x, int i) { return xs(x) + (rev ? xc(x) - 1 - i : i); };
+  auto locate = [&](int L) { locate_g(pos_of(L % 8, L / 8)); };
   const bool DYN = p.sched_slot >= 0;                  // slot < 0: static workgroup-strided split (A/B experiments)
   const int myx = blockIdx.x % 8;
   unsigned* sched = g_sched[p.sched_slot & 63];
@@ -819,12 +824,12 @@ __global__ __launch_bounds__(512) void gemm_pers_kernel(GemmParams p) {
     int res = -1;
     asm volatile("" : "+v"(pend));
     if (lane == 0) {
-      if ((int)pend < xc(myx)) res = xs(myx) + (int)pend;
+      if ((int)pend < xc(myx)) res = pos_of(myx, (int)pend);
       else
         for (int k = 1; k < 8 && res < 0; k++) {       // own range exhausted: take from the others (blocking; only at a kernel's tail)
           const int x2 = (myx + k) & 7;
           const unsigned i2 = atomicAdd(&sched[x2], 1u);
-          if ((int)i2 < xc(x2)) res = xs(x2) + (int)i2;
+          if ((int)i2 < xc(x2)) res = pos_of(x2, (int)i2);
         }
     }
     return __builtin_amdgcn_readfirstlane(res);
@@ -1697,6 +1702,8 @@ extern "C" int pxa_gemm(const pxa_gemm_args* a, hipStream_t stream) {
   p.outf = a->out_f32; p.ldf = a->ld_f32;
   p.act = a->act; p.accumulate = a->accumulate;
   p.tile_hint = 0;
+  static const bool force_asc = getenv("PXA_GEMM_ASCENDING") != nullptr;      // A/B: ignore items_descending
+  p.desc = (a->items_descending && !force_asc) ? 1 : 0;
   p.k_seg = a->k_seg; p.seg_jump = a->k_seg ? a->a_seg_stride - a->k_seg : 0;
   p.k_tap = a->k_seg ? a->k_tap : 0; p.tap_s = a->a_seg_stride;
   if (a->k_seg && a->k_tap)

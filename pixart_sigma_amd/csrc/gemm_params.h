@@ -9,6 +9,7 @@ struct GemmParams {
   bf16_t* out; bf16_t* out2; int ldo;
   float* outf; int ldf;
   int act, accumulate, k_per_split, tile_hint, split, sched_slot;
+  int desc;        // persistent NT / NN kernels: every XCD walks its item range from the end (pxa_gemm_args.items_descending)
   float* slab;
   float* colsum;   // optional [PXA_COLSUM_SLOTS][colsum_stride] partials: += column sums of the bf16 output, staged epilogue only
   long colsum_stride;

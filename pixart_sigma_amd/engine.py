@@ -192,8 +192,16 @@ class Engine:
             self._pos_cache[key] = torch.from_numpy(tab).to(F32).to(self.S.device).contiguous()
         return self._pos_cache[key]
 
+    # Item order of the token GEMMs (round 5, pxa_gemm_args.items_descending).  Every row kernel and attention kernel sweeps the token rows upwards, so the rows it
+    # wrote LAST are the ones still in the 256 MB Infinity Cache when the next GEMM starts: that GEMM walks its tiles downwards, and its own output then ends with the
+    # first rows - fresh for the ascending consumer behind it.  The second GEMM of a GEMM -> GEMM pair (fc2 behind fc1; fc1's dX behind fc2's dX) follows its
+    # producer by walking upwards.  Bit-identical results; -1.7 ... -2.1 ms per training step (profiles/r5_16 / r5_17_step_ab_reverse.txt).  PXA_GEMM_ASCENDING=1: off (A/B).
+    @staticmethod
+    def _desc(name):
+        return not name.endswith(("mlp.fc2", "kv_linear", "y_proj.fc1", "y_proj.fc2"))
+
     def _lin(self, x, name, **kw):
-        return ops.gemm(x, self.S.w(name + ".weight"), NT, bias=self.S.f(name + ".bias"), **kw)
+        return ops.gemm(x, self.S.w(name + ".weight"), NT, bias=self.S.f(name + ".bias"), descending=self._desc(name), **kw)
 
     def _lin_bwd(self, dy, x, name, need_dx=True, dx_kw=None, bias_done=False):
         """dW += dy^T x ; db += colsum(dy) (unless the kernel that produced dy already accumulated it) ; returns dx = dy W (bf16)."""
@@ -202,8 +210,9 @@ class Engine:
         ops.gemm(dy, x, TN, out_f32=S.g(name + ".weight"), accumulate=True, split_k=0)
         if not bias_done:
             ops.colsum(dy, S.g(name + ".bias"))
-        if need_dx:
-            return ops.gemm(dy, S.w(name + ".weight"), NN, **(dx_kw or {}))
+        if need_dx:                 # dX of fc1 follows fc2's dX GEMM (upwards); the text-row and caption-MLP GEMMs are too small to care
+            desc = not name.endswith(("mlp.fc1", "kv_linear", "y_proj.fc1", "y_proj.fc2"))
+            return ops.gemm(dy, S.w(name + ".weight"), NN, descending=desc, **(dx_kw or {}))
         return None
 
     def _qkv_prescaled(self, l):
@@ -263,7 +272,7 @@ class Engine:
         pre = dict(q_prescaled=True) if self.prescale else {}
         if self.prescale:
             wq, bq = self._qkv_prescaled(l)
-            qkv = ops.gemm(xn1, wq, NT, bias=bq)
+            qkv = ops.gemm(xn1, wq, NT, bias=bq, descending=True)
         else:
             qkv = self._lin(xn1, p + "attn.qkv")
         qkn = None

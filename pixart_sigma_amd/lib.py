@@ -13,7 +13,7 @@ OPERAND = os.environ.get("PXA_OPERAND_DTYPE", "bf16").lower()
 assert OPERAND in ("bf16", "f16"), f"PXA_OPERAND_DTYPE must be bf16 or f16, got {OPERAND!r}"
 OPERAND_DTYPE = torch.float16 if OPERAND == "f16" else torch.bfloat16
 LIB_PATH = os.environ.get("PXA_LIB_PATH") or os.path.join(_HERE, "libpixart_hip_f16.so" if OPERAND == "f16" else "libpixart_hip.so")   # env override: A/B kernel builds
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 c_void_p, c_int, c_long, c_float = C.c_void_p, C.c_int, C.c_long, C.c_float
 
@@ -26,7 +26,7 @@ class GemmArgs(C.Structure):
                 ("out_f32", c_void_p), ("ld_f32", c_int), ("accumulate", c_int), ("split_k", c_int),
                 ("splitk_ws", c_void_p), ("splitk_ws_elems", c_long), ("colsum", c_void_p), ("colsum_stride", c_long),
                 ("k_seg", c_int), ("a_seg_stride", c_long), ("k_tap", c_int),
-                ("gn_part", c_void_p), ("gn_img_rows", c_int), ("gn_row_pitch", c_int), ("gn_h", c_int), ("gn_w", c_int)]
+                ("gn_part", c_void_p), ("gn_img_rows", c_int), ("gn_row_pitch", c_int), ("gn_h", c_int), ("gn_w", c_int), ("items_descending", c_int)]
 
 
 class GridArg(C.Structure):

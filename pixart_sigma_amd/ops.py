@@ -21,12 +21,14 @@ def _chk(t, dtype, name):
 
 
 def gemm(a, b, layout=NT, bias=None, act=ACT_NONE, aux=None, out=None, out2=None, out_f32=None, accumulate=False,
-         split_k=1, out_dtype=BF16, colsum=None, k_seg=0, a_seg_stride=0, k_tap=0, gn_part=None, gn_geom=None):
+         split_k=1, out_dtype=BF16, colsum=None, k_seg=0, a_seg_stride=0, k_tap=0, gn_part=None, gn_geom=None, descending=False):
     """C = op(A) op(B) (see include/pixart_hip.h).  a, b: 2-D bf16 (row stride arbitrary multiple of 8).
     Returns the bf16 output (or fp32 when out_dtype is float32 / out_f32 is given).
     k_seg / a_seg_stride / k_tap: segmented-K A operand (the implicit 3x3 convolution of the VAE kernel set).
     gn_part (PXA_COLSUM_SLOTS, B, N/4, 2) fp32 zeros + gn_geom = (img_rows, row_pitch, H, W): GroupNorm statistics of the output
-    accumulated by the epilogue (see pxa_gemm_args.gn_part)."""
+    accumulated by the epilogue (see pxa_gemm_args.gn_part).
+    descending: the persistent NT / NN kernels walk their output tiles from the last token rows to the first (pxa_gemm_args.items_descending) - for a launch
+    whose A operand was just written by a kernel that swept the rows upwards; bit-identical results."""
     _chk(a, BF16, "A")
     _chk(b, BF16, "B")
     if layout == NT:
@@ -66,6 +68,7 @@ def gemm(a, b, layout=NT, bias=None, act=ACT_NONE, aux=None, out=None, out2=None
         assert out is not None and out2.stride(0) == out.stride(0)
         g.out2_bf16 = ptr(out2)
     g.accumulate, g.split_k = int(accumulate), split_k
+    g.items_descending = int(bool(descending))
     g.k_seg, g.a_seg_stride, g.k_tap = k_seg, a_seg_stride, k_tap
     if gn_part is not None:
         _chk(gn_part, F32, "gn_part")

@@ -564,13 +564,22 @@ def test_gemm_item_schedulers_agree(ops, layout):
     prev = L.pxa_gemm_set_dynamic_items(0)
     try:
         o_static = ops.gemm(a, w, getattr(ops, layout), bias=b).clone()
+        o_static_desc = ops.gemm(a, w, getattr(ops, layout), bias=b, descending=True).clone()     # round 5: every XCD walks its range from the end
         assert L.pxa_gemm_set_dynamic_items(1) == 0
         o_dyn = ops.gemm(a, w, getattr(ops, layout), bias=b).clone()
+        o_dyn_desc = ops.gemm(a, w, getattr(ops, layout), bias=b, descending=True).clone()
         assert L.pxa_gemm_set_dynamic_items(0) == 1
     finally:
         L.pxa_gemm_set_dynamic_items(prev)
     ref = a.float() @ (w.float().t() if layout == "NT" else w.float()) + b
     assert rel_l2(o_static.float(), ref) < BF16_TOL and torch.equal(o_static, o_dyn)
+    assert torch.equal(o_static, o_static_desc) and torch.equal(o_static, o_dyn_desc)
+    # ragged shape (a remainder column, a partial last row tile), descending, with an epilogue flavour that reads aux
+    M2, N2, K2 = 2300, 1096 if layout == "NN" else 1152, 640
+    a2 = bf(_gpu_rnd(M2, K2, seed=4))
+    w2 = bf(_gpu_rnd(N2, K2, scale=K2 ** -0.5, seed=5)) if layout == "NT" else bf(_gpu_rnd(K2, N2, scale=K2 ** -0.5, seed=5))
+    kw = dict(bias=_gpu_rnd(N2, seed=6)) if layout == "NT" else dict(act=ops.ACT_MUL_AUX, aux=bf(_gpu_rnd(M2, N2, seed=7)))
+    assert torch.equal(ops.gemm(a2, w2, getattr(ops, layout), **kw), ops.gemm(a2, w2, getattr(ops, layout), descending=True, **kw))
 
 
 @pytest.mark.parametrize("K,N,flavour", [(3456, 1152, "plain"), (1152, 1152, "plain"), (4608, 1152, "plain"), (1152, 4608, "mul_aux_colsum")])
