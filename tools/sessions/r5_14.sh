@@ -1,7 +1,7 @@
 #!/bin/bash
 # round 5 session 14: the GPU test tier, smoke() and the default bench line once more at the round's last commit (kernels as in the r5final bundle; two more test cases)
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" || exit 1
-O=gpurun_out; tag=r5head
+O=gpurun_out; tag=${1:-r5head}
 export PYTHONUNBUFFERED=1
 hdr="# box $(hostname) $(date -u +%FT%TZ) HEAD $(cat .gpurun_head 2>/dev/null || echo unknown)"
 echo "$hdr (both operand builds: the tier re-runs the kernel and model suites under f16 in subprocesses)" > $O/${tag}_pytest_gpu.txt
