@@ -161,9 +161,6 @@ def _splitk(M, N, K):
     return max(1, min((640 + tiles - 1) // tiles, max(1, K // 512)))
 
 
-_DX_FIRST = os.environ.get("PXA_DX_FIRST", "0") == "1"
-
-
 class Engine:
     """Forward/backward sequencing for one PixArtMS instance."""
 
@@ -210,19 +207,15 @@ class Engine:
         """dW += dy^T x ; db += colsum(dy) (unless the kernel that produced dy already accumulated it) ; returns dx = dy W (bf16)."""
         S = self.S
         M, N = S.shape[name + ".weight"]
-        dx = None
-        dx_first = need_dx and _DX_FIRST           # experiment (PXA_DX_FIRST=1): dX right behind the kernel that produced dy, the weight gradient after it
-        def run_dx():                # dX of fc1 follows fc2's dX GEMM (upwards); the text-row and caption-MLP GEMMs are too small to care
-            desc = not name.endswith(("mlp.fc1", "kv_linear", "y_proj.fc1", "y_proj.fc2"))
-            return ops.gemm(dy, S.w(name + ".weight"), NN, descending=desc, **(dx_kw or {}))
-        if dx_first:
-            dx = run_dx()
+        # (order measured: the weight gradient FIRST - its pass over dy leaves dy in the Infinity Cache for the dX GEMM; dX first is 1.6 ms per step slower,
+        # profiles/r5_20_step_ab_dx_first.txt)
         ops.gemm(dy, x, TN, out_f32=S.g(name + ".weight"), accumulate=True, split_k=0)
         if not bias_done:
             ops.colsum(dy, S.g(name + ".bias"))
-        if need_dx and not dx_first:
-            dx = run_dx()
-        return dx
+        if need_dx:                 # dX of fc1 follows fc2's dX GEMM (upwards); the text-row and caption-MLP GEMMs are too small to care
+            desc = not name.endswith(("mlp.fc1", "kv_linear", "y_proj.fc1", "y_proj.fc2"))
+            return ops.gemm(dy, S.w(name + ".weight"), NN, descending=desc, **(dx_kw or {}))
+        return None
 
     def _qkv_prescaled(self, l):
         """(weight (3D, D) in the operand type, bias (3D,) fp32) of block l with the q rows times scale * log2 e; rebuilt when the weights changed."""
