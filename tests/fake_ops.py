@@ -39,7 +39,7 @@ def gemm(a, b, layout=NT, bias=None, act=ACT_NONE, aux=None, out=None, out2=None
         M, N = a.shape[0], b.shape[1]
     else:
         M, N = a.shape[1], b.shape[1]
-    CALLS.append(("gemm", layout, M, N))
+    CALLS.append(("gemm", layout, M, N) + (("desc",) if kw.get("descending") else ()))
     if out_f32 is not None:
         assert tuple(out_f32.shape) == (M, N)
         if accumulate:                       # a weight gradient (or the caption-gradient accumulator): lands in the flat buffer

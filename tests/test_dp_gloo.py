@@ -198,3 +198,28 @@ def test_reducer_restores_the_gemm_item_hand_out(monkeypatch, tmp_path):
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     assert out.returncode == 0, out.stderr
     assert out.stdout.strip().splitlines()[-1].split() == ["1", "0", "0"], out.stdout
+
+
+def test_engine_sets_the_gemm_item_direction(monkeypatch):
+    """Round 5 (pxa_gemm_args.items_descending): every NT / NN token GEMM behind an ascending producer walks its tiles downwards; the second GEMM of a GEMM -> GEMM
+    pair (fc2 behind fc1, fc1's dX behind fc2's dX), the text-row and caption GEMMs and every weight-gradient (TN) GEMM keep the ascending order."""
+    m, fake_ops, run = _build(monkeypatch)
+    from pixart_sigma_amd import ops
+    fake_ops.CALLS.clear()
+    run()
+    g = [c for c in fake_ops.CALLS if c[0] == "gemm"]
+    R, D = 2 * 16, 1152                                                  # 2 samples x (8 / 2)^2 tokens
+    tok = [c for c in g if c[2] == R]                                    # token-row launches (M = tokens): NT forward, NN dX
+    desc = lambda c: c[-1] == "desc"
+    fwd = [c for c in tok if c[1] == ops.NT]
+    dx = [c for c in tok if c[1] == ops.NN]
+    assert fwd and dx
+    # forward, per block: qkv, attn.proj, q_linear, cross.proj, fc1 descending; fc2 (N = D behind an N = 4 D launch) ascending
+    for i, c in enumerate(fwd):
+        follows_fc1 = i > 0 and fwd[i - 1][3] == 4 * D
+        assert desc(c) == (not follows_fc1 and c[3] in (D, 3 * D, 4 * D)), (i, c)
+    # backward: fc2's dX (N = 4 D) descending, fc1's dX right behind it ascending, the others descending
+    for i, c in enumerate(dx):
+        follows_fc2_dx = i > 0 and dx[i - 1][3] == 4 * D
+        assert desc(c) == (not follows_fc2_dx), (i, c)
+    assert not any(desc(c) for c in g if c[1] == ops.TN)
