@@ -291,6 +291,7 @@ def main():
                     help="SURVEY.md section 8d secondary: caption lengths drawn from 12..300 per sample (packed varlen cross-attention) instead of all 300")
     ap.add_argument("--no-other-dtype", action="store_true", help="skip the subprocess run of the other operand build (N = 1 only)")
     ap.add_argument("--no-torch-baseline", action="store_true", help="skip the stock-PyTorch-ROCm leg (N = 1 only)")
+    ap.add_argument("--no-configs", action="store_true", help="skip the BASELINE configs 2 / 4 / 5 leg (N = 1 only; subprocesses after the timed region)")
     ap.add_argument("--optimizer", choices=["adamw", "came"], default="adamw",
                     help="adamw = the BASELINE config (configs/PixArt_xl2_internal.py); came = the CAMEWrapper of the Sigma configs")
     a = ap.parse_args()

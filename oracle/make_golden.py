@@ -74,7 +74,19 @@ CASES = {
     # full-depth 2K with the shipped KV-compression layout (conv x2 on blocks 14..27: PixArt_sigma_xl2_img2K_internalms_kvcompress.py:44-49)
     "fwd_xl2_2k_kv_b1": (dict(depth=28, input_size=256, model_max_length=300, pe_interpolation=4.0, kv_sampling="conv", kv_scale_factor=2,
                               kv_layers=tuple(range(14, 28))), dict(B=1, Hl=256, Wl=256, L=300, lens=[300])),
+    # ---- round 6: the inference configs END TO END at their configured step count (VERDICT r05 missing #2) ----
+    # BASELINE.json configs[1]: the full-depth XL/2 at 512px, 20-step DPM-Solver++(2M) with CFG 4.5 (scripts/inference.py:107-118,
+    # diffusion/model/dpm_solver.py:1196-1241), batch 2 (model batch 4), ragged captions; every intermediate x_t is kept (error against step index)
+    "dpms_xl2_512_s20": (dict(depth=28, input_size=64, model_max_length=300, pe_interpolation=1.0), dict(B=2, Hl=64, Wl=64, L=300, lens=[300, 77])),
+    # BASELINE.json configs[3]: 2K latent, the shipped KV-compression layout, a 4-step chain (8 full-depth N = 16384 forwards on the CPU)
+    "dpms_xl2_2k_kv_s4": (dict(depth=28, input_size=256, model_max_length=300, pe_interpolation=4.0, kv_sampling="conv", kv_scale_factor=2,
+                               kv_layers=tuple(range(14, 28))), dict(B=1, Hl=256, Wl=256, L=300, lens=[211])),
+    # BASELINE.json configs[4]: the one-step generator of PixArt-alpha-DMD: eps at t = 400 without guidance, then eps -> x0 through the reference's own
+    # eps_to_mu (scripts/DMD/transformer_train/generate.py:34-41; the diffusers pipeline takes the same pred_original_sample, scripts/diffusers_patches.py:448-449)
+    "dmd_xl2_512_l120": (dict(depth=28, input_size=64, model_max_length=120, pe_interpolation=1.0), dict(B=2, Hl=64, Wl=64, L=120, lens=[120, 41])),
 }
+# steps of the DPM-Solver chains above (2 for the round-1 cases)
+DPMS_STEPS = {"dpms_xl2_512_s20": 20, "dpms_xl2_2k_kv_s4": 4}
 
 
 def build_reference(cfg, sd):
@@ -172,15 +184,38 @@ def gen_case(name):
             finally:
                 torch.randn_like = real_randn_like
         out["sample"], out["draws"] = s_.clone(), draws
+    elif name.startswith("dmd"):
+        import importlib.util
+        import types
+        from diffusion.model import gaussian_diffusion as gd
+        spec = importlib.util.spec_from_file_location("_ref_dmd_generate", os.path.join(ref_stubs.REFERENCE_ROOT, "scripts/DMD/transformer_train/generate.py"))
+        gen_mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(gen_mod)
+        # the scheduler of the alpha / DMD pipelines: linear betas 1e-4 .. 2e-2 over 1000 steps; eps_to_mu reads .alphas_cumprod only
+        betas = torch.tensor(gd.get_named_beta_schedule("linear", 1000))
+        sched = types.SimpleNamespace(alphas_cumprod=torch.cumprod(1.0 - betas, dim=0))
+        t = torch.full((inp["x"].shape[0],), 400, dtype=torch.long)          # app/app_pixart_dmd.py:193-196: timesteps=[400], one step, no guidance
+        with torch.no_grad():
+            eps = m.forward_with_dpmsolver(inp["x"], t, inp["y"], data_info=data_info, mask=mask)
+            out["eps"] = eps.clone()
+            out["x0"] = gen_mod.eps_to_mu(sched, eps, inp["x"], t).clone()
+        out["t"], out["abar_t"] = 400, float(sched.alphas_cumprod[400])
     elif name.startswith("dpms") or name.startswith("cfg1"):
         from diffusion import DPMS
         g = torch.Generator().manual_seed(7)
         null_y = torch.randn(1, 1, ikw["L"], 4096, generator=g).repeat(inp["x"].shape[0], 1, 1, 1)
+        steps = DPMS_STEPS.get(name, 2)
         with torch.no_grad():
-            out["fwd"] = m(inp["x"], inp["t"], inp["y"], mask=mask, data_info=data_info).clone()
+            if steps == 2:
+                out["fwd"] = m(inp["x"], inp["t"], inp["y"], mask=mask, data_info=data_info).clone()
             dpms = DPMS(m.forward_with_dpmsolver, condition=inp["y"], uncondition=null_y, cfg_scale=4.5,
                         model_kwargs=dict(data_info=data_info, mask=mask))
-            out["sample"] = dpms.sample(inp["x"], steps=2, order=2, skip_type="time_uniform", method="multistep").clone()
+            if steps == 2:
+                out["sample"] = dpms.sample(inp["x"], steps=2, order=2, skip_type="time_uniform", method="multistep").clone()
+            else:       # x_t after every solver step (intermediates[0] is the initial latent, [-1] the sample: dpm_solver.py:1207-1234)
+                s_, inter = dpms.sample(inp["x"], steps=steps, order=2, skip_type="time_uniform", method="multistep", return_intermediate=True)
+                out["sample"], out["steps"] = s_.clone(), steps
+                out["intermediates"] = torch.stack([v.clone() for v in inter])
         out["null_seed"] = 7
     out["ref_seconds"] = time.time() - t0
     return out

@@ -1,0 +1,92 @@
+#!/bin/bash
+# ONE parameterised GPU-session runner (round 6; replaces the 112 one-off tools/sessions/*.sh - tools/sessions/MANIFEST.md maps every historical session to the
+# recipe + environment that reproduces it).  Runs on the GPU box from the repo root:
+#     gpurun --timeout T -- 'bash tools/session.sh TAG recipe [recipe ...]'
+# Every text artefact starts with the box, the UTC time, the HEAD the snapshot carries (.gpurun_head, written by tools/gpurun_session.sh) and the operand build.
+# A recipe may carry arguments after colons:  step_ab:"default|":"asc|PXA_GEMM_ASCENDING=1"
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT" || exit 1
+O=gpurun_out
+tag=$1; shift
+export PYTHONUNBUFFERED=1
+mkdir -p $O
+hdr="# box $(hostname) $(date -u +%FT%TZ) HEAD $(cat .gpurun_head 2>/dev/null || echo unknown)"
+BENCH_QUIET="--no-cpu-baseline --no-kernel-roofline --no-torch-baseline --no-other-dtype --no-configs"
+
+r_tests() {      # the GPU test tier (both operand builds: the tier re-runs the kernel and model suites under f16 in subprocesses)
+  echo "$hdr (both operand builds)" > $O/${tag}_pytest_gpu.txt
+  timeout 2700 python -m pytest tests -m gpu -q -p no:cacheprovider "$@" >> $O/${tag}_pytest_gpu.txt 2>&1; echo "pytest rc=$?" >> $O/${tag}_pytest_gpu.txt
+  tail -n 5 $O/${tag}_pytest_gpu.txt
+}
+r_pytest() {     # selected tests:  pytest:tests/test_model_gpu.py:-k:dpm   (PXA_OPERAND_DTYPE from the environment)
+  echo "$hdr operand build ${PXA_OPERAND_DTYPE:-bf16}: pytest $*" >> $O/${tag}_pytest_sel.txt
+  timeout 1800 python -m pytest -m gpu -q -p no:cacheprovider -s "$@" >> $O/${tag}_pytest_sel.txt 2>&1; echo "pytest rc=$?" >> $O/${tag}_pytest_sel.txt
+  grep -v amdgpu $O/${tag}_pytest_sel.txt | tail -n 40 | cut -c1-300
+}
+r_smoke() {
+  echo "$hdr" > $O/${tag}_smoke.txt
+  timeout 900 python __graft_entry__.py smoke >> $O/${tag}_smoke.txt 2>&1; echo "smoke rc=$?" >> $O/${tag}_smoke.txt
+  grep -v amdgpu $O/${tag}_smoke.txt | tail -n 12 | cut -c1-600
+}
+r_bench() {      # the default bench line with every leg (what the driver runs)
+  timeout 2400 python bench.py "$@" > $O/${tag}_bench_default.json 2> $O/${tag}_bench_default.err
+  cut -c1-1500 $O/${tag}_bench_default.json; tail -n 3 $O/${tag}_bench_default.err
+}
+r_profile_step() {   # rocprofv3 --kernel-trace --stats of the benchmark's training step -> per-kernel csv + family table
+  rocprofv3 --kernel-trace --stats -d $O/prof_$tag -o step -- python bench.py --steps 2 --warmup 1 $BENCH_QUIET > $O/prof_${tag}_step.log 2>&1
+  python tools/export_profile.py $O/prof_$tag/step_results.db $O/${tag}_step_kernel_stats.csv 3
+  rm -rf $O/prof_$tag
+  { echo "$hdr operand build f16"; python tools/family_times.py $O/${tag}_step_kernel_stats.csv; } > $O/${tag}_family_times.txt
+  cat $O/${tag}_family_times.txt; head -14 $O/${tag}_step_kernel_stats.csv | cut -c1-130
+}
+r_profile_round() { timeout 900 bash tools/profile_round.sh $tag > $O/${tag}_profile_round.log 2>&1; tail -n 5 $O/${tag}_profile_round.log; }
+r_pmc_step() {
+  timeout 1200 bash tools/pmc_step.sh $tag > $O/${tag}_pmc_step.log 2>&1
+  { echo "$hdr operand build f16"; python tools/pmc_step_table.py $O/$tag; } > $O/${tag}_pmc_step_gemm_table.txt 2>&1
+  cut -c1-150 $O/${tag}_pmc_step_gemm_table.txt
+}
+r_step_ab() {    # same-box A/B of the training step:  step_ab:"label|ENV=1 ENV2=x":"other|"
+  echo "$hdr operand build f16" > $O/${tag}_step_ab.hdr
+  bash tools/step_ab.sh $O/${tag}_step_ab.body "$@" > /dev/null
+  cat $O/${tag}_step_ab.hdr $O/${tag}_step_ab.body > $O/${tag}_step_ab.txt; rm -f $O/${tag}_step_ab.hdr $O/${tag}_step_ab.body
+  cat $O/${tag}_step_ab.txt
+}
+r_infer() {      # BASELINE configs 2 / 4 / 5, fp16 operands (what bench.py's `configs` leg runs)
+  echo "$hdr operand build f16 (tools/bench_infer.py, tools/bench_dmd.py) $*" >> $O/${tag}_bench_infer.txt
+  timeout 900 python tools/bench_infer.py both "$@" >> $O/${tag}_bench_infer.txt 2>&1
+  timeout 900 python tools/bench_dmd.py >> $O/${tag}_bench_infer.txt 2>&1
+  grep -v amdgpu $O/${tag}_bench_infer.txt | tail -n 4 | cut -c1-500
+}
+r_profile_infer() {  # kernel trace of the denoiser evaluations of config 2 (512px, model batch 16) and config 4 (2K, model batch 4), per NFE
+  export PXA_OPERAND_DTYPE=f16
+  for c in "512|4" "2k|2"; do
+    w=${c%%|*}; st=${c#*|}
+    rocprofv3 --kernel-trace --stats -d $O/prof_${tag}_i$w -o r -- python tools/bench_infer.py $w --steps $st > $O/prof_${tag}_i$w.log 2>&1
+    python tools/export_profile.py $O/prof_${tag}_i$w/r_results.db $O/${tag}_infer${w}_kernel_stats.csv $((3 * st))     # three sample() calls of `st` evaluations
+    rm -rf $O/prof_${tag}_i$w
+    sed -i "1i $hdr operand build f16; python tools/bench_infer.py $w --steps $st; per denoiser evaluation (NFE)" $O/${tag}_infer${w}_kernel_stats.csv
+    head -16 $O/${tag}_infer${w}_kernel_stats.csv | cut -c1-140
+  done
+}
+r_profile_vae() {    # kernel trace of the SD-VAE decode of config 5 (64 x 512px): per-kernel csv + the launch-ordered trace of the last decode (per-layer table)
+  export PXA_OPERAND_DTYPE=f16
+  rocprofv3 --kernel-trace --stats -d $O/prof_${tag}_vae -o r -- python tools/bench_vae.py --px 512 --batch ${1:-64} --iters 2 > $O/prof_${tag}_vae.log 2>&1
+  python tools/export_profile.py $O/prof_${tag}_vae/r_results.db $O/${tag}_vae_decode512_kernel_stats.csv 3
+  python tools/export_trace.py $O/prof_${tag}_vae/r_results.db $O/${tag}_vae_decode512_trace.csv 3
+  rm -rf $O/prof_${tag}_vae
+  sed -i "1i $hdr operand build f16; python tools/bench_vae.py --px 512 --batch ${1:-64} --iters 2; per decode" $O/${tag}_vae_decode512_kernel_stats.csv
+  grep -v amdgpu $O/prof_${tag}_vae.log | tail -n 2 | cut -c1-400; head -14 $O/${tag}_vae_decode512_kernel_stats.csv | cut -c1-140
+  python tools/vae_layer_table.py $O/${tag}_vae_decode512_trace.csv ${1:-64} > $O/${tag}_vae_layer_table.txt 2>&1 && sed -i "1i $hdr operand build f16" $O/${tag}_vae_layer_table.txt
+  cat $O/${tag}_vae_layer_table.txt | cut -c1-170
+}
+r_run() {        # anything else, logged under the tag:  run:python:tools/kbench.py:attn
+  echo "$hdr operand build ${PXA_OPERAND_DTYPE:-bf16}: $*" >> $O/${tag}_run.txt
+  timeout 1500 "$@" >> $O/${tag}_run.txt 2>&1; echo "rc=$?" >> $O/${tag}_run.txt
+  grep -v amdgpu $O/${tag}_run.txt | tail -n 30 | cut -c1-400
+}
+
+for spec in "$@"; do
+  IFS=':' read -r -a parts <<< "$spec"
+  name=${parts[0]}
+  echo "=== $name ${parts[*]:1}"
+  "r_$name" "${parts[@]:1}"
+done
