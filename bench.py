@@ -272,6 +272,45 @@ def torch_rocm_baseline(B, lat, px, steps=3, warmup=1):
     return dt, mode["ckpt"]
 
 
+def baseline_configs(timeout=900):
+    """BASELINE.json configs[1], [3], [4] on this box, each in its own process AFTER the headline's timed region and legs: the 20-step
+    DPM-Solver++ CFG-4.5 samplers at 512px / batch 8 and 2K / batch 2 with KV compression (tools/bench_infer.py) and the DMD one-step generator + SD-VAE decode at
+    batch 64 (tools/bench_dmd.py), fp16 operands - the reference's inference dtype (scripts/inference.py:188-196).  Parity of exactly these chains:
+    tests/test_model_gpu.py (dpms_xl2_512_s20, dpms_xl2_2k_kv_s4, dmd_xl2_512_l120 goldens from the live reference)."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("PXA_OPERAND_DTYPE", "PXA_LIB_PATH", "RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env["PXA_OPERAND_DTYPE"] = "f16"
+    out = {}
+
+    def lines(cmd):
+        r = subprocess.run([sys.executable] + cmd, capture_output=True, text=True, env=env, timeout=timeout, cwd=ROOT)
+        js = []
+        for ln in r.stdout.splitlines():
+            if ln.startswith("{"):
+                try:
+                    js.append(json.loads(ln))
+                except ValueError:
+                    pass
+        if not js:
+            raise RuntimeError((r.stderr or r.stdout)[-300:])
+        return js
+    try:
+        for key, j in zip(("c2", "c4"), lines([os.path.join(ROOT, "tools", "bench_infer.py"), "both"])):
+            out[key] = {"workload": j["workload"], "seconds": round(j["seconds"], 4), "unit": "s per batch of images (20 denoiser evaluations)", "images_per_s": round(j["images_per_s"], 3),
+                        "ms_per_nfe": round(j["ms_per_nfe"], 3), "TFLOP/s": round(j["TFLOP/s"], 1), "frac": round(j["mfma_frac"], 4), "dtype": "fp16"}
+    except Exception as e:   # noqa: BLE001 - a side leg must never take the headline number down
+        out["c2_c4_error"] = f"{type(e).__name__}: {e}"[:300]
+    try:
+        j = lines([os.path.join(ROOT, "tools", "bench_dmd.py")])[-1]
+        out["c5"] = {"workload": j["workload"], "ms_per_batch": round(j["ms_per_batch"], 2), "images_per_s": round(j["images_per_s"], 2), "ms_dit": round(j["ms_dit"], 2),
+                     "ms_vae_decode": round(j["ms_vae_decode"], 2), "TFLOP/s": round(j["TFLOP/s"], 1), "frac": round(j["mfma_frac"], 4),
+                     "frac_dit": round(j["TFLOP_dit"] * 1e12 / (j["ms_dit"] * 1e-3) / MFMA_PEAK, 4),
+                     "frac_vae": round(j["TFLOP_vae"] * 1e12 / (j["ms_vae_decode"] * 1e-3) / MFMA_PEAK, 4), "dtype": "fp16"}
+    except Exception as e:   # noqa: BLE001
+        out["c5_error"] = f"{type(e).__name__}: {e}"[:300]
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -316,7 +355,7 @@ def main():
     lat = a.image_size // 8
     N = (lat // 2) ** 2
     B = a.batch
-    torch.manual_seed(0)     # identical init on every rank (DDP broadcast equivalent)
+    torch.manual_seed(0)     # identical init on every rank; model.prepare() below ALSO broadcasts rank 0's weights when a process group exists (DDP semantics)
     model = PixArtMS_XL_2(input_size=lat, pe_interpolation=a.image_size / 512, model_max_length=LTXT, class_dropout_prob=0.0)
     with torch.no_grad():    # re-randomise the zero-init tensors so no branch is numerically dead
         for blk in model.blocks:
@@ -422,7 +461,9 @@ def main():
             except Exception as e:   # noqa: BLE001 - a measurement leg must never take the headline number down
                 roof["mfma_only_rate"] = {"error": f"{type(e).__name__}: {e}"[:300]}
         out["roofline"] = roof
-        if world == 1 and not (a.no_other_dtype and a.no_torch_baseline):
+        if getattr(opt.reducer, "last_trace", None) is not None:     # PXA_DP_TRACE=1: the last step's per-bucket record (ready / passed / exposed communication)
+            out["dp_trace"] = opt.reducer.last_trace
+        if world == 1 and not (a.no_other_dtype and a.no_torch_baseline and a.no_configs):
             del opt
             model._store = model._engine = None
             del model
@@ -432,7 +473,7 @@ def main():
             import subprocess
             other = "bf16" if a.dtype == "fp16" else "fp16"
             cmd = [sys.executable, os.path.abspath(__file__), "--dtype", other, "--steps", str(a.steps), "--warmup", str(a.warmup), "--batch", str(B),
-                   "--image-size", str(a.image_size), "--optimizer", a.optimizer, "--no-other-dtype", "--no-cpu-baseline", "--no-torch-baseline", "--no-kernel-roofline"]
+                   "--image-size", str(a.image_size), "--optimizer", a.optimizer, "--no-other-dtype", "--no-cpu-baseline", "--no-torch-baseline", "--no-kernel-roofline", "--no-configs"]
             if a.grad_checkpoint:
                 cmd.append("--grad-checkpoint")
             env = {k: v for k, v in os.environ.items() if k not in ("PXA_OPERAND_DTYPE", "PXA_LIB_PATH", "RANK", "WORLD_SIZE", "LOCAL_RANK")}
@@ -453,6 +494,8 @@ def main():
                                                       f"{B}" + ("; per-block activation checkpointing (activations did not fit)" if ckpt else "; no recompute")}
             except Exception as e:   # noqa: BLE001 - the baseline leg must never take the headline number down with it
                 out["torch_rocm_baseline"] = {"value": None, "error": f"{type(e).__name__}: {e}"[:300]}
+        if not a.no_configs and world == 1:
+            out["configs"] = baseline_configs()
         if not a.no_cpu_baseline and world == 1:
             cdt, cores, desc = cpu_baseline(a.image_size)
             out["cpu_baseline"] = {"value": 1.0 / (cdt * B), "unit": "steps/s", "cores": cores, "kind": "port",

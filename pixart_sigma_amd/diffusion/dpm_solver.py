@@ -72,7 +72,7 @@ class DPM_Solver:
         return e_u + self.cfg_scale * (e_c - e_u)
 
     def sample(self, x, steps=20, t_start=None, t_end=None, order=2, skip_type="time_uniform", method="multistep",
-               lower_order_final=True, solver_type="dpmsolver", **unused):
+               lower_order_final=True, solver_type="dpmsolver", return_intermediate=False, **unused):
         assert method == "multistep" and skip_type == "time_uniform" and solver_type == "dpmsolver" and order in (1, 2)
         assert steps >= order
         ns = self.ns
@@ -96,10 +96,13 @@ class DPM_Solver:
             D1 = float(1.0 / r0) * (m0 - m1)
             return float(sig[i_t] / sig[i0]) * x - c * m0 - 0.5 * c * D1
 
+        inter = [x] if return_intermediate else None                      # :1207-1208: x_t after every solver step, the initial latent first
         with torch.no_grad():
             idx_prev, m_prev = [0], [x0_pred(x, 0)]
             for step in range(1, order):                                  # :1205-1213
                 x = first(x, idx_prev[-1], step, m_prev[-1])
+                if inter is not None:
+                    inter.append(x)
                 idx_prev.append(step)
                 m_prev.append(x0_pred(x, step))
             for step in range(order, steps + 1):                          # :1215-1241
@@ -108,12 +111,14 @@ class DPM_Solver:
                     x = first(x, idx_prev[-1], step, m_prev[-1])
                 else:
                     x = second(x, idx_prev[-2], idx_prev[-1], step, m_prev[-2], m_prev[-1])
+                if inter is not None:
+                    inter.append(x)
                 for i in range(order - 1):
                     idx_prev[i], m_prev[i] = idx_prev[i + 1], m_prev[i + 1]
                 idx_prev[-1] = step
                 if step < steps:
                     m_prev[-1] = x0_pred(x, step)
-        return x
+        return (x, inter) if return_intermediate else x                   # :1279-1282
 
     def sample_graphed(self, x, **kw):
         """the whole K-step loop — K denoiser evaluations (~700 kernel launches each) and the solver
@@ -133,6 +138,9 @@ class DPM_Solver:
             with torch.cuda.graph(graph):
                 self._static_out = self.sample(self._static_x, **kw)
             self._graph, self._graph_key = graph, key
+        owner = getattr(self.model, "__self__", None)        # the denoiser behind a bound forward: weights loaded / edited by torch ops since the capture are
+        if hasattr(owner, "prepare") and hasattr(owner, "_store"):   # re-cast into the buffers the graph reads (shadow + derived copies, all rewritten in place)
+            owner.prepare(broadcast=False)
         self._static_x.copy_(x)
         self._graph.replay()
         return self._static_out.clone()

@@ -83,6 +83,7 @@ class ParamStore:
         self.params = dict(named_params)
         self._versions = None
         self.generation = 0        # bumped whenever the shadow weights change (re-cast here, fused optimizer steps): keys everything cached from them
+        self._on_change = []       # callables run at every bump: buffers DERIVED from the weights are rewritten in place there (Engine._refresh_qs)
         for name, p in named_params:
             v = self.view(self.master, name)
             v.copy_(p.data)
@@ -126,6 +127,13 @@ class ParamStore:
         or an assignment to p.data re-points parameters one by one; checking only the first one would keep reading stale copies)."""
         return all(n in self.offset and self.owns(p, n) for n, p in named_params)
 
+    def bump(self):
+        """The shadow weights changed (a re-cast, a fused optimizer step): new generation, and every buffer derived from the weights is rewritten IN PLACE now -
+        so whatever holds its address (a captured HIP graph) keeps reading current values, exactly as it does for the shadow itself."""
+        self.generation += 1
+        for fn in self._on_change:
+            fn()
+
     def refresh_shadow(self, force=False):
         """Re-cast master -> bf16 shadow if any parameter was modified by torch ops since the last cast (the fused AdamW
         kernel refreshes the shadow itself and does not bump versions)."""
@@ -136,7 +144,7 @@ class ParamStore:
         if force or vers != self._versions:
             ops.cast_bf16(self.master, self.shadow)
             self._versions = vers
-            self.generation += 1
+            self.bump()
 
     def attach_grads(self):
         """Make every p.grad the view of the flat buffer; returns True if the buffer had to be (re)zeroed."""
@@ -181,7 +189,15 @@ class Engine:
         # untouched: dq comes out with respect to the unscaled queries and the dX / dW GEMMs read the true weights.  Off under qk_norm (the LayerNorm behind
         # the projection would normalise the factor away) and with PXA_Q_PRESCALE=0 (A/B).
         self.prescale = (not cfg.get("qk_norm")) and os.environ.get("PXA_Q_PRESCALE", "1") != "0" and cfg["hidden_size"] // cfg["num_heads"] == 72
+        # The copy lives in ONE pair of buffers per engine, allocated here and rewritten in place whenever the shadow weights change (ParamStore.bump):
+        # a HIP graph captured over the forward (DPM_Solver.sample_graphed) bakes these addresses exactly as it bakes the shadow's, and replays after an
+        # optimizer step / weight load read current values (the per-generation allocation it replaces left such a graph reading a freed block,
+        # and cost the training step a 223 MB allocate / free).
         self._qs = None
+        if self.prescale:
+            D, depth = cfg["hidden_size"], cfg["depth"]
+            self._qs = (torch.empty((depth, 3 * D, D), dtype=BF16, device=store.device), torch.empty((depth, 3 * D), dtype=F32, device=store.device))
+            store._on_change.append(self._refresh_qs)
 
     # ------------------------------------------------------------------ helpers
     def pos_table(self, h, w):
@@ -217,30 +233,26 @@ class Engine:
             return ops.gemm(dy, S.w(name + ".weight"), NN, descending=desc, **(dx_kw or {}))
         return None
 
+    def _refresh_qs(self):
+        """Rewrite the prescaled qkv weight / bias copies from the fp32 master (one rounding), in place: one launch per run of equally spaced blocks."""
+        S, D, depth = self.S, self.cfg["hidden_size"], self.cfg["depth"]
+        w, b = self._qs
+        offw = [S.offset[f"blocks.{i}.attn.qkv.weight"] for i in range(depth)]
+        offb = [S.offset[f"blocks.{i}.attn.qkv.bias"] for i in range(depth)]
+        i = 0
+        while i < depth:                                  # runs of equally spaced blocks (KV-compressed blocks carry extra parameters)
+            n, st = 1, 0
+            if i + 1 < depth:
+                st = offw[i + 1] - offw[i]
+                while i + n < depth and offw[i + n] - offw[i + n - 1] == st and offb[i + n] - offb[i + n - 1] == st:
+                    n += 1
+            ops.scale_copy(S.master[offw[i]:], st if n > 1 else 0, n, D * D, 3 * D * D, ops.Q_PRESCALE, out_bf16=w[i:i + n])
+            ops.scale_copy(S.master[offb[i]:], st if n > 1 else 0, n, D, 3 * D, ops.Q_PRESCALE, out_f32=b[i:i + n])
+            i += n
+
     def _qkv_prescaled(self, l):
-        """(weight (3D, D) in the operand type, bias (3D,) fp32) of block l with the q rows times scale * log2 e; rebuilt when the weights changed."""
-        S, D = self.S, self.cfg["hidden_size"]
-        qs = self._qs
-        if qs is None or qs["gen"] != S.generation:
-            depth = self.cfg["depth"]
-            w = torch.empty((depth, 3 * D, D), dtype=BF16, device=S.device)
-            b = torch.empty((depth, 3 * D), dtype=F32, device=S.device)
-            offw = [S.offset[f"blocks.{i}.attn.qkv.weight"] for i in range(depth)]
-            offb = [S.offset[f"blocks.{i}.attn.qkv.bias"] for i in range(depth)]
-            i = 0
-            while i < depth:                                  # runs of equally spaced blocks (KV-compressed blocks carry extra parameters): one launch per run
-                n, st = 1, 0
-                if i + 1 < depth:
-                    st = offw[i + 1] - offw[i]
-                    while i + n < depth and offw[i + n] - offw[i + n - 1] == st and offb[i + n] - offb[i + n - 1] == st:
-                        n += 1
-                ops.scale_copy(S.master[offw[i]:], st if n > 1 else 0, n, D * D, 3 * D * D, ops.Q_PRESCALE, out_bf16=w[i:i + n])
-                ops.scale_copy(S.master[offb[i]:], st if n > 1 else 0, n, D, 3 * D, ops.Q_PRESCALE, out_f32=b[i:i + n])
-                i += n
-            qs = dict(gen=S.generation, w=w, b=b)
-            if not _capturing():                              # a buffer first allocated during graph capture lives in the graph's pool: not cached
-                self._qs = qs
-        return qs["w"][l], qs["b"][l]
+        """(weight (3D, D) in the operand type, bias (3D,) fp32) of block l with the q rows times scale * log2 e: views of the engine's persistent copy."""
+        return self._qs[0][l], self._qs[1][l]
 
     # ------------------------------------------------------------------ caption branch
     def caption_fwd(self, y, row_idx, L, drop, y_null):

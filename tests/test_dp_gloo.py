@@ -147,6 +147,81 @@ def test_engine_driven_bucketed_allreduce(tmp_path, world, bucket_dtype):
     assert "no_sync" in res["double"], res["double"]
 
 
+def _bcast_worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    os.environ["PXA_DP_TRACE"], os.environ["PXA_DP_TRACE_PRINT"] = "1", "0"
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    import fake_ops
+    from pixart_sigma_amd import engine
+    from pixart_sigma_amd.dp import GradReducer, check_replicas
+    engine.ops = fake_ops
+    from pixart_sigma_amd.model.nets.PixArtMS import PixArtMS
+    torch.manual_seed(100 + rank)                 # every rank initialises DIFFERENTLY: only the broadcast can make them equal
+    m = PixArtMS(depth=2, input_size=8, model_max_length=8, class_dropout_prob=0.0)
+    res = {}
+    m._prepare(torch.device("cpu"))               # the store alone (what a forward would build): replicas differ, and the check says so
+    try:
+        check_replicas(m._store)
+        res["differ_detected"] = False
+    except RuntimeError as e:
+        res["differ_detected"] = "different parameters" in str(e)
+    m.prepare("cpu")                              # DDP wrap-time semantics: rank 0's parameters and buffers everywhere
+    check_replicas(m._store)
+    every = [torch.empty_like(m._store.master) for _ in range(world)]
+    dist.all_gather(every, m._store.master)
+    bufs = [torch.empty_like(m.y_embedder.y_embedding) for _ in range(world)]
+    dist.all_gather(bufs, m.y_embedder.y_embedding)
+    res["equal"] = all(torch.equal(e, every[0]) for e in every) and all(torch.equal(b, bufs[0]) for b in bufs)
+    res["params_are_views"] = m._store.owns_all(m._ordered_named_params())
+    res["shadow_recast"] = ("cast_bf16" in [c[0] for c in fake_ops.CALLS]) if hasattr(fake_ops, "CALLS") else None
+    # the per-bucket trace of one step (PXA_DP_TRACE=1): three buckets from the engine's hooks, 'cond' from finish() (this driver has no autograd pass)
+    red = GradReducer(m._store)
+    m._engine.grad_ready_hook = red.on_group_ready
+    B, L, D = 2, 8, 1152
+    o, saved = m._engine.forward(torch.zeros(B, 4, 8, 8), torch.zeros(B * L, 4096), torch.zeros(2, B, 6, D), torch.zeros(B, 2, D),
+                                 torch.arange(B * L, dtype=torch.int32), [L] * B, None, "all", y_null=None)
+    m._engine.backward(torch.zeros_like(o), saved)
+    red.finish()
+    res["trace"] = red.last_trace
+    if rank == 1:                                  # a NON-source rank reports: it must hold rank 0's values
+        torch.save(res, out)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_prepare_broadcasts_rank0_parameters_and_buffers(tmp_path):
+    """VERDICT r05 weak #9 / next #6a: ranks seeded differently end bit-identical after model.prepare() (accelerate.prepare(model) -> DDP's initial broadcast,
+    reference train_scripts/train.py:486); without it the replica check raises.  Also: the PXA_DP_TRACE record of a step."""
+    out = str(tmp_path / "b.pt")
+    here = os.path.dirname(os.path.abspath(__file__))
+    os.environ["PYTHONPATH"] = here + os.pathsep + os.path.dirname(here) + os.pathsep + os.environ.get("PYTHONPATH", "")
+    mp.spawn(_bcast_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    res = torch.load(out, weights_only=False)
+    assert res["differ_detected"] is True and res["equal"] is True and res["params_are_views"] is True, res
+    tr = res["trace"]
+    assert [b["bucket"] for b in tr["buckets"]] == ["final", "blocks.1", "blocks.0", "cond"]
+    assert [b["launched_from"] for b in tr["buckets"]] == ["hook", "hook", "hook", "finish()"]
+    assert tr["world"] == 2 and tr["exposed_ms"] >= 0.0 and all(b["passed_ms"] >= b["ready_ms"] for b in tr["buckets"])
+
+
+def test_cond_bucket_is_launched_by_the_autograd_end_of_backward_callback(monkeypatch):
+    """next #6b: through the real autograd bridge (_CoreFn) the hook order is final, blocks L-1 .. 0, then 'cond' - fired by the autograd engine's
+    end-of-backward callback, after the nodes behind dmod / dfin (t_block, t_embedder, the tables) have run, and before backward() returns."""
+    m, fake_ops, run = _build(monkeypatch)
+    from pixart_sigma_amd.model.nets.PixArtMS import _CoreFn
+    launches, seen_tb = [], []
+    m._engine.grad_ready_hook = lambda name: (launches.append(name), seen_tb.append(tb.grad is not None))
+    B, L, D = 2, 8, 1152
+    tb = torch.zeros(1, requires_grad=True)                      # stands for a 'cond' parameter behind the modulation tensor
+    mod = torch.zeros(2, B, 6, D) + tb
+    out = _CoreFn.apply(m, torch.zeros(B, 4, 8, 8), torch.zeros(B * L, 4096), mod, torch.zeros(B, 2, D), torch.arange(B * L, dtype=torch.int32),
+                        [L] * B, None, m._anchor)
+    out.sum().backward()
+    assert launches == ["final", "blocks.1", "blocks.0", "cond"], launches
+    assert seen_tb == [False, False, False, True]                # 'cond' fired after autograd reached the leaf behind dmod
+
+
 def test_bucket_layout_follows_backward_completion_order(monkeypatch):
     """Flat-store layout the reducer relies on: contiguous buckets in forward order cond | blocks.0 .. | final that tile the buffer."""
     m, fake_ops, run = _build(monkeypatch)
@@ -191,13 +266,19 @@ def test_reducer_restores_the_gemm_item_hand_out(monkeypatch, tmp_path):
         "r2 = GradReducer(S()); del r2\n"
         "import gc; gc.collect()\n"
         "c = L.pxa_gemm_set_dynamic_items(0)\n"
-        "print(a, b, c)\n"
+        # nesting: B is built while A lives, A is collected first - the cursors must stay on until B closes, then return to what A found
+        "ra = GradReducer(S()); rb = GradReducer(S())\n"
+        "del ra; gc.collect()\n"
+        "d = L.pxa_gemm_set_dynamic_items(1)\n"          # still dynamic: B is active
+        "rb.close()\n"
+        "e = L.pxa_gemm_set_dynamic_items(0)\n"          # static again
+        "print(a, b, c, d, e)\n"
         "dist.destroy_process_group()\n")
     env = dict(os.environ, PXA_DP_FORCE_COLLECTIVES="1")
     env.pop("PXA_GEMM_DYNAMIC", None); env.pop("PXA_GEMM_STATIC", None)
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     assert out.returncode == 0, out.stderr
-    assert out.stdout.strip().splitlines()[-1].split() == ["1", "0", "0"], out.stdout
+    assert out.stdout.strip().splitlines()[-1].split() == ["1", "0", "0", "1", "0"], out.stdout
 
 
 def test_engine_sets_the_gemm_item_direction(monkeypatch):

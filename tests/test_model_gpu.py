@@ -273,6 +273,73 @@ def test_dpm_solver_sampling_matches_reference(golden):
     assert e < (SAMPLE_TOL if F16 else FWD_F32_TOL)
 
 
+# ---- round 6: the inference configs end to end at their configured step count (VERDICT r05 missing #2).  A sampler chain is not a contraction: the solver's
+# x_t carries every earlier evaluation's error, and the last steps divide by alpha_t ~ 1 after multiplying eps by sigma_t -> 0, so the error of x_t against the
+# reference chain grows over the first steps and settles.  Bounds below are the measured end-of-chain errors with ~1.5x headroom.
+CHAIN_TOL = {"dpms_xl2_512_s20": (4e-3, 4e-2), "dpms_xl2_2k_kv_s4": (2e-3, 2e-2)}      # (fp16, bf16)
+
+
+@pytest.mark.parametrize("name", ["dpms_xl2_512_s20", "dpms_xl2_2k_kv_s4"])
+def test_dpm_solver_chain_at_configured_steps_full_depth(golden, name):
+    """BASELINE configs[1] (XL/2 512px, 20-step DPM-Solver++(2M), CFG 4.5: scripts/inference.py:107-118, model/dpm_solver.py:1196-1241) and configs[3]
+    (2K, KV compression on blocks 14..27, 4 steps) at FULL DEPTH against the reference's own chain: x_t after EVERY solver step, error printed per step."""
+    from pixart_sigma_amd import DPMS
+    g = golden(name)
+    cfg, sd, inp, mask, m = _build(g)
+    gen = torch.Generator().manual_seed(g["null_seed"])
+    null_y = torch.randn(1, 1, g["inputs"]["L"], 4096, generator=gen).repeat(inp["x"].shape[0], 1, 1, 1).cuda()
+    solver = DPMS(m.forward_with_dpmsolver, condition=inp["y"].cuda(), uncondition=null_y, cfg_scale=4.5, model_kwargs=dict(data_info=None, mask=mask))
+    s, inter = solver.sample(inp["x"].cuda(), steps=g["steps"], order=2, skip_type="time_uniform", method="multistep", return_intermediate=True)
+    ref = g["intermediates"]
+    assert len(inter) == ref.shape[0] == g["steps"] + 1 and torch.equal(inter[0].cpu(), ref[0])
+    errs = [rel_l2(a.cpu(), b) for a, b in zip(inter, ref)]
+    print(f"\n[{name}] rel-L2 of x_t vs the reference chain, by solver step: " + " ".join(f"{i}:{e:.1e}" for i, e in enumerate(errs)))
+    e = rel_l2(s.cpu(), g["sample"])
+    tol = CHAIN_TOL[name][0 if F16 else 1]
+    record_parity(f"{name}: {g['steps']}-step DPM-Solver++ sample (depth 28)", e, tol)
+    record_parity(f"{name}: worst x_t over the chain (step {max(range(len(errs)), key=errs.__getitem__)})", max(errs), tol)
+    assert torch.isfinite(s).all() and max(errs) < tol, errs
+
+
+def test_dmd_one_step_generator_matches_reference(golden):
+    """BASELINE configs[4]: the PixArt-alpha-DMD generator step - eps at t = 400 without guidance, x0 = (x_t - sqrt(1 - abar_t) eps) / sqrt(abar_t)
+    (scripts/DMD/transformer_train/generate.py:20-41, scripts/diffusers_patches.py:448-449) - full depth, 512px, L = 120, ragged captions."""
+    g = golden("dmd_xl2_512_l120")
+    cfg, sd, inp, mask, m = _build(g)
+    x = inp["x"].cuda()
+    t = torch.full((x.shape[0],), g["t"], device="cuda", dtype=torch.long)
+    with torch.no_grad():
+        eps = m.forward_with_dpmsolver(x, t, inp["y"].cuda(), data_info=None, mask=mask)
+    abar = g["abar_t"]
+    x0 = (x - (1.0 - abar) ** 0.5 * eps) / abar ** 0.5                      # what tools/bench_dmd.py times in front of the VAE decode
+    e_eps, e_x0 = rel_l2(eps.cpu(), g["eps"]), rel_l2(x0.cpu(), g["x0"])
+    print(f"\nDMD one-step generator (depth 28, N = 1024, L = 120): eps rel-L2 {e_eps:.2e}, x0 rel-L2 {e_x0:.2e} vs the reference")
+    record_parity("dmd_xl2_512_l120: eps at t = 400", e_eps, FWD_DEEP_TOL); record_parity("dmd_xl2_512_l120: one-step x0", e_x0, FWD_DEEP_TOL)
+    assert e_eps < FWD_DEEP_TOL and e_x0 < FWD_DEEP_TOL
+
+
+def test_graphed_sampler_follows_weight_updates(golden):
+    """a captured sampling graph must read CURRENT weights after they change.  The q-prescaled copy of the qkv projection is a buffer derived from
+    the weights; it lives at a fixed address and is rewritten in place with the shadow (ParamStore.bump), so a replay after load_state_dict equals a fresh
+    eager sample - with the per-generation allocation it replaces the replay read the old block."""
+    from pixart_sigma_amd import DPMS
+    g = golden("dpms_d2")
+    cfg, sd, inp, mask, m = _build(g)
+    gen = torch.Generator().manual_seed(g["null_seed"])
+    null_y = torch.randn(1, 1, g["inputs"]["L"], 4096, generator=gen).repeat(inp["x"].shape[0], 1, 1, 1).cuda()
+    solver = DPMS(m.forward_with_dpmsolver, condition=inp["y"].cuda(), uncondition=null_y, cfg_scale=4.5, model_kwargs=dict(data_info=None, mask=mask))
+    kw = dict(steps=3, order=2, skip_type="time_uniform", method="multistep")
+    x = inp["x"].cuda()
+    g1 = solver.sample_graphed(x, **kw)
+    assert torch.equal(g1, solver.sample(x, **kw))
+    graph = solver._graph
+    qs_ptr = m._engine._qs[0].data_ptr()
+    m.load_state_dict({k: (v * 1.1 if ".attn.qkv." in k else v) for k, v in m.state_dict().items()})
+    g2 = solver.sample_graphed(x, **kw)
+    assert solver._graph is graph and m._engine._qs[0].data_ptr() == qs_ptr          # the same graph, the same derived buffer
+    assert torch.equal(g2, solver.sample(x, **kw)) and not torch.equal(g2, g1)
+
+
 def test_inference_text_cache_is_exact_and_invalidated(golden, monkeypatch):
     """engine.Engine._text_cache (round 3): the caption MLP and the 28 cross-attention kv_linear outputs depend on the text alone, so a sampler's
     steps reuse them.  Same sample bit for bit with the cache off; a different caption tensor, an in-place edit of the same one, and a training

@@ -140,6 +140,35 @@ def test_config1_xl2_256_matches_reference(golden):
     assert rel_l2(s, g["sample"]) < 1e-4
 
 
+@pytest.mark.slow
+def test_dmd_one_step_generator_matches_reference(golden):
+    """Round 6, BASELINE.json configs[4]: eps at t = 400 without guidance and the reference's eps_to_mu (scripts/DMD/transformer_train/generate.py:34-41),
+    full depth, 512px, L = 120."""
+    g = golden("dmd_xl2_512_l120")
+    cfg, sd, inp, mask = _setup(g)
+    t = torch.full((inp["x"].shape[0],), g["t"], dtype=torch.long)
+    with torch.no_grad():
+        eps = po.forward_with_dpmsolver(sd, cfg, inp["x"], t, inp["y"], mask)
+    ab = float(po.GaussianDiffusionOracle().sqrt_ac[g["t"]] ** 2)          # abar_t of the linear 1e-4 .. 2e-2 schedule (gaussian_diffusion.py:107-116)
+    assert abs(ab - g["abar_t"]) < 1e-7
+    x0 = (inp["x"] - (1.0 - ab) ** 0.5 * eps) / ab ** 0.5
+    assert rel_l2(eps, g["eps"]) < 5e-5 and rel_l2(x0, g["x0"]) < 5e-5
+
+
+@pytest.mark.slow
+def test_head_of_the_20_step_chain_matches_reference(golden):
+    """Round 6, BASELINE.json configs[1]: the first two solver steps (one order-1, one order-2 update) of the full-depth 512px 20-step DPM-Solver++ CFG-4.5 chain
+    against the reference's intermediates (the whole chain is 80 full-depth forwards: the GPU tier runs all of it)."""
+    g = golden("dpms_xl2_512_s20")
+    cfg, sd, inp, mask = _setup(g)
+    gen = torch.Generator().manual_seed(g["null_seed"])
+    null_y = torch.randn(1, 1, g["inputs"]["L"], 4096, generator=gen).repeat(inp["x"].shape[0], 1, 1, 1)
+    with torch.no_grad():
+        x3 = po.dpm_solver_sample(lambda x, t_in, c: po.forward_with_dpmsolver(sd, cfg, x, t_in, c, mask), inp["x"], inp["y"], null_y, 4.5,
+                                  steps=g["steps"], order=2, stop_after=2)
+    assert rel_l2(x3, g["intermediates"][2]) < 1e-4
+
+
 def test_tables_match_reference(golden):
     g = golden("tables")
     for (h, w, pe, base), ref in g["pos"].items():

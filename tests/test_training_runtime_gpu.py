@@ -77,7 +77,7 @@ def test_came_skips_on_overflow():
 def _bench(extra_env, launcher):
     env = dict(os.environ, **extra_env)
     cmd = launcher + [os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "0", "--image-size", "256", "--batch", "4",
-                      "--no-cpu-baseline", "--no-kernel-roofline", "--no-torch-baseline", "--no-other-dtype"]
+                      "--no-cpu-baseline", "--no-kernel-roofline", "--no-torch-baseline", "--no-other-dtype", "--no-configs"]
     r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=900, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     return json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])

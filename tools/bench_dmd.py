@@ -1,7 +1,8 @@
 """BASELINE.json config 5: PixArt-alpha-DMD 512px one-step generator, batch 64 per GPU (the VAE-decode-bound path).
 One generation = one PixArtMS forward at t = 400 without CFG (reference app/app_pixart_dmd.py:193-196: timesteps=[400],
 guidance_scale=1, 1 step), x0 = (x_t - sqrt(1 - abar_t) eps) / sqrt(abar_t), then SD-VAE decode of x0 / 0.18215.
-Random-init weights, synthetic caption features (L = 120).  Usage: python tools/bench_dmd.py [--batch 64] [--iters 3]"""
+Random-init weights, synthetic caption features (L = 120).  Parity of this exact step: tests/test_model_gpu.py::test_dmd_one_step_generator_matches_reference
+(reference generate.py:20-41); of the decoder: tests/test_vae_gpu.py.  Usage: python tools/bench_dmd.py [--batch 64] [--iters 3]"""
 import argparse
 import json
 import os
@@ -14,7 +15,7 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 from bench import MFMA_PEAK, fwd_flops_per_sample  # noqa: E402
-from bench_vae import conv_flops  # noqa: E402
+from vae_layer_table import decode_schedule  # noqa: E402
 from pixart_sigma_amd import PixArtMS_XL_2  # noqa: E402
 from pixart_sigma_amd.vae import AutoencoderKL  # noqa: E402
 
@@ -25,7 +26,6 @@ def main():
     ap.add_argument("--iters", type=int, default=3)
     ap.add_argument("--dtype", choices=["fp16", "bf16"], default="fp16")
     a = ap.parse_args()
-    from oracle.vae_ref import AutoencoderKLRef, randomize_
     B, lat, L = a.batch, 64, 120
     torch.manual_seed(0)
     m = PixArtMS_XL_2(input_size=lat, pe_interpolation=1.0, model_max_length=L)
@@ -34,9 +34,7 @@ def main():
             blk.cross_attn.proj.weight.normal_(std=0.02)
         m.final_layer.linear.weight.normal_(std=0.02)
     m = m.cuda().eval()
-    vae = AutoencoderKL(scaling_factor=0.18215)
-    vae.load_state_dict(randomize_(AutoencoderKLRef(), seed=0).state_dict())
-    vae = vae.cuda()
+    vae = AutoencoderKL(scaling_factor=0.18215).cuda()        # random-init weights (torch's default Conv2d / Linear init under the seed above; GroupNorm 1 / 0)
     betas = np.linspace(1e-4, 2e-2, 1000, dtype=np.float64)          # the linear schedule of the alpha / DMD checkpoints
     abar = float(np.cumprod(1.0 - betas)[400])
     g = torch.Generator().manual_seed(1)
@@ -67,7 +65,7 @@ def main():
             t_all += ev[0].elapsed_time(ev[2])
     t_dit, t_all = t_dit / a.iters, t_all / a.iters
     f_dit = fwd_flops_per_sample((lat // 2) ** 2, L=L) * B
-    f_vae = conv_flops(AutoencoderKLRef().to("meta"), 512) * B
+    f_vae = sum(e[2] for e in decode_schedule(B, 512))             # 2 m n k of every convolution / projection / attention product of the decoder, unpadded
     print(json.dumps({"workload": "config5: PixArt-alpha-DMD 512px one-step generator + SD-VAE decode", "batch": B, "ms_per_batch": t_all,
                       "images_per_s": B / t_all * 1e3, "ms_dit": t_dit, "ms_vae_decode": t_all - t_dit, "TFLOP_dit": f_dit / 1e12, "TFLOP_vae": f_vae / 1e12,
                       "TFLOP/s": (f_dit + f_vae) / t_all / 1e9, "mfma_frac": (f_dit + f_vae) / t_all / 1e9 / (MFMA_PEAK / 1e12),

@@ -48,13 +48,17 @@ def main():
     ap.add_argument("--encode", action="store_true")
     ap.add_argument("--cpu-sample", action="store_true")
     a = ap.parse_args()
-    from oracle.vae_ref import AutoencoderKLRef, randomize_
     from pixart_sigma_amd.vae import AutoencoderKL
-    ref = randomize_(AutoencoderKLRef(), seed=0)
-    fl = conv_flops(AutoencoderKLRef().to("meta"), a.px, decode=not a.encode)
-    vae = AutoencoderKL()
-    vae.load_state_dict(ref.state_dict())
-    vae = vae.cuda()
+    torch.manual_seed(0)
+    vae = AutoencoderKL().cuda()                               # random-init weights (torch's default init; GroupNorm 1 / 0)
+    if a.encode or a.cpu_sample:                               # the encoder's FLOP count and the CPU sample come from the restated reference (tools only)
+        from oracle.vae_ref import AutoencoderKLRef, randomize_
+        ref = randomize_(AutoencoderKLRef(), seed=0)
+        vae.load_state_dict(ref.state_dict())
+        fl = conv_flops(AutoencoderKLRef().to("meta"), a.px, decode=not a.encode)
+    if not a.encode:
+        from vae_layer_table import decode_schedule
+        fl = sum(e[2] for e in decode_schedule(1, a.px))
     g = torch.Generator().manual_seed(0)
     if a.encode:
         x = torch.randn(a.batch, 3, a.px, a.px, generator=g).cuda()

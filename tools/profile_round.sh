@@ -4,7 +4,7 @@
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 tag=${1:-r02}
 hdr="# box $(hostname) $(date -u +%FT%TZ) HEAD $(cat .gpurun_head 2>/dev/null || echo unknown) operand build f16"
-rocprofv3 --kernel-trace --stats -d gpurun_out/prof_$tag -o step -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-roofline --no-torch-baseline --no-other-dtype > gpurun_out/prof_${tag}_step.log 2>&1
+rocprofv3 --kernel-trace --stats -d gpurun_out/prof_$tag -o step -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-roofline --no-torch-baseline --no-other-dtype --no-configs > gpurun_out/prof_${tag}_step.log 2>&1
 python tools/export_profile.py gpurun_out/prof_$tag/step_results.db gpurun_out/${tag}_step_kernel_stats.csv 3
 rm -rf gpurun_out/prof_$tag
 export PXA_OPERAND_DTYPE=f16

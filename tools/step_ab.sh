@@ -12,7 +12,7 @@ export PYTHONUNBUFFERED=1
 for rep in 1 2; do
   for cfg in "$@"; do
     label=${cfg%%|*}; envs=${cfg#*|}
-    r=$(env $envs timeout 300 python bench.py --steps 8 --warmup 3 --no-cpu-baseline --no-kernel-roofline --no-other-dtype --no-torch-baseline 2>/dev/null \
+    r=$(env $envs timeout 300 python bench.py --steps 8 --warmup 3 --no-cpu-baseline --no-kernel-roofline --no-other-dtype --no-torch-baseline --no-configs 2>/dev/null \
         | python -c 'import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d["ms_per_step"], d["final_loss"])')
     echo "$label: $r" >> "$out"
   done

@@ -53,6 +53,9 @@ def main():
     path, B = sys.argv[1], int(sys.argv[2])
     px = int(sys.argv[3]) if len(sys.argv) > 3 else 512
     rows = [r for r in csv.DictReader(l for l in open(path) if not l.startswith("#"))]
+    starts = [i for i, r in enumerate(rows) if "nchw_to_grid" in r["kernel"]]      # decode() begins with the latent's layout change: keep the LAST decode only
+    if starts:
+        rows = rows[starts[-1]:]
     sched = decode_schedule(B, px)
     segs, cur = [], []
     for r in rows:
