@@ -30,7 +30,15 @@ sys.path.insert(0, ROOT)
 
 D, H, DFF, DEPTH, LTXT = 1152, 16, 4608, 28, 300
 MFMA_PEAK = 2.5e15   # dense bf16, MI355X (MI355X_MICROARCH.md)
-PMC_FILES = ["profiles/r5final_pmc_attention.json", "profiles/r5_07_pmc_attention.json", "profiles/r4final_pmc_attention.json", "profiles/r4_18_pmc_attention.json", "profiles/r03s_pmc_attention.json", "profiles/r03l_pmc_attention.json", "profiles/r03c_pmc_attention.json", "profiles/r02f_pmc_attention.json", "profiles/r02_pmc_attention.json"]   # newest first (tools/pmc_query.py --json)
+def _pmc_files():
+    """profiles/*_pmc_attention.json, newest session first (tools/pmc_query.py --json; name order: round, then `final` over numbered / lettered sessions)."""
+    import glob
+    import re
+
+    def key(path):
+        m = re.match(r"r0?(\d+)(final|[a-z]?)_?(\d*)", os.path.basename(path))
+        return (int(m.group(1)), 1 if m.group(2) == "final" else 0, m.group(2), int(m.group(3) or 0)) if m else (0, 0, "", 0)
+    return sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_attention.json")), key=key, reverse=True)
 DOMINANT = "attn_bwd_dkv4_kernel"     # the step's largest kernel by total time (profiles/r4final_step_kernel_stats.csv: 28 self-attention launches; round 4: the
                                       # one-wave-per-SIMD dK/dV kernel, 256 keys per workgroup - attn_bwd_dkv2_kernel<1> until round 3; its 16-row variant dkv5 is
                                       # faster alone and slower in the step, profiles/r4_34_step_ab_attention.txt)
@@ -40,15 +48,19 @@ def pmc_traffic(kernel_substr, grid):
     """HBM bytes per launch of a kernel from the committed PMC passes (rocprofv3 cannot run inside the benchmark): separate --pmc
     passes for FETCH_SIZE / WRITE_SIZE (KB per launch); FETCH_SIZE doubled per the gfx950 note of MI355X_MICROARCH.md.
     Returns (bytes | None, source)."""
-    for rel in PMC_FILES:
-        path = os.path.join(ROOT, rel)
-        if not os.path.exists(path):
-            continue
+    for path in _pmc_files():
+        rel = os.path.relpath(path, ROOT)
         with open(path) as f:
             rows = json.load(f)["kernels"]
+        head = ""
+        txt = path[:-5] + ".txt"                       # the session's text artefact starts with "# box .. HEAD .. operand build .."
+        if os.path.exists(txt):
+            with open(txt) as f:
+                first = f.readline().strip()
+            head = " [" + first.lstrip("# ") + "]" if first.startswith("#") else ""
         for r in rows:
             if kernel_substr in r["kernel"] and r.get("grid") in grid and "FETCH_SIZE" in r["counters"] and "WRITE_SIZE" in r["counters"]:
-                return 2 * r["counters"]["FETCH_SIZE"] * 1e3 + r["counters"]["WRITE_SIZE"] * 1e3, f"{rel}: 2 x FETCH_SIZE (gfx950 correction) + WRITE_SIZE, separate --pmc passes, bytes per launch"
+                return 2 * r["counters"]["FETCH_SIZE"] * 1e3 + r["counters"]["WRITE_SIZE"] * 1e3, f"{rel}{head}: 2 x FETCH_SIZE (gfx950 correction) + WRITE_SIZE, separate --pmc passes, bytes per launch (a committed file, not measured by this run)"
     return None, "no PMC file for this kernel / grid under profiles/"
 
 

@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-#define PXA_ABI_VERSION 8
+#define PXA_ABI_VERSION 9
 /* Kernels that fuse a bias-gradient column sum add into one of PXA_COLSUM_SLOTS partial rows ([slot][stride] fp32, caller-zeroed),
  * chosen per sample / row tile, so no address sees thousands of atomics; pxa_colsum_reduce folds the partials into the gradient. */
 #define PXA_COLSUM_SLOTS 16
@@ -300,6 +300,12 @@ int pxa_vae_softmax_rows(const float* s, long ld, void* p_bf16, long ldp, int ro
 /* fp32 NCHW (B, C, H, W) image / latent -> bf16 grid scaled by mul, channels C..grid.C-1 zero; and back (first C channels). */
 int pxa_vae_nchw_to_grid(const float* img, int C, float mul, const pxa_grid* y, hipStream_t stream);
 int pxa_vae_grid_to_nchw(const pxa_grid* x, int C, float* img, hipStream_t stream);
+/* Direct 3x3 stride-1 pad-1 convolution of act(norm(x)) to Cout <= 4 channels, written as an fp32 NCHW image (B, Cout, H, W): the decoder's conv_out
+ * (diffusers AutoencoderKL: decoder.conv_norm_out -> SiLU -> decoder.conv_out, 128 -> 3; call site of the whole decode: reference scripts/inference.py:136).
+ * One pass over x: no padded copy, no patch matrix, no crop / permute.  w_taps: [9][Cout][C] in the library's operand type (tap = ky * 3 + kx);
+ * norm arguments as pxa_vae_gn_apply (mean == NULL: none); x.C a multiple of 64. */
+int pxa_vae_conv3x3_small_out(const pxa_grid* x, const float* mean, const float* rstd, const float* gamma, const float* beta, int groups, int silu,
+                              const void* w_taps, const float* bias, int Cout, float* img, hipStream_t stream);
 
 /* ---------------------------------------------------------------------------------------------- conditioning linears (fp32)
  * y = x W^T + b and its backward for the O(batch) conditioning path: TimestepEmbedder / SizeEmbedder MLPs and t_block (PixArt_blocks.py:267-344,

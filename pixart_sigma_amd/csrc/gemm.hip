@@ -562,7 +562,14 @@ __device__ __forceinline__ bf16x8 frag_p(const char* lds, int rbase, int ks, int
   }
 }
 template <int V> struct IntC { static constexpr int value = V; };
-template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+#ifndef GEMM_WAIT_ALL
+#define GEMM_WAIT_ALL 0     // debug build: every COUNTED vmcnt wait of this file becomes vmcnt(0).  The counts below mirror issue orders by hand; a count that
+#endif                      // over-estimates lets registers / LDS be read before they land.  tests/test_kernels_gpu.py::test_gemm_counted_waits_match_full_waits builds
+                            // this variant and demands bit-identical outputs from every epilogue flavour.
+template <int N> __device__ __forceinline__ void wait_vmcnt() {
+  if constexpr (GEMM_WAIT_ALL != 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
 // A value the compiler must treat as new at this point: per-lane constants derived from it are RECOMPUTED where they are used (a few VALU per item)
 // instead of being hoisted above the item loop - where, at the 256-register ceiling of the main loop, they were spilled and came back through
 // `scratch_load; s_waitcnt vmcnt(0)` pairs that also drained the epilogue's own stores and the next item's DMA (round 3: 15 registers / 64 B of
@@ -866,41 +873,53 @@ __global__ __launch_bounds__(512) void gemm_pers_kernel(GemmParams p) {
   const long stepA = A_KC ? BKT : (long)BKT * p.lda, stepB = B_KC ? BKT : (long)BKT * p.ldb;
   int s_lo = 0, s_hi = 0;                              // ring slots of the next first-half / second-half issue
   bool vt_pf = false;                                  // paired flag of the item whose DMA is being issued
+  int dma_count = 0;                                   // LDS-DMA instructions this wave has issued since the last prefetch() began (wave-uniform; what the epilogue's
+                                                       // counted waits must allow in flight - counted where they are issued, not re-derived: ADVICE r05)
   auto piece = [&](int i, int slot) {
+    dma_count++;
     lds_dma16(pp[i], smem + slot * UNIT + dof[i]);
 #if !(GEMM_ABL & 1)
     pp[i] += st[i];
 #endif
   };
-  int seg_left = 0;                                    // SEG: k elements left in the A segment the next first-half issue reads
-  int tap_kx = 0, tap_ky = 0, tap_half = 0;            // SEG, tap-interleaved order: position of the next first-half issue
-  auto issue_lo = [&]() {
+  // SEG: the A pieces' walk over the segments / taps.  State 0 belongs to pieces 0, 1 (issued by issue_lo), state 1 to pieces 2, 3 of a PAIRED item (its
+  // other two A pieces, issued by issue_hi half a unit later): the same walk, one issue apart.  (Scalars and references, not arrays indexed by a lambda
+  // parameter: with those the compiler kept pp[] / dof[] in SCRATCH - 768 bytes of private segment, the LDS offset in a VGPR, the kernel 16x slower.)
+  int seg_left0 = 0, seg_left1 = 0;                    // k elements left in the A segment the next issue reads
+  int tap_kx0 = 0, tap_ky0 = 0, tap_half0 = 0, tap_kx1 = 0, tap_ky1 = 0, tap_half1 = 0;   // tap-interleaved order: position of the next issue
+  // (the walk is written out in both issue lambdas, and both are always_inline: as one more lambda called from the two, the inliner gave up on the PAIR && SEG
+  // instances and the closure - kernel arguments, item state, pp[] / dof[] - went to scratch: 816 bytes of private segment, the kernel 16x slower)
+#define PXA_SEG_ADVANCE(seg_left, tap_kx, tap_ky, tap_half, pa, pb)                                                          \
+  do {                                                                                                                       \
+    if (p.k_tap) {                                     /* tap-interleaved order: 64 channels = two k-units per tap */        \
+      if (tap_half) {                                                                                                        \
+        long adj;                                                                                                            \
+        if (tap_kx < 2) { adj = p.k_tap - 64; tap_kx++; }                                                                    \
+        else if (tap_ky < 2) { adj = p.tap_s - 2L * p.k_tap - 64; tap_kx = 0; tap_ky++; }                                    \
+        else { adj = -2L * p.tap_s - 2L * p.k_tap; tap_kx = 0; tap_ky = 0; }                                                 \
+        pa += adj; pb += adj;                                                                                                \
+      }                                                                                                                      \
+      tap_half ^= 1;                                                                                                         \
+    } else {                                                                                                                 \
+      seg_left -= BKT;                                                                                                       \
+      if (seg_left == 0) { pa += p.seg_jump; pb += p.seg_jump; seg_left = p.k_seg; }                                         \
+    }                                                                                                                        \
+  } while (0)
+  auto issue_lo = [&]() __attribute__((always_inline)) {
 #pragma unroll
     for (int i = 0; i < H1; i++) piece(i, s_lo);
-    if (SEG) {                                         // pieces 0 and 1 are the A pieces of every SEG instantiation (no pairing)
-      if (p.k_tap) {                                   // tap-interleaved order: 64 channels = two k-units per tap
-        if (tap_half) {
-          long adj;
-          if (tap_kx < 2) { adj = p.k_tap - 64; tap_kx++; }
-          else if (tap_ky < 2) { adj = p.tap_s - 2L * p.k_tap - 64; tap_kx = 0; tap_ky++; }
-          else { adj = -2L * p.tap_s - 2L * p.k_tap; tap_kx = 0; tap_ky = 0; }
-          pp[0] += adj; pp[1] += adj;
-        }
-        tap_half ^= 1;
-      } else {
-        seg_left -= BKT;
-        if (seg_left == 0) { pp[0] += p.seg_jump; pp[1] += p.seg_jump; seg_left = p.k_seg; }
-      }
-    }
+    if (SEG) PXA_SEG_ADVANCE(seg_left0, tap_kx0, tap_ky0, tap_half0, pp[0], pp[1]);      // pieces 0 and 1 are A pieces of every SEG item
     s_lo = (s_lo + 1) & 3;
   };
-  auto issue_hi = [&]() {
+  auto issue_hi = [&]() __attribute__((always_inline)) {
     piece(2, s_hi);
     if (!(HALF && vt_pf)) piece(3, s_hi);
     if (PAIR && vt_pf) piece(4, s_hi);
+    if (SEG && PAIR) { if (vt_pf) PXA_SEG_ADVANCE(seg_left1, tap_kx1, tap_ky1, tap_half1, pp[2], pp[3]); }   // paired item: pieces 2 and 3 are its other two A pieces
     s_hi = (s_hi + 1) & 3;
   };
-  auto prefetch = [&]() {                              // units 0, 1 and the first half of unit 2 of the item at (m0a, m0b, n0, z_)
+#undef PXA_SEG_ADVANCE
+  auto prefetch = [&]() __attribute__((always_inline)) {   // units 0, 1 and the first half of unit 2 of the item at (m0a, m0b, n0, z_)
     vt_pf = (RM != 0) && vt;
     const long k0 = (long)z_ * p.k_per_split;
     const bool vq = PAIR && vt, hq = HALF && vt;
@@ -919,7 +938,8 @@ __global__ __launch_bounds__(512) void gemm_pers_kernel(GemmParams p) {
       dof[i] = (is_a ? 0 : (vq ? 32768 : 16384)) + pid * 1024;
     }
     s_lo = s_hi = 0;
-    if (SEG) { seg_left = p.k_seg; tap_kx = tap_ky = tap_half = 0; }
+    dma_count = 0;
+    if (SEG) { seg_left0 = seg_left1 = p.k_seg; tap_kx0 = tap_kx1 = tap_ky0 = tap_ky1 = tap_half0 = tap_half1 = 0; }
     issue_lo(); issue_hi(); issue_lo(); issue_hi();
     if (nk_pf > 2) { issue_lo(); if (PH16) issue_hi(); }      // PH16: three whole units ahead; else 2.5
   };
@@ -1184,10 +1204,9 @@ __global__ __launch_bounds__(512) void gemm_pers_kernel(GemmParams p) {
           prefetch();
         }
       }
-      if (more) {
-        const int hi_ops = 1 + ((HALF && vt_pf) ? 0 : 1) + ((PAIR && vt_pf) ? 1 : 0);
-        pf_ops = 2 * (H1 + hi_ops) + (nk_pf > 2 ? H1 + (PH16 ? hi_ops : 0) : 0);
-      }
+      if (more) pf_ops = dma_count;                    // = 2 (H1 + hi_ops) + (nk_pf > 2 ? H1 + (PH16 ? hi_ops : 0) : 0), hi_ops = 2 (3 paired, 1 half): counted in piece().
+                                                       // NOT in the count: wave 0 / lane 0's cursor atomic (fetch_issue, issued BEHIND the prefetch): one more operation
+                                                       // in flight for that wave only, so its waits are conservative by one - never the other way.
     };
     const int le = opaque<LAYOUT == 1 || (EPI >= 2 && EPI != 7) || (GEMM_EPI_EARLY && RM == 2)>(lane);          // NN: epilogue-only lane constants are rebuilt per item (see opaque())
     const int srow = le & 31;
@@ -1544,7 +1563,7 @@ static inline int pers_tiles(int M, int N, int rm) {
 }
 template <int LAYOUT, int EPI, int RM = 0, bool SEG = false>
 int launch_pers(GemmParams p, int split, hipStream_t s) {
-  static_assert(!SEG || (LAYOUT == 0 && RM != 1), "segmented A: layout NT without pairing");
+  static_assert(!SEG || LAYOUT == 0, "segmented A: layout NT");
   p.split = split;
   constexpr int LDSP = 4 * 40960;                      // the ring (4 x 40 KiB slots) = the CU's whole 160 KiB: one workgroup per CU
   static bool attr_set_pp = false;
@@ -1631,12 +1650,18 @@ int launch(GemmParams p, int split, hipStream_t s) {
     if constexpr (LAYOUT == 0) {
       static const bool no_pers_seg = getenv("PXA_GEMM_NO_PERSISTENT") != nullptr;
       if (p.out && !p.outf && (p.act == 0 || p.act == 5) && p.M >= 1024 && p.N >= 128 && p.N % 128 == 0 && p.k_seg % 32 == 0 && !no_pers_seg) {
+        // Remainder columns of 128 (the VAE's 128-channel layers: N = 128 is ONLY a remainder column).  Round 6: PAIRED items - the remainder columns of two
+        // consecutive m-tiles as one 512 x 128 item on full 128 x 64 wave tiles - instead of HALF items (256 x 128 on 64 x 64 wave tiles: half the MFMAs per
+        // barrier pair, 500-640 TFLOP/s on the 512 x 512 x 128-channel layers of the decoder, profiles/r6_01_vae_layer_table.txt).  The token GEMMs keep HALF
+        // items: there the remainder column is a ninth of the work and equal rounds matter more (see RM above).  PXA_GEMM_SEG_HALF=1: the round-5 choice (A/B).
+        static const bool seg_half = getenv("PXA_GEMM_SEG_HALF") != nullptr;
+        const bool hc = pers_halfcol(p.N), pair = hc && !seg_half && p.M >= 512;
         if (p.gn_part) {                                 // + GroupNorm statistics of the output
-          if (p.act == 5) return pers_halfcol(p.N) ? launch_pers<0, 6, 2, true>(p, 1, s) : launch_pers<0, 6, 0, true>(p, 1, s);
-          return pers_halfcol(p.N) ? launch_pers<0, 5, 2, true>(p, 1, s) : launch_pers<0, 5, 0, true>(p, 1, s);
+          if (p.act == 5) return pair ? launch_pers<0, 6, 1, true>(p, 1, s) : hc ? launch_pers<0, 6, 2, true>(p, 1, s) : launch_pers<0, 6, 0, true>(p, 1, s);
+          return pair ? launch_pers<0, 5, 1, true>(p, 1, s) : hc ? launch_pers<0, 5, 2, true>(p, 1, s) : launch_pers<0, 5, 0, true>(p, 1, s);
         }
-        if (p.act == 5) return pers_halfcol(p.N) ? launch_pers<0, 4, 2, true>(p, 1, s) : launch_pers<0, 4, 0, true>(p, 1, s);   // conv + residual
-        return pers_halfcol(p.N) ? launch_pers<0, 0, 2, true>(p, 1, s) : launch_pers<0, 0, 0, true>(p, 1, s);
+        if (p.act == 5) return pair ? launch_pers<0, 4, 1, true>(p, 1, s) : hc ? launch_pers<0, 4, 2, true>(p, 1, s) : launch_pers<0, 4, 0, true>(p, 1, s);   // conv + residual
+        return pair ? launch_pers<0, 0, 1, true>(p, 1, s) : hc ? launch_pers<0, 0, 2, true>(p, 1, s) : launch_pers<0, 0, 0, true>(p, 1, s);
       }
       if (p.gn_part) { pxa_set_error("pxa_gemm: gn_part needs the persistent implicit-convolution path (bf16 output, M >= 1024, N a multiple of 128)"); return -1; }
       if (p.out && !p.outf && p.act == 0) return launch_glds_e<0, 128, 128, 2, 2, 1, true>(p, 1, s);

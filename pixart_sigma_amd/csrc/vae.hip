@@ -142,6 +142,62 @@ __global__ __launch_bounds__(256) void im2col3x3_kernel(Grid x, Norm nm, int str
   *reinterpret_cast<uint4*>(col + (((long)b * Ho + yo) * Wo * 9 * CV + i) * 8) = v;
 }
 
+// ---- 3x3 stride-1 pad-1 convolution of act(norm(x)) down to a FEW output channels (decoder conv_out: 128 -> 3), fp32 NCHW image out.
+// As an implicit GEMM this layer is a 256 x 128 tile with 3 live columns in front of a full-size GroupNorm-apply pass and behind a crop / permute:
+// 6.65 ms of the 206 ms decode at 0.08 of the HBM roofline (profiles/r6_01_vae_layer_table.txt).  Here it is what it is - one HBM read of the input:
+// a workgroup owns an 8 x 32 pixel tile; per 64-channel chunk it stages the (8+2) x (32+2) halo of act(norm(x)), rounded to the operand type exactly as the
+// padded grid of the GEMM path holds it, in LDS (pixel stride 144 B: the 16 lanes of a ds_read_b128 group land on 16 distinct 4-bank groups), and every
+// thread accumulates its pixel's CO outputs with packed dot products (v_dot2_f32_*; the weights are wave-uniform -> scalar loads through the constant cache).
+// Outside the image the staged value is ZERO (the convolution pads the activated tensor), not act(norm(0)).
+constexpr int SO_TH = 8, SO_TW = 32, SO_CC = 64, SO_PIX = (SO_CC + 8) * 2;      // 144 bytes per staged pixel
+template <int CO>
+__global__ __launch_bounds__(256) void conv3x3_small_out_kernel(Grid x, Norm nm, const uint32_t* __restrict__ wts, const float* __restrict__ bias,
+                                                                float* __restrict__ img) {
+  __shared__ __attribute__((aligned(16))) char tile[(SO_TH + 2) * (SO_TW + 2) * SO_PIX];
+  const int tid = threadIdx.x, px = tid % SO_TW, py = tid / SO_TW;
+  const int x0 = blockIdx.x * SO_TW, y0 = blockIdx.y * SO_TH, b = blockIdx.z;
+  const int C2 = x.C / 2;                              // weights: [tap][co][C / 2] packed channel pairs
+  float acc[CO];
+#pragma unroll
+  for (int co = 0; co < CO; co++) acc[co] = 0.f;
+  for (int c0 = 0; c0 < x.C; c0 += SO_CC) {
+    if (c0) __syncthreads();                           // everybody is done with the previous chunk's tile
+    constexpr int PIECES = (SO_TH + 2) * (SO_TW + 2) * (SO_CC / 8);
+    for (int pi = tid; pi < PIECES; pi += 256) {
+      const int pix = pi / (SO_CC / 8), ch = pi % (SO_CC / 8), ty = pix / (SO_TW + 2), tx = pix % (SO_TW + 2);
+      const int yy = y0 + ty - 1, xx = x0 + tx - 1;
+      uint4 v = make_uint4(0u, 0u, 0u, 0u);
+      if (yy >= 0 && yy < x.H && xx >= 0 && xx < x.W) {
+        float f[8];
+        unpack_bf16x8(*reinterpret_cast<const uint4*>(x.at(b, yy, xx) + c0 + ch * 8), f);
+        nm.apply(f, b, c0 + ch * 8);
+        v = pack8(f);
+      }
+      *reinterpret_cast<uint4*>(tile + pix * SO_PIX + ch * 16) = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int tap = 0; tap < 9; tap++) {
+      const char* src = tile + ((py + tap / 3) * (SO_TW + 2) + px + tap % 3) * SO_PIX;
+      const uint32_t* w = wts + (size_t)tap * CO * C2 + c0 / 2;
+#pragma unroll
+      for (int j = 0; j < SO_CC / 8; j++) {
+        const uint4 v = *reinterpret_cast<const uint4*>(src + j * 16);
+#pragma unroll
+        for (int co = 0; co < CO; co++) {
+          const uint4 wv = *reinterpret_cast<const uint4*>(w + co * C2 + j * 4);      // wave-uniform address
+          acc[co] = dot2_acc(v.w, wv.w, dot2_acc(v.z, wv.z, dot2_acc(v.y, wv.y, dot2_acc(v.x, wv.x, acc[co]))));
+        }
+      }
+    }
+  }
+  const int yo = y0 + py, xo = x0 + px;
+  if (yo < x.H && xo < x.W) {
+#pragma unroll
+    for (int co = 0; co < CO; co++) img[(((long)b * CO + co) * x.H + yo) * x.W + xo] = acc[co] + (bias ? bias[co] : 0.f);
+  }
+}
+
 __global__ __launch_bounds__(256) void add_kernel(Grid a, Grid bb, Grid o) {
   const int i = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y, b = blockIdx.z;   // grid: (chunks of one row, row, sample)
   if (i >= a.W * (a.C / 8)) return;
@@ -322,6 +378,26 @@ extern "C" int pxa_vae_grid_to_nchw(const pxa_grid* x, int C, float* img, hipStr
   PXA_CHECK(img && C > 0 && C <= x->C, "pxa_vae_grid_to_nchw: bad channel count %d (grid has %d)", C, x->C);
   PXA_CHECK(x->H <= 65535 && x->B <= 65535, "pxa_vae_grid_to_nchw: grid too large");
   hipLaunchKernelGGL(grid_to_nchw_kernel, dim3((x->W + 255) / 256, x->H, x->B), dim3(256), 0, stream, to_grid(x), C, img);
+  PXA_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int pxa_vae_conv3x3_small_out(const pxa_grid* x, const float* mean, const float* rstd, const float* gamma, const float* beta, int groups, int silu,
+                                         const void* w_taps, const float* bias, int Cout, float* img, hipStream_t stream) {
+  if (int rc = check_grid(x, "pxa_vae_conv3x3_small_out")) return rc;
+  PXA_CHECK(w_taps && img && Cout >= 1 && Cout <= 4, "pxa_vae_conv3x3_small_out: Cout=%d must be 1..4", Cout);
+  PXA_CHECK(x->C % SO_CC == 0, "pxa_vae_conv3x3_small_out: C=%d must be a multiple of %d", x->C, SO_CC);
+  Norm nm;
+  if (int rc = make_norm(nm, mean, rstd, gamma, beta, x->C, groups, silu, "pxa_vae_conv3x3_small_out")) return rc;
+  PXA_CHECK(x->H <= 65535 * SO_TH && x->B <= 65535, "pxa_vae_conv3x3_small_out: grid too large");
+  const dim3 grid((x->W + SO_TW - 1) / SO_TW, (x->H + SO_TH - 1) / SO_TH, x->B);
+  const uint32_t* w = (const uint32_t*)w_taps;
+  switch (Cout) {
+    case 1: hipLaunchKernelGGL(conv3x3_small_out_kernel<1>, grid, dim3(256), 0, stream, to_grid(x), nm, w, bias, img); break;
+    case 2: hipLaunchKernelGGL(conv3x3_small_out_kernel<2>, grid, dim3(256), 0, stream, to_grid(x), nm, w, bias, img); break;
+    case 3: hipLaunchKernelGGL(conv3x3_small_out_kernel<3>, grid, dim3(256), 0, stream, to_grid(x), nm, w, bias, img); break;
+    default: hipLaunchKernelGGL(conv3x3_small_out_kernel<4>, grid, dim3(256), 0, stream, to_grid(x), nm, w, bias, img); break;
+  }
   PXA_LAUNCH_CHECK();
   return 0;
 }

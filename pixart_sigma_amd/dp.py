@@ -52,6 +52,8 @@ def check_replicas(store, group=None):
         return True
     m = store.master.double()
     mine = torch.stack([m.sum(), (m * m).sum()])
+    if dist.get_backend(group) == "gloo":          # (gloo moves GPU tensors through the host for broadcast / all-reduce only)
+        mine = mine.cpu()
     every = [torch.empty_like(mine) for _ in range(world)]
     dist.all_gather(every, mine, group=group)
     if not all(torch.equal(e, every[0]) for e in every):

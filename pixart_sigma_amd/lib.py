@@ -13,7 +13,7 @@ OPERAND = os.environ.get("PXA_OPERAND_DTYPE", "bf16").lower()
 assert OPERAND in ("bf16", "f16"), f"PXA_OPERAND_DTYPE must be bf16 or f16, got {OPERAND!r}"
 OPERAND_DTYPE = torch.float16 if OPERAND == "f16" else torch.bfloat16
 LIB_PATH = os.environ.get("PXA_LIB_PATH") or os.path.join(_HERE, "libpixart_hip_f16.so" if OPERAND == "f16" else "libpixart_hip.so")   # env override: A/B kernel builds
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 c_void_p, c_int, c_long, c_float = C.c_void_p, C.c_int, C.c_long, C.c_float
 
@@ -110,6 +110,7 @@ SIGNATURES = {
     "pxa_vae_softmax_rows": [_P, _L, _P, _L, _I, _I, _F, _P],
     "pxa_vae_nchw_to_grid": [_P, _I, _F, _G, _P],
     "pxa_vae_grid_to_nchw": [_G, _I, _P, _P],
+    "pxa_vae_conv3x3_small_out": [_G, _P, _P, _P, _P, _I, _I, _P, _P, _I, _P, _P],
 }
 OTHER_SYMBOLS = ["pxa_last_error", "pxa_abi_version", "pxa_operand_dtype", "pxa_device_info", "pxa_gemm_splitk_ws_elems", "pxa_came_scratch_elems", "pxa_attn_bwd_stats_bytes", "pxa_gemm_set_dynamic_items",
                  "pxa_mfma_rate_probe_bytes", "pxa_mfma_rate_probe"]

@@ -431,6 +431,16 @@ def vae_nchw_to_grid(img, y, mul=1.0):
     return y
 
 
+def vae_conv3x3_small_out(x, w_taps, bias, Cout, norm=None, silu=False):
+    """fp32 NCHW image (B, Cout, H, W) = conv3x3(act(norm(x))) for Cout <= 4 (decoder conv_out); w_taps (9, Cout, C) in the operand type."""
+    mean, rstd, gamma, beta, groups = norm if norm is not None else (None, None, None, None, 1)
+    _chk(w_taps, BF16, "w_taps")
+    assert w_taps.is_contiguous() and tuple(w_taps.shape) == (9, Cout, x.C)
+    img = torch.empty(x.B, Cout, x.H, x.W, dtype=F32, device=x.buf.device)
+    call("pxa_vae_conv3x3_small_out", x.arg(), ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), groups, int(silu), ptr(w_taps), ptr(bias), Cout, ptr(img))
+    return img
+
+
 def vae_grid_to_nchw(x, C):
     img = torch.empty(x.B, C, x.H, x.W, dtype=F32, device=x.buf.device)
     call("pxa_vae_grid_to_nchw", x.arg(), C, ptr(img))

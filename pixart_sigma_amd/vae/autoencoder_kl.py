@@ -225,6 +225,10 @@ class AutoencoderKL(nn.Module):
                 P[id(mod)] = (w2.to(BF16).contiguous(), self._bias(mod.bias, co, dev), co)
             elif isinstance(mod, nn.GroupNorm):
                 P[id(mod)] = (mod.weight.detach().to(dev, F32).contiguous(), mod.bias.detach().to(dev, F32).contiguous())
+        co = self.decoder.conv_out                               # few-channel output convolution: direct kernel, weights as [tap][Cout][Cin]
+        if co.out_channels <= 4 and co.in_channels % 64 == 0:
+            P[("taps", id(co))] = (co.weight.detach().to(dev, F32).permute(2, 3, 0, 1).reshape(9, co.out_channels, co.in_channels).to(BF16).contiguous(),
+                                   co.bias.detach().to(dev, F32).contiguous() if co.bias is not None else None)
         for at in (self.encoder.mid_block.attentions[0], self.decoder.mid_block.attentions[0]):   # q, k, v as one GEMM
             ws, bs = zip(*[P[id(m)][:2] for m in (at.to_q, at.to_k, at.to_v)])
             P[("qkv", id(at))] = (torch.cat(ws).contiguous(), torch.cat(bs).contiguous(), sum(w.shape[0] for w in ws))
@@ -363,8 +367,12 @@ class AutoencoderKL(nn.Module):
                 h = self._resnet(h, r, out_stats=not (hasattr(blk, "upsamplers") and i == len(blk.resnets) - 1))
             if hasattr(blk, "upsamplers"):
                 h = self._conv3(h, blk.upsamplers[0].conv, upsample=2, stats=True)
-        img = self._conv3(h, dec.conv_out, self._norm(h, dec.conv_norm_out), silu=True, out_f32=True)
-        img = img[..., : self.config.out_channels].permute(0, 3, 1, 2).contiguous().to(z.dtype)
+        taps = self._packed.get(("taps", id(dec.conv_out)))
+        if taps is not None and os.environ.get("PXA_VAE_CONV_OUT_GEMM") != "1":      # one pass over h: norm + SiLU + 3x3 conv to the fp32 NCHW image
+            img = ops.vae_conv3x3_small_out(h, taps[0], taps[1], self.config.out_channels, self._norm(h, dec.conv_norm_out), silu=True).to(z.dtype)
+        else:
+            img = self._conv3(h, dec.conv_out, self._norm(h, dec.conv_norm_out), silu=True, out_f32=True)
+            img = img[..., : self.config.out_channels].permute(0, 3, 1, 2).contiguous().to(z.dtype)
         return SimpleNamespace(sample=img) if return_dict else (img,)
 
     def forward(self, sample, sample_posterior=False, return_dict=True, generator=None):

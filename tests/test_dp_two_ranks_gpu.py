@@ -4,7 +4,8 @@ GPU tensors through host memory) - the closest thing to the multi-GPU job that a
 while the remaining backward kernels are still being enqueued, and the fused clip + AdamW consumes the reduced buffer.
 
 Checked, on different per-rank batches:
-  * both ranks fire the bucket collectives from the hooks in the order final -> blocks.1 -> blocks.0 (then 'cond' in finish());
+  * the ranks are seeded DIFFERENTLY and become replicas through model.prepare()'s broadcast of rank 0's parameters (round 6: DDP's wrap-time semantics);
+  * both ranks fire the bucket collectives from the hooks in the order final -> blocks.1 -> blocks.0 -> cond (the last one from autograd's end-of-backward callback);
   * the reduced gradient buffer equals the sum of the two batches' gradients accumulated by ONE process into one buffer (per-tensor
     rel-L2; the kernels' fp32 atomics and the different summation order leave ~1e-6) - the DDP contract of the reference's accelerate wrapper
     (train_scripts/train.py:180-184,318-326), with 1 / world folded into the clip coefficient;
@@ -32,9 +33,11 @@ def _free_port():
     return p
 
 
-def _model():
+def _model(seed=0, broadcast=None):
+    """broadcast=None: prepare() broadcasts rank 0's weights when a process group of > 1 ranks exists (a COLLECTIVE, like wrapping in DDP: every rank calls it);
+    False: a local model (the single-process reference rank 0 builds on its own)."""
     from pixart_sigma_amd import PixArtMS
-    torch.manual_seed(0)                                   # identical init on every rank (DDP's broadcast)
+    torch.manual_seed(seed)
     m = PixArtMS(depth=2, input_size=16, model_max_length=16, class_dropout_prob=0.0,
                  kv_compress_config={"sampling": "conv", "scale_factor": 2, "kv_compress_layer": [1]})
     with torch.no_grad():
@@ -42,7 +45,7 @@ def _model():
             blk.cross_attn.proj.weight.normal_(std=0.02)
         m.final_layer.linear.weight.normal_(std=0.02)
     m = m.cuda().train()
-    m.prepare("cuda")
+    m.prepare("cuda", broadcast=broadcast)
     return m
 
 
@@ -70,7 +73,7 @@ def _worker(rank, world, port, out):
     from pixart_sigma_amd import IDDPM
     from pixart_sigma_amd.dp import FusedAdamW, GradReducer
     diff = IDDPM("1000", learn_sigma=True, pred_sigma=True, snr=False)
-    model = _model()
+    model = _model(seed=100 + rank)                        # ranks initialise DIFFERENTLY: prepare()'s broadcast of rank 0's weights is what makes them replicas
     store = model._store
     red = GradReducer(store)
     assert red.active and red.world == world
@@ -83,7 +86,8 @@ def _worker(rank, world, port, out):
     g_dp = store.grad.detach().clone()
     res = None
     if rank == 0:
-        ref = _model()
+        ref = _model(seed=100, broadcast=False)             # rank 0's own initialisation = what every rank holds after the broadcast
+        assert torch.equal(ref._store.master, store.master)
         for r in range(world):
             _loss(diff, ref, _batch(7, r)).backward()
         torch.cuda.synchronize()
@@ -129,7 +133,7 @@ def test_two_ranks_real_kernels_match_single_process(tmp_path):
     print(f"two-rank DP with the HIP kernels: reduced gradients vs single-process sum rel-L2 {res['grad_rel']:.2e} (worst tensor "
           f"{res['grad_worst'][1]} {res['grad_worst'][0]:.2e}); after {STEPS} steps |rank0 - rank1| {res['ranks_diff']:.2e}, weights moved by "
           f"{res['moved']:.2e}; losses {res['losses']}")
-    want = ["final", "blocks.1", "blocks.0"]
+    want = ["final", "blocks.1", "blocks.0", "cond"]        # 'cond' from the autograd end-of-backward callback (round 6), i.e. before finish()
     assert res["order_a"] == want and all(o == want for o in res["orders"]), (res["order_a"], res["orders"])
     assert res["inv"] == 0.5
     assert res["grad_rel"] < 1e-5 and res["grad_worst"][0] < 1e-4, res["grad_worst"]

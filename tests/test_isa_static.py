@@ -151,3 +151,20 @@ def test_row_kernels_keep_their_register_budget(tmp_path):
     assert plain[0] <= 288 and fused[0] <= plain[0] + 24, (plain, fused)
     assert gate[0] <= 256, gate
     assert plain[1] == 0 and fused[1] == 0 and gate[1] == 0, (plain, fused, gate)
+
+
+def test_persistent_gemm_instances_use_no_scratch(asm):
+    """Round 6: the PAIR && SEG instances of gemm_pers_kernel (the VAE's 128-channel convolutions as 512 x 128 paired items) first compiled with one lambda NOT
+    inlined - the closure (kernel arguments, item state, the DMA pointer arrays) went to 816 bytes of scratch per lane and the kernel ran 16x slower with correct
+    results (profiles/r6_03_*).  No instance of the persistent kernel may make a call or hold more than a few spilled registers in its private segment."""
+    text = asm[("gemm.hip", "bf16")]
+    names = re.findall(r"^\s+\.amdhsa_kernel (_Z\w*gemm_pers_kernel\w*)", text, re.M)
+    assert len(names) >= 20
+    for name in names:
+        meta = text[text.index(".amdhsa_kernel " + name):]
+        meta = meta[:meta.index(".end_amdhsa_kernel")]
+        m = re.search(r"\.amdhsa_private_segment_fixed_size (\d+)", meta)
+        assert m and int(m.group(1)) <= 64, (name, m and m.group(1))       # (the run-time-epilogue NN flavour <1, 3, 0> spills 16 bytes: a few registers, not a closure)
+        body = text[text.index("\n" + name + ":"):]
+        body = body[:body.index(".end_amdhsa_kernel")]
+        assert "s_swappc_b64" not in body, name

@@ -880,3 +880,37 @@ def test_cond_linear_f32(ops, M, K, N):
     # a second backward accumulates into .grad like any nn.Linear
     lin(x).backward(g)
     assert rel_l2(lin.weight.grad.double(), 2 * w2.grad) < 2e-6
+
+
+def test_gemm_counted_waits_match_full_waits(tmp_path):
+    """the persistent GEMM's epilogue waits are COUNTED (`s_waitcnt vmcnt(N)`, N mirroring the issue order of the prefetch / aux / bias / store
+    instructions by hand); a count that over-estimates would let registers be read before they land.  The debug build -DGEMM_WAIT_ALL=1 turns every counted wait
+    into vmcnt(0): every epilogue flavour must give the same BITS under both libraries (column-sum / GroupNorm partials, added with atomics, to 1e-5)."""
+    import shutil
+    import subprocess
+    import sys
+    from conftest import ROOT
+    from pixart_sigma_amd import lib as L_
+    if shutil.which("hipcc") is None and not os.path.exists("/opt/rocm/bin/hipcc"):
+        pytest.skip("no hipcc on this box: the debug variant cannot be built")
+    env = dict(os.environ, VARIANT_OPERAND=L_.OPERAND, PXA_OPERAND_DTYPE=L_.OPERAND)
+    env.pop("PXA_LIB_PATH", None)
+    name = "waitall_" + L_.OPERAND
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "build_variant.py"), name, "csrc/gemm.hip", "-DGEMM_WAIT_ALL=1"], capture_output=True, text=True,
+                       env=env, cwd=ROOT, timeout=1200)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    variant = os.path.join(ROOT, "pixart_sigma_amd", "variants", f"lib_{name}.so")
+    outs = {}
+    for tag, e in (("product", env), ("waitall", dict(env, PXA_LIB_PATH=variant))):
+        out = str(tmp_path / f"{tag}.pt")
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gemm_flavour_dump.py"), out], capture_output=True, text=True, env=e, cwd=ROOT, timeout=900)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+        outs[tag] = torch.load(out, weights_only=False)
+    assert set(outs["product"]) == set(outs["waitall"]) and len(outs["product"]) >= 12
+    for k, a in outs["product"].items():
+        b = outs["waitall"][k]
+        assert torch.isfinite(a.float()).all(), k
+        if k.endswith("_sum"):
+            assert rel_l2(a, b) < 1e-5, k
+        else:
+            assert torch.equal(a, b), (k, rel_l2(a, b))

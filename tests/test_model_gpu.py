@@ -33,6 +33,14 @@ GRAD_TOL = 1.2e-3 if F16 else 3e-2          # fp16: worst tensor measured 1.08e-
 # fp32 run on the same inputs): worst tensor 1.19e-3 (y_embedder fc1), cross_attn.q_linear 1.09e-3, at depth 2 up to 1.29e-3.  This path measures
 # 1.26e-3 worst (blocks.5.mlp.fc1.weight), q_linear 1.06e-3 - the same noise floor; the bound sits just above both.
 GRAD_TOL_DEEP = 1.5e-3 if F16 else 3e-2
+REF_NOISE_RATIO = 1.1                           # fp16 build: worst gradient error <= 1.1 x the worst gradient error of the reference's own fp16-autocast run on the same inputs
+
+
+def _ref_fp16_noise():
+    import json
+    import os
+    p = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_fp16_noise.json")
+    return json.load(open(p)) if os.path.exists(p) else {}
 
 
 @pytest.fixture(scope="module", autouse=True)
@@ -215,6 +223,31 @@ def test_training_step_loss_and_grads(golden, gname):
     worst.sort(reverse=True)
     for w in worst[:8]:
         print("grad err (max, norm, elementwise) %.2e %.2e %.2e %s" % w)
+    # Side by side with the REFERENCE's own mixed-precision noise on the same inputs (tests/golden/ref_fp16_noise.json: the unmodified reference under
+    # torch.autocast(float16) + 65536 loss scale against its own fp32 run, oracle/ref_fp16_noise.py) - VERDICT r05 item 7.  Per family of tensors: this path, the
+    # reference's fp16 path, the ratio.
+    noise = _ref_fp16_noise().get(gname)
+    if noise is not None:
+        fam = {}
+        for e, _, _, k in worst:
+            f = ".".join(p_ for p_ in k.split(".") if not p_.isdigit())
+            r = noise["grad_rel"].get(k)
+            if r is None:
+                continue
+            o = fam.setdefault(f, [0.0, 0.0, 0.0, k])
+            o[0], o[1] = max(o[0], e), max(o[1], r)
+            if e / r > o[2]:
+                o[2], o[3] = e / r, k
+        print(f"  {'family':44s} {'this path':>10s} {'ref fp16':>10s} {'worst ratio of one tensor':>26s}")
+        for f, (e, r, q, k) in sorted(fam.items(), key=lambda kv: -kv[1][0])[:14]:
+            print(f"  {f:44s} {e:10.2e} {r:10.2e} {q:10.2f}  ({k})")
+        ours_worst, ref_worst = worst[0][0], noise["worst"]
+        ratio_worst = max(v[2] for v in fam.values())
+        print(f"  worst tensor: this path {ours_worst:.2e}, reference fp16 path {ref_worst:.2e}; worst per-tensor ratio {ratio_worst:.2f}; loss: {e_loss:.2e} vs {noise['loss_rel']:.2e}")
+        record_parity(f"{gname}: worst gradient / the reference's own fp16-autocast worst gradient", ours_worst / ref_worst, REF_NOISE_RATIO if F16 else None)
+        record_parity(f"{gname}: worst per-tensor ratio to the reference's fp16-autocast error of the same tensor", ratio_worst)
+        if F16:
+            assert ours_worst <= REF_NOISE_RATIO * ref_worst, (ours_worst, ref_worst)
     record_parity(f"{gname}: worst parameter gradient ({worst[0][3]})", worst[0][0], GRAD_TOL_DEEP if cfg.depth > 2 else GRAD_TOL)
     assert worst[0][0] < (GRAD_TOL_DEEP if cfg.depth > 2 else GRAD_TOL), worst[0]
     # gradients live in the flat buffer the fused optimizer / all-reduce work on
@@ -273,10 +306,11 @@ def test_dpm_solver_sampling_matches_reference(golden):
     assert e < (SAMPLE_TOL if F16 else FWD_F32_TOL)
 
 
-# ---- round 6: the inference configs end to end at their configured step count (VERDICT r05 missing #2).  A sampler chain is not a contraction: the solver's
-# x_t carries every earlier evaluation's error, and the last steps divide by alpha_t ~ 1 after multiplying eps by sigma_t -> 0, so the error of x_t against the
-# reference chain grows over the first steps and settles.  Bounds below are the measured end-of-chain errors with ~1.5x headroom.
-CHAIN_TOL = {"dpms_xl2_512_s20": (4e-3, 4e-2), "dpms_xl2_2k_kv_s4": (2e-3, 2e-2)}      # (fp16, bf16)
+# ---- round 6: the inference configs end to end at their configured step count (VERDICT r05 missing #2).  Measured (profiles/r6_03_pytest_sel.txt): the error of x_t
+# against the reference chain is made in the first two solver steps (t = 1 -> 0.9: sigma_t ~ 1, the whole eps error lands in x) and then STAYS - fp16 operands
+# 4.9e-4 after step 1, 5.7e-4 after step 20; bf16 4.0e-3 -> 4.6e-3 - the later steps contract (sigma_t / sigma_s < 1) about as fast as they add.  So the fp16
+# build meets north_star's 1e-3 on the 20-step sample itself; the bounds are the measured end-of-chain errors with ~1.7x headroom.
+CHAIN_TOL = {"dpms_xl2_512_s20": (1e-3, 1e-2), "dpms_xl2_2k_kv_s4": (1e-3, 1e-2)}      # (fp16, bf16)
 
 
 @pytest.mark.parametrize("name", ["dpms_xl2_512_s20", "dpms_xl2_2k_kv_s4"])

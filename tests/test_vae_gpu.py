@@ -62,6 +62,27 @@ def test_groupnorm_stats_and_apply(ops, B, C, H, W, groups):
     assert torch.equal(from_grid(y), F.interpolate(x, scale_factor=2.0, mode="nearest"))
 
 
+@pytest.mark.parametrize("B,C,Co,H,W,groups", [(2, 128, 3, 37, 45, 32), (1, 64, 4, 8, 32, 16), (1, 256, 1, 19, 70, 32), (3, 128, 2, 16, 64, 0)])
+def test_conv3x3_small_out_is_groupnorm_silu_conv2d(ops, B, C, Co, H, W, groups):
+    """pxa_vae_conv3x3_small_out (round 6: the decoder's conv_norm_out -> SiLU -> conv_out 128 -> 3 as one pass) == Conv2d(3, padding=1) of SiLU(GroupNorm(x)) as an
+    fp32 NCHW image; tiles that overhang the image on both sides, 1 to 4 output channels, with and without the norm (groups = 0)."""
+    g, x = to_grid(ops, rnd(B, C, H, W, seed=1) * 1.5 + 0.3)
+    w = rnd(Co, C, 3, 3, scale=(9 * C) ** -0.5, seed=2).to(ops.BF16)
+    bias = rnd(Co, seed=3)
+    taps = w.permute(2, 3, 0, 1).reshape(9, Co, C).contiguous()
+    if groups:
+        gamma, beta = rnd(C, seed=4) * 0.3 + 1.0, rnd(C, seed=5) * 0.2
+        mean, rstd = ops.vae_gn_stats(g, groups, 1e-6)
+        a = F.silu(F.group_norm(x, groups, gamma, beta, eps=1e-6))
+        img = ops.vae_conv3x3_small_out(g, taps, bias, Co, (mean, rstd, gamma, beta, groups), silu=True)
+    else:
+        a = x
+        img = ops.vae_conv3x3_small_out(g, taps, bias, Co)
+    ref = F.conv2d(a.to(ops.BF16).float(), w.float(), bias, padding=1)          # the staged operand carries one rounding, like the padded grid of the GEMM path
+    assert img.shape == ref.shape and img.dtype == torch.float32
+    assert rel_l2(img, ref) < (1e-3 if groups else 2e-5)                          # with the norm: the kernel's SiLU (rcp / exp intrinsics) against torch's, before the rounding
+
+
 @pytest.mark.parametrize("B,C,Co,H,W", [(2, 64, 128, 9, 13), (1, 128, 8, 20, 20), (2, 256, 256, 16, 8), (1, 512, 512, 8, 8),
                                          (2, 128, 128, 30, 30), (1, 256, 512, 40, 24), (2, 512, 256, 24, 24), (3, 64, 384, 20, 31)])
 @pytest.mark.parametrize("interleave", [False, True])

@@ -1,12 +1,13 @@
 #!/bin/bash
-# After `gpurun -- 'bash tools/sessions/r5_bundle.sh [tag]'` (the validation bundle, default tag r5final): copy what the judge reads from gpurun_out/ (scratch) into profiles/ (tracked).
-#   usage (this container, repo root):  bash tools/collect_bundle.sh [tag]
-tag=${1:-r5final}
+# After a GPU session (tools/gpurun_session.sh TIMEOUT TAG recipe ...): copy what the judge reads from gpurun_out/ (scratch) into profiles/ (tracked) - every
+# TAG_* text / csv / json artefact except raw logs - plus the session's parity summaries when they come from a full tier run.
+#   usage (this container, repo root):  bash tools/collect_bundle.sh TAG
+tag=${1:?tag}
 cd "$(dirname "$0")/.." || exit 1
-for f in pytest_gpu.txt smoke.txt bench_default.json step_kernel_stats.csv pmc_attention.txt pmc_attention.json pmc_gemm.txt bench_infer.txt profile_round.log pmc_step_gemm_table.txt; do
-  [ -f gpurun_out/${tag}_$f ] && cp gpurun_out/${tag}_$f profiles/${tag}_$f
+for f in gpurun_out/${tag}_*; do
+  case "$f" in *.log|*.err|*_trace.csv) continue;; esac
+  [ -f "$f" ] && [ "$(stat -c %s "$f")" -lt 2000000 ] && cp "$f" profiles/
 done
-# (the per-session parity summaries are overwritten by EVERY GPU pytest session: take them only when they are the full tier's)
 for op in f16 bf16; do
   python - <<PY
 import json, shutil, os
@@ -15,10 +16,4 @@ if os.path.exists(p) and len(json.load(open(p)).get("entries", [])) >= 50:
     shutil.copy(p, "profiles/${tag}_parity_summary_$op.json")
 PY
 done
-python tools/family_times.py profiles/${tag}_step_kernel_stats.csv
-python - <<PY
-import json
-d = json.loads(open("profiles/${tag}_bench_default.json").read().strip().splitlines()[-1])
-r = d["roofline"]
-print(f"{d['ms_per_step']:.1f} ms/step = {d['value']:.3f} steps/s ({d['dtype']}); other dtype {d.get('other_dtype', {}).get('ms_per_step')}; dominant {r['kernel'].split()[0]} {r['ms_per_launch']:.3f} ms frac {r['frac']:.3f} traffic {r['traffic']}")
-PY
+ls profiles/${tag}_* 2>/dev/null

@@ -19,9 +19,10 @@ r_tests() {      # the GPU test tier (both operand builds: the tier re-runs the 
 }
 r_pytest() {     # selected tests:  pytest:tests/test_model_gpu.py:-k:dpm   (PXA_OPERAND_DTYPE from the environment)
   echo "$hdr operand build ${PXA_OPERAND_DTYPE:-bf16}: pytest $*" >> $O/${tag}_pytest_sel.txt
-  timeout 1800 python -m pytest -m gpu -q -p no:cacheprovider -s "$@" >> $O/${tag}_pytest_sel.txt 2>&1; echo "pytest rc=$?" >> $O/${tag}_pytest_sel.txt
+  timeout ${PYTEST_TIMEOUT:-600} python -m pytest -m gpu -q -p no:cacheprovider -s "$@" >> $O/${tag}_pytest_sel.txt 2>&1; echo "pytest rc=$?" >> $O/${tag}_pytest_sel.txt
   grep -v amdgpu $O/${tag}_pytest_sel.txt | tail -n 40 | cut -c1-300
 }
+r_pytest_f16() { PXA_OPERAND_DTYPE=f16 r_pytest "$@"; }     # the same under the fp16-operand library
 r_smoke() {
   echo "$hdr" > $O/${tag}_smoke.txt
   timeout 900 python __graft_entry__.py smoke >> $O/${tag}_smoke.txt 2>&1; echo "smoke rc=$?" >> $O/${tag}_smoke.txt
@@ -78,9 +79,27 @@ r_profile_vae() {    # kernel trace of the SD-VAE decode of config 5 (64 x 512px
   python tools/vae_layer_table.py $O/${tag}_vae_decode512_trace.csv ${1:-64} > $O/${tag}_vae_layer_table.txt 2>&1 && sed -i "1i $hdr operand build f16" $O/${tag}_vae_layer_table.txt
   cat $O/${tag}_vae_layer_table.txt | cut -c1-170
 }
+r_dp_ab() {      # the N > 1 code path as far as one GPU can run it: bench.py under torchrun (world 1, real RCCL group) with PXA_DP_FORCE_COLLECTIVES=1 - every gradient
+                 # bucket all-reduced from the engine's hooks - against the plain run; dynamic item cursors (the reducer's default) against the static split
+                 # (PXA_DP_STATIC_ITEMS=1); PXA_DP_TRACE=1 prints the per-bucket record.  Two alternating rounds, 8 steps after 3 of warm-up.
+  echo "$hdr operand build f16" > $O/${tag}_dp_ab.txt
+  port=29650
+  for rep in 1 2; do
+    for cfg in "plain (no process group)|NOPG=1" "rccl world 1, forced collectives, dynamic cursors|PXA_DP_FORCE_COLLECTIVES=1 PXA_DP_TRACE=1" "rccl world 1, forced collectives, static split|PXA_DP_FORCE_COLLECTIVES=1 PXA_DP_TRACE=1 PXA_DP_STATIC_ITEMS=1"; do
+      label=${cfg%%|*}; envs=${cfg#*|}; port=$((port + 1))
+      if [ "$envs" = "NOPG=1" ]; then launcher="python"; else launcher="python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port $port"; fi
+      r=$(env $envs timeout 600 $launcher bench.py --gpus 1 --steps 8 --warmup 3 $BENCH_QUIET 2> $O/${tag}_dp_ab.err | python -c 'import sys,json
+d=json.loads([l for l in sys.stdin.read().splitlines() if l.startswith("{")][-1]); t=d.get("dp_trace") or {}
+print(round(d["ms_per_step"],2), "ms/step; process_group", d["process_group"], "; trace:", {k: t[k] for k in ("backward_done_ms","all_reduced_ms","exposed_ms","world") if k in t}, [(b["bucket"], b["launched_from"]) for b in t.get("buckets", [])][-2:])')
+      echo "$label: $r" >> $O/${tag}_dp_ab.txt
+      grep "dp trace" $O/${tag}_dp_ab.err | tail -1 >> $O/${tag}_dp_ab.txt
+    done
+  done
+  cat $O/${tag}_dp_ab.txt
+}
 r_run() {        # anything else, logged under the tag:  run:python:tools/kbench.py:attn
   echo "$hdr operand build ${PXA_OPERAND_DTYPE:-bf16}: $*" >> $O/${tag}_run.txt
-  timeout 1500 "$@" >> $O/${tag}_run.txt 2>&1; echo "rc=$?" >> $O/${tag}_run.txt
+  timeout ${RUN_TIMEOUT:-600} "$@" >> $O/${tag}_run.txt 2>&1; echo "rc=$?" >> $O/${tag}_run.txt
   grep -v amdgpu $O/${tag}_run.txt | tail -n 30 | cut -c1-400
 }
 
