@@ -86,6 +86,14 @@ typedef struct {
                                  /*  token rows in ascending order: the rows written last are the ones still in the 256 MB Infinity     */
                                  /*  Cache, and this launch's own output then ends with the FIRST rows - fresh for an ascending         */
                                  /*  consumer.  Results are bit-identical either way.  0 = ascending.                                   */
+  int up_row_pitch;              /* (ABI 9, round 6) > 0: ONE PHASE of a 3x3 convolution over a 2x nearest-upsampled input, computed on the LOW-RES grid */
+  int up_img_rows;               /*  (diffusers Upsample2D: F.interpolate(scale 2, nearest) then Conv2d(3, padding 1); decoder call site reference        */
+  int up_dy, up_dx;              /*  scripts/inference.py:136).  Output pixel (2y+dy, 2x+dx) of the upsampled convolution sees only a 2 x 2 patch of       */
+                                 /*  low-res pixels, with the 3 x 3 taps that fall on the same low-res pixel summed: 4 phases x 4 taps = 16 / 36 of the     */
+                                 /*  products.  The launch is an implicit convolution over the low-res padded grid (gn_* describe THAT grid; k_seg = 2 C,   */
+                                 /*  K = 4 C, gn_part required); the row of interior low-res pixel (py, px) is stored at row                               */
+                                 /*  image * up_img_rows + (2 py - 1 + up_dy) * up_row_pitch + (2 px - 1 + up_dx) of the output (the high-res padded grid,  */
+                                 /*  row pitch up_row_pitch = 2 gn_w + 2), border rows are not stored; statistics as for gn_part.  0 = off.                */
 } pxa_gemm_args;
 /* Upper bound of the split-K workspace (in floats) pxa_gemm may use for an (M, N) fp32-accumulate output. */
 long pxa_gemm_splitk_ws_elems(int M, int N);

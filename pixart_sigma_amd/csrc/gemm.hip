@@ -1465,9 +1465,18 @@ __global__ __launch_bounds__(512) void gemm_pers_kernel(GemmParams p) {
             const int sw = JW == 2 ? (row & 7) : ((row >> 1) & 3);
             const uint4 v4 = *reinterpret_cast<const uint4*>(stg + row * RB + ((ch ^ sw) << 4));
             const int mm = mw + i * 32 + row, nn = nw + j0 * 32 + ch * 8;
-            if (mm < p.M && nn < p.N && !((GEMM_ABL & 32) && pass == 0)) {
-              if (GEMM_NT_STORE) __builtin_nontemporal_store(nt_u4{v4.x, v4.y, v4.z, v4.w}, reinterpret_cast<nt_u4*>(dst + (size_t)mm * p.ldo + nn));
-              else *reinterpret_cast<uint4*>(dst + (size_t)mm * p.ldo + nn) = v4;
+            size_t orow = (size_t)mm;
+            bool st_ok = mm < p.M && nn < p.N && !((GEMM_ABL & 32) && pass == 0);
+            if constexpr (want_st) {
+              if (p.up_rp) {                           // phase of an upsampled convolution: interior low-res pixels only, scattered into the high-res padded grid
+                const int pixu = mm - st_base, pyu = (int)(((float)pixu + 0.5f) * p.gn_inv_rp), pxu = pixu - pyu * p.gn_rp;
+                st_ok = st_ok && pyu >= 1 && pyu <= p.gn_h && pxu >= 1 && pxu <= p.gn_w;
+                orow = (size_t)st_img * p.up_ip + (size_t)((2 * pyu - 1) * p.up_rp + 2 * pxu - 1 + p.up_off);
+              }
+            }
+            if (st_ok) {
+              if (GEMM_NT_STORE) __builtin_nontemporal_store(nt_u4{v4.x, v4.y, v4.z, v4.w}, reinterpret_cast<nt_u4*>(dst + orow * p.ldo + nn));
+              else *reinterpret_cast<uint4*>(dst + orow * p.ldo + nn) = v4;
             }
             if (pass == 1 && want_cs && mm < p.M) {
               float f[8];
@@ -1530,7 +1539,8 @@ __global__ __launch_bounds__(512) void gemm_pers_kernel(GemmParams p) {
     {   // stores this wave has just issued, if every one of them was a full (unpredicated) 16-byte row segment
       const bool interior = mw + tm_eff * 32 <= p.M && nw + 64 <= p.N;
       // (the statistics / column-sum flavours issue 4 / 8 more vector-memory instructions behind the stores: their atomics)
-      prev_stores = (interior && p.out) ? tm_eff * 4 * ((dual && !(GEMM_ABL & 32)) ? 2 : 1) + (want_st ? 4 : 0) + (want_cs ? 8 : 0) + ((AUXA && tm_eff > 2) ? 16 : 0) : 0;
+      // (upsampled-convolution phases predicate their stores per row: nothing may be assumed in flight)
+      prev_stores = (interior && p.out && !(want_st && p.up_rp)) ? tm_eff * 4 * ((dual && !(GEMM_ABL & 32)) ? 2 : 1) + (want_st ? 4 : 0) + (want_cs ? 8 : 0) + ((AUXA && tm_eff > 2) ? 16 : 0) : 0;
     }
     nk = nk_pf;
     if (!more) break;
@@ -1766,6 +1776,14 @@ extern "C" int pxa_gemm(const pxa_gemm_args* a, hipStream_t stream) {
   p.colsum = a->colsum; p.colsum_stride = a->colsum_stride;
   p.gn_part = a->gn_part; p.gn_img_rows = a->gn_img_rows; p.gn_rp = a->gn_row_pitch; p.gn_h = a->gn_h; p.gn_w = a->gn_w;
   p.gn_B = 0; p.gn_inv_rp = 0.f;
+  p.up_rp = 0; p.up_ip = 0; p.up_off = 0;
+  if (a->up_row_pitch) {
+    PXA_CHECK(a->gn_part && a->k_seg && a->act == 0 && !a->k_tap, "pxa_gemm: up_row_pitch needs an implicit convolution with gn_part, act 0 and the plain segment order");
+    PXA_CHECK(a->K == 2 * a->k_seg && a->up_row_pitch == 2 * a->gn_w + 2 && a->up_img_rows >= (2 * a->gn_h + 2) * a->up_row_pitch && (a->up_dy | 1) == 1 && (a->up_dx | 1) == 1,
+              "pxa_gemm: bad upsampled-convolution phase (K=%d k_seg=%d up_row_pitch=%d up_img_rows=%d dy=%d dx=%d)", a->K, a->k_seg, a->up_row_pitch, a->up_img_rows, a->up_dy, a->up_dx);
+    PXA_CHECK(a->M >= 1024 && a->N % 128 == 0 && (long)(a->M / a->gn_img_rows) * a->up_img_rows < (1L << 31), "pxa_gemm: upsampled-convolution phase needs the persistent path (M >= 1024, N a multiple of 128)");
+    p.up_rp = a->up_row_pitch; p.up_ip = a->up_img_rows; p.up_off = a->up_dy * a->up_row_pitch + a->up_dx;
+  }
   if (a->gn_part) {
     PXA_CHECK(a->k_seg && a->out_bf16 && !a->out_f32 && (a->act == 0 || a->act == 5), "pxa_gemm: gn_part needs an implicit convolution (k_seg) with a bf16 output and act 0 or 5");
     PXA_CHECK(a->gn_img_rows > 0 && a->gn_img_rows % 256 == 0 && a->M % a->gn_img_rows == 0, "pxa_gemm: gn_img_rows=%d must be a multiple of 256 dividing M=%d", a->gn_img_rows, a->M);

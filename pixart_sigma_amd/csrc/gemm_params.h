@@ -21,6 +21,9 @@ struct GemmParams {
   // the bf16 output over the INTERIOR pixels of each image, per QUAD of adjacent channels (GroupNorm groups are multiples of 4 channels
   // wide), added into gn_part[slot][image][N/4][2] (slot = 128-row block % PXA_COLSUM_SLOTS)
   float* gn_part; int gn_img_rows, gn_rp, gn_h, gn_w, gn_B; float gn_inv_rp;
+  // one phase of a 3x3 convolution over a 2x nearest-upsampled input (pxa_gemm_args.up_*): interior low-res pixel (py, px) of image b is stored at output row
+  // b * up_ip + (2 py - 1) * up_rp + 2 px - 1 + up_off (up_off = dy * up_rp + dx); up_rp = 0: off
+  int up_rp, up_ip, up_off;
 };
 
 // gemm_nt4.hip: the one-wave-per-SIMD NT kernel.  Returns 1 when the call is not one it takes (the caller goes on to the other kernels), 0 after a launch,

@@ -26,7 +26,8 @@ class GemmArgs(C.Structure):
                 ("out_f32", c_void_p), ("ld_f32", c_int), ("accumulate", c_int), ("split_k", c_int),
                 ("splitk_ws", c_void_p), ("splitk_ws_elems", c_long), ("colsum", c_void_p), ("colsum_stride", c_long),
                 ("k_seg", c_int), ("a_seg_stride", c_long), ("k_tap", c_int),
-                ("gn_part", c_void_p), ("gn_img_rows", c_int), ("gn_row_pitch", c_int), ("gn_h", c_int), ("gn_w", c_int), ("items_descending", c_int)]
+                ("gn_part", c_void_p), ("gn_img_rows", c_int), ("gn_row_pitch", c_int), ("gn_h", c_int), ("gn_w", c_int), ("items_descending", c_int),
+                ("up_row_pitch", c_int), ("up_img_rows", c_int), ("up_dy", c_int), ("up_dx", c_int)]
 
 
 class GridArg(C.Structure):

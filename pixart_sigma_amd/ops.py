@@ -21,14 +21,16 @@ def _chk(t, dtype, name):
 
 
 def gemm(a, b, layout=NT, bias=None, act=ACT_NONE, aux=None, out=None, out2=None, out_f32=None, accumulate=False,
-         split_k=1, out_dtype=BF16, colsum=None, k_seg=0, a_seg_stride=0, k_tap=0, gn_part=None, gn_geom=None, descending=False):
+         split_k=1, out_dtype=BF16, colsum=None, k_seg=0, a_seg_stride=0, k_tap=0, gn_part=None, gn_geom=None, descending=False, up=None):
     """C = op(A) op(B) (see include/pixart_hip.h).  a, b: 2-D bf16 (row stride arbitrary multiple of 8).
     Returns the bf16 output (or fp32 when out_dtype is float32 / out_f32 is given).
     k_seg / a_seg_stride / k_tap: segmented-K A operand (the implicit 3x3 convolution of the VAE kernel set).
     gn_part (PXA_COLSUM_SLOTS, B, N/4, 2) fp32 zeros + gn_geom = (img_rows, row_pitch, H, W): GroupNorm statistics of the output
     accumulated by the epilogue (see pxa_gemm_args.gn_part).
     descending: the persistent NT / NN kernels walk their output tiles from the last token rows to the first (pxa_gemm_args.items_descending) - for a launch
-    whose A operand was just written by a kernel that swept the rows upwards; bit-identical results."""
+    whose A operand was just written by a kernel that swept the rows upwards; bit-identical results.
+    up = (row_pitch, img_rows, dy, dx) of the HIGH-RES padded output grid: this launch is phase (dy, dx) of a 3x3 convolution over a 2x nearest-upsampled
+    input, computed on the low-res grid (pxa_gemm_args.up_*); `out` must be given (its rows are high-res padded pixels)."""
     _chk(a, BF16, "A")
     _chk(b, BF16, "B")
     if layout == NT:
@@ -75,6 +77,9 @@ def gemm(a, b, layout=NT, bias=None, act=ACT_NONE, aux=None, out=None, out2=None
         assert gn_part.is_contiguous() and gn_part.numel() == COLSUM_SLOTS * (M // gn_geom[0]) * (N // 4) * 2
         g.gn_part = ptr(gn_part)
         g.gn_img_rows, g.gn_row_pitch, g.gn_h, g.gn_w = gn_geom
+    if up is not None:
+        assert out is not None and gn_part is not None
+        g.up_row_pitch, g.up_img_rows, g.up_dy, g.up_dx = up
     if colsum is not None:               # (PXA_COLSUM_SLOTS, stride) partial buffer view: row 0 of the slice to accumulate
         g.colsum, g.colsum_stride = ptr(colsum), colsum.stride(0)
     if accumulate and split_k != 1:       # split-K partial slabs: caller-owned workspace, cached per device (max 16 slabs)

@@ -225,6 +225,24 @@ class AutoencoderKL(nn.Module):
                 P[id(mod)] = (w2.to(BF16).contiguous(), self._bias(mod.bias, co, dev), co)
             elif isinstance(mod, nn.GroupNorm):
                 P[id(mod)] = (mod.weight.detach().to(dev, F32).contiguous(), mod.bias.detach().to(dev, F32).contiguous())
+        # Upsample2D convolutions (decoder): conv3x3(nearest 2x upsample(x)) = four 2 x 2 convolutions of x, one per output parity (dy, dx), whose taps are the
+        # sums of the 3 x 3 taps that land on the same low-res pixel - 16 of 36 products (ops.gemm(..., up=...)).  Tap sums in fp32, ONE rounding to the operand
+        # type; K order [a][b][Cin] (a, b = the 2 x 2 patch rows / columns: low-res pixel (y + dy - 1 + a, x + dx - 1 + b)).
+        for blk in self.decoder.up_blocks:
+            if hasattr(blk, "upsamplers"):
+                cv = blk.upsamplers[0].conv
+                w = cv.weight.detach().to(dev, F32)                # (Co, Ci, 3, 3)
+                if w.shape[0] % 128 == 0 and w.shape[1] % 64 == 0:
+                    phases = []
+                    for dy in (0, 1):
+                        for dx in (0, 1):
+                            wp = torch.zeros(w.shape[0], 2, 2, w.shape[1], device=dev)
+                            for ky in range(3):
+                                for kx in range(3):
+                                    a, b = (dy + ky - 1) // 2 - (dy - 1), (dx + kx - 1) // 2 - (dx - 1)
+                                    wp[:, a, b] += w[:, :, ky, kx]
+                            phases.append(wp.reshape(w.shape[0], -1).to(BF16).contiguous())
+                    P[("up", id(cv))] = (phases, self._bias(cv.bias, w.shape[0], dev))
         co = self.decoder.conv_out                               # few-channel output convolution: direct kernel, weights as [tap][Cout][Cin]
         if co.out_channels <= 4 and co.in_channels % 64 == 0:
             P[("taps", id(co))] = (co.weight.detach().to(dev, F32).permute(2, 3, 0, 1).reshape(9, co.out_channels, co.in_channels).to(BF16).contiguous(),
@@ -292,6 +310,30 @@ class AutoencoderKL(nn.Module):
         assert upsample == 1 and not out_f32 and residual is None
         col = ops.vae_im2col3x3(x, 1, 1, H, W, norm, silu)      # stem convolutions: C = 8 (3 / 4 real channels)
         return Grid(ops.gemm(col, w, ops.NT, bias=b), B, H, W, w.shape[0])
+
+    def _conv3_up2(self, x, conv):
+        """Upsample2D: conv3x3(nearest-2x(x)) with GroupNorm statistics of the result, as four low-res 2 x 2 phase convolutions that scatter into the high-res
+        padded grid (see _prepare); falls back to the upsampled 3x3 form where the persistent phase kernel does not apply (tiny grids, PXA_VAE_UP_PHASES=0)."""
+        up = self._packed.get(("up", id(conv)))
+        B, H, W, C, dev = x.B, x.H, x.W, x.C, x.buf.device
+        ipL, rpL = _img_rows(H, W), W + 2
+        if up is None or B * ipL < 1024 or os.environ.get("PXA_VAE_UP_PHASES", "1") == "0":
+            return self._conv3(x, conv, upsample=2, stats=True)
+        phases, bias = up
+        Co = phases[0].shape[0]
+        buf = self._padded(B, H, W, C, dev)                      # low-res zero-bordered copy (no norm / activation in front of an upsampling convolution)
+        ops.vae_gn_apply(x, Grid(buf, B, H, W, C, rpL, ipL, origin=(W + 3) + rpL + 1))
+        H2, W2 = 2 * H, 2 * W
+        ipH, rpH = _img_rows(H2, W2), W2 + 2
+        out = torch.empty((B * ipH, Co), dtype=BF16, device=dev)  # only interior rows are written; the others are never read as pixels
+        part = torch.zeros(ops.COLSUM_SLOTS, B, Co // 4, 2, dtype=F32, device=dev)
+        for i, (dy, dx) in enumerate(((0, 0), (0, 1), (1, 0), (1, 1))):
+            off = (W + 3) + (dy - 1) * rpL + dx - 1               # A row m = low-res padded pixel m; its 2 x 2 patch starts at buffer pixel m + off
+            a = buf.as_strided((B * ipL, 4 * C), (C, 1), off * C)
+            ops.gemm(a, phases[i], ops.NT, bias=bias, out=out, k_seg=2 * C, a_seg_stride=rpL * C, gn_part=part, gn_geom=(ipL, rpL, H, W), up=(rpH, ipH, dy, dx))
+        y = Grid(out, B, H2, W2, Co, rpH, ipH, origin=W2 + 3)
+        y.gn_part = part
+        return y
 
     def _conv3_s2(self, x, conv):
         """diffusers Downsample2D: F.pad(x, (0, 1, 0, 1)) then Conv2d(3, stride 2, padding 0)."""
@@ -366,7 +408,10 @@ class AutoencoderKL(nn.Module):
             for i, r in enumerate(blk.resnets):
                 h = self._resnet(h, r, out_stats=not (hasattr(blk, "upsamplers") and i == len(blk.resnets) - 1))
             if hasattr(blk, "upsamplers"):
-                h = self._conv3(h, blk.upsamplers[0].conv, upsample=2, stats=True)
+                h = self._conv3_up2(h, blk.upsamplers[0].conv)
+        # (Running the 256 / 512-pixel levels in sub-batches of 2 .. 16 images, so that a layer's tensors stay inside the 256 MB Infinity Cache between the
+        # kernels that write and read them, was measured and dropped: 171.8 ms whole batch, 173.3 / 176.4 / 183.7 / 199.2 ms at 16 / 8 / 4 / 2 images -
+        # profiles/r6_06_run.txt.)
         taps = self._packed.get(("taps", id(dec.conv_out)))
         if taps is not None and os.environ.get("PXA_VAE_CONV_OUT_GEMM") != "1":      # one pass over h: norm + SiLU + 3x3 conv to the fp32 NCHW image
             img = ops.vae_conv3x3_small_out(h, taps[0], taps[1], self.config.out_channels, self._norm(h, dec.conv_norm_out), silu=True).to(z.dtype)

@@ -5,6 +5,8 @@ Tolerance, stated: every activation between layers is stored as bf16 (the refere
 end-to-end rel-L2 of the ~30-layer decoder / encoder is 1.2e-2 ... 1.7e-2 with bf16 operands (deterministic for fixed seeds) and
 1.5e-3 ... 2.0e-3 with the fp16-operand build (tests/test_f16_parity_gpu.py, tools/vae_parity.py) -> bound 2.5e-2 here.  Parity is
 unpinned for this row (no reference vectors exist)."""
+import os
+
 import pytest
 import torch
 import torch.nn.functional as F
@@ -60,6 +62,39 @@ def test_groupnorm_stats_and_apply(ops, B, C, H, W, groups):
     assert rel_l2(from_grid(y), F.interpolate(F.silu(ref), scale_factor=2.0, mode="nearest")) < BF16_TOL
     y = ops.vae_gn_apply(g, ops.Grid.compact(B, 2 * H, 2 * W, C, "cuda"), None, upsample=2)                 # plain upsampling copy
     assert torch.equal(from_grid(y), F.interpolate(x, scale_factor=2.0, mode="nearest"))
+
+
+@pytest.mark.parametrize("B,H,W,chans", [(2, 24, 20, (128, 256)), (1, 33, 47, (128, 512)), (3, 16, 16, (256, 256))])
+def test_upsample_conv_as_four_phase_convolutions(ops, B, H, W, chans):
+    """Round 6: Upsample2D (nearest 2x, then Conv2d 3x3 pad 1) as four 2 x 2 phase convolutions on the LOW-RES grid whose epilogues scatter into the high-res
+    padded grid (pxa_gemm_args.up_*, AutoencoderKL._conv3_up2): equals conv2d(interpolate(x)) up to the ONE rounding of the summed taps, and the GroupNorm partial
+    sums its epilogues accumulate over the four launches equal the statistics of the stored result.  Odd sizes, batch > 1, 256 / 512 channels."""
+    from pixart_sigma_amd.vae import AutoencoderKL
+    torch.manual_seed(3)
+    vae = AutoencoderKL(block_out_channels=chans, layers_per_block=1).cuda()
+    vae._prepare()
+    conv = vae.decoder.up_blocks[0].upsamplers[0].conv
+    C = conv.in_channels
+    g, x = to_grid(ops, rnd(B, C, H, W, seed=1))
+    assert ("up", id(conv)) in vae._packed
+    y = vae._conv3_up2(g, conv)
+    assert (y.H, y.W, y.C, y.row_pitch) == (2 * H, 2 * W, conv.out_channels, 2 * W + 2) and y.gn_part is not None
+    ref = F.conv2d(F.interpolate(x, scale_factor=2.0, mode="nearest"), conv.weight.float(), conv.bias.float(), padding=1)
+    got = from_grid(y)
+    e = rel_l2(got, ref)
+    print(f"\nupsample conv as 4 phases B{B} C{C} {H}x{W}: rel-L2 vs conv2d(interpolate(x)) {e:.2e}")
+    assert e < BF16_TOL
+    groups = 32
+    mean, rstd = ops.vae_gn_finalize(y.gn_part, B, y.C, groups, y.H * y.W, 1e-6)
+    gg = got.view(B, groups, -1)
+    assert rel_l2(mean, gg.mean(-1).flatten()) < 1e-4 and rel_l2(rstd, (gg.var(-1, unbiased=False) + 1e-6).rsqrt().flatten()) < 1e-4
+    # and the fallback (upsampled 3x3 form) agrees with it
+    os.environ["PXA_VAE_UP_PHASES"] = "0"
+    try:
+        y3 = vae._conv3_up2(g, conv)
+    finally:
+        del os.environ["PXA_VAE_UP_PHASES"]
+    assert rel_l2(from_grid(y3), got) < BF16_TOL
 
 
 @pytest.mark.parametrize("B,C,Co,H,W,groups", [(2, 128, 3, 37, 45, 32), (1, 64, 4, 8, 32, 16), (1, 256, 1, 19, 70, 32), (3, 128, 2, 16, 64, 0)])

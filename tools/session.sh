@@ -100,7 +100,7 @@ print(round(d["ms_per_step"],2), "ms/step; process_group", d["process_group"], "
 r_run() {        # anything else, logged under the tag:  run:python:tools/kbench.py:attn
   echo "$hdr operand build ${PXA_OPERAND_DTYPE:-bf16}: $*" >> $O/${tag}_run.txt
   timeout ${RUN_TIMEOUT:-600} "$@" >> $O/${tag}_run.txt 2>&1; echo "rc=$?" >> $O/${tag}_run.txt
-  grep -v amdgpu $O/${tag}_run.txt | tail -n 30 | cut -c1-400
+  grep -v amdgpu $O/${tag}_run.txt | tail -n 4 | cut -c1-400
 }
 
 for spec in "$@"; do
