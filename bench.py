@@ -469,7 +469,9 @@ def main():
                                           "what": "pxa_mfma_rate_probe: v_mfma_f32_32x32x16 only, N(0,1) operands in registers, one wave per SIMD on every CU, "
                                                   "2 s back to back, rate of the second half (second figure: the same FLOPs as 16x16x32)"}
                 roof["issued_time_floor_ms"] = issued / mr[32] * 1e3          # the issued matrix work alone at that rate
-                roof["step_frac_of_mfma_only_rate"] = (issued / sec_per_step) / mr[32]
+                roof["step_frac_of_mfma_only_rate"] = (issued / sec_per_step) / mr[32]     # pipe OCCUPANCY: issued FLOPs include head_dim / key padding and the
+                #   S / dP recomputation of the two backward kernels - it rises if the kernels pad more; the EFFICIENCY figure is the next one
+                roof["step_algorithmic_frac_of_mfma_only_rate"] = (flops_step / sec_per_step) / mr[32]
             except Exception as e:   # noqa: BLE001 - a measurement leg must never take the headline number down
                 roof["mfma_only_rate"] = {"error": f"{type(e).__name__}: {e}"[:300]}
         out["roofline"] = roof

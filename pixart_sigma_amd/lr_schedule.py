@@ -12,6 +12,8 @@ plain float per step (no parameter groups to walk), so a schedule is a pure func
     steps, and a reference checkpoint's `scheduler.last_epoch` counts world x applied steps.  `steps_per_call` (= world size in train.py) and
     `step(applied=...)` reproduce both.
 """
+import os
+import warnings
 import math
 
 
@@ -78,6 +80,15 @@ class LRSchedule:
             saved_unit = max(1, int(sd["steps_per_call"]))
             if saved_unit != self.steps_per_call:
                 last = last * self.steps_per_call // saved_unit
-        elif optimizer_step and self.steps_per_call > 1 and last == int(optimizer_step):
-            last = last * self.steps_per_call
+        else:
+            # unit-less checkpoint.  PXA_LR_CKPT_UNIT states it explicitly: "optimizer" = optimizer steps (round 2's files: scaled by this run's
+            # steps_per_call), "scheduler" = scheduler steps (round 3's files, the reference's last_epoch: loaded as it stands).  Without it the heuristic below
+            # decides - and says so, because last_step == step can also be a coincidence (a scheduler restarted mid-run).
+            unit = os.environ.get("PXA_LR_CKPT_UNIT", "").lower()
+            if unit == "optimizer":
+                last = last * self.steps_per_call
+            elif unit != "scheduler" and optimizer_step and self.steps_per_call > 1 and last == int(optimizer_step):
+                warnings.warn(f"LRSchedule.load_state_dict: the checkpoint carries no scheduler unit and last_step == step == {last}: reading it as OPTIMIZER steps and "
+                              f"scaling by steps_per_call = {self.steps_per_call}; set PXA_LR_CKPT_UNIT=scheduler (or optimizer) to state the unit")
+                last = last * self.steps_per_call
         self.last_step = last

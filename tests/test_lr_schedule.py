@@ -2,6 +2,8 @@
 diffusers' lambdas, auto-lr equals reference diffusion/utils/optimizer.py:18-28, state round-trips."""
 import math
 
+import pytest
+
 import torch
 
 from pixart_sigma_amd.lr_schedule import LRSchedule, auto_scale_lr
@@ -126,3 +128,21 @@ def test_state_dict_records_its_unit_and_rescales_on_load():
     e = LRSchedule(1e-4, "constant", num_warmup_steps=1000, steps_per_call=8)
     e.load_state_dict({"last_epoch": 400})                                          # a reference checkpoint's LambdaLR state: already world x steps
     assert e.last_step == 400
+
+
+def test_unitless_checkpoint_heuristic_warns_and_can_be_overridden(monkeypatch):
+    """when last_step == step decides the unit of a unit-less checkpoint, the schedule says so; PXA_LR_CKPT_UNIT states the unit explicitly."""
+    import warnings
+    from pixart_sigma_amd.lr_schedule import LRSchedule
+    s = LRSchedule(1e-4, "constant", num_warmup_steps=1000, steps_per_call=8)
+    with pytest.warns(UserWarning, match="no scheduler unit"):
+        s.load_state_dict({"last_step": 50}, optimizer_step=50)
+    assert s.last_step == 400
+    monkeypatch.setenv("PXA_LR_CKPT_UNIT", "scheduler")          # "it already counts scheduler steps": loaded as it stands, no warning
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        s.load_state_dict({"last_step": 50}, optimizer_step=50)
+    assert s.last_step == 50
+    monkeypatch.setenv("PXA_LR_CKPT_UNIT", "optimizer")          # "optimizer steps": scaled, whatever `step` says
+    s.load_state_dict({"last_step": 50})
+    assert s.last_step == 400

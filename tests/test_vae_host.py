@@ -34,6 +34,70 @@ def test_oracle_shapes_and_downsample_convention():
     assert out[0, :, 0, 0].abs().sum() > 0 and out[0, :, 1:, :].abs().sum() == 0 and out[0, :, :, 1:].abs().sum() == 0
 
 
+def _delta_conv(conv, tap):
+    """weights of an (identity-over-channels, single-tap) convolution: out[:, c] = in[:, c] shifted by the tap; zero bias."""
+    with torch.no_grad():
+        conv.weight.zero_()
+        conv.bias.zero_()
+        for c in range(conv.weight.shape[0]):
+            conv.weight[c, c, tap[0], tap[1]] = 1.0
+
+
+def test_known_answers_of_the_restatement_resampling_and_attention():
+    """known-answer checks of oracle/vae_ref.py that do not lean on its author's reading of the architecture - the expected tensors are written
+    out by hand from the PUBLISHED definitions (diffusers Downsample2D: pad right / bottom by one, then 3x3 stride 2 without padding; Upsample2D: nearest 2x, then
+    3x3 padding 1; Attention of the mid block: GroupNorm, one head of width C, softmax(q k^T / sqrt(C)) over the KEY axis, output projection, residual)."""
+    from oracle.vae_ref import Attention, Downsample2D, Upsample2D
+    C = 32
+    x = torch.arange(1.0, 17.0).view(1, 1, 4, 4).repeat(1, C, 1, 1) * torch.linspace(1.0, 2.0, C).view(1, C, 1, 1)   # x[c, y, x] = (4 y + x + 1) * s_c
+    v = lambda y, xx: (4 * y + xx + 1) if (0 <= y < 4 and 0 <= xx < 4) else 0.0                                       # noqa: E731 - channel 0 (s = 1); 0 outside
+    # ---- Downsample2D, delta tap (ky, kx): out[y, x] = in[2 y + ky, 2 x + kx], zero where that falls on the ONE padded row / column (bottom / right)
+    d = Downsample2D(C)
+    for tap in ((0, 0), (2, 2), (1, 2), (2, 0)):
+        _delta_conv(d.conv, tap)
+        out = d(x)
+        assert out.shape == (1, C, 2, 2)
+        want = torch.tensor([[v(2 * y + tap[0], 2 * xx + tap[1]) for xx in range(2)] for y in range(2)])
+        assert torch.equal(out[0, 0], want), (tap, out[0, 0], want)
+        assert torch.allclose(out[0, C - 1], want * 2.0)
+    # ---- Upsample2D, delta tap: out[Y, X] = up[Y + ky - 1, X + kx - 1] with up[Y, X] = in[Y // 2, X // 2], zero outside the 8 x 8 upsampled image
+    u = Upsample2D(C)
+    for tap in ((1, 1), (0, 0), (2, 1), (1, 2)):
+        _delta_conv(u.conv, tap)
+        out = u(x)
+        assert out.shape == (1, C, 8, 8)
+        up = lambda Y, X: v(Y // 2, X // 2) if (0 <= Y < 8 and 0 <= X < 8) else 0.0                                     # noqa: E731
+        want = torch.tensor([[up(Y + tap[0] - 1, X + tap[1] - 1) for X in range(8)] for Y in range(8)])
+        assert torch.equal(out[0, 0], want), tap
+    # ---- Attention: x pre-normalised per GroupNorm group (two pixel classes +p / -p, every 16-channel... here 1 group of 32 channels: 16 of +1, 16 of -1), so that
+    # GroupNorm (weight 1, bias 0) is the identity up to 1 / sqrt(1 + eps); to_v = to_out = I
+    a = Attention(C, groups=1)
+    with torch.no_grad():
+        for lin in (a.to_q, a.to_k, a.to_v, a.to_out[0]):
+            lin.weight.zero_()
+            lin.bias.zero_()
+        a.to_v.weight.copy_(torch.eye(C))
+        a.to_out[0].weight.copy_(torch.eye(C))
+    pat = torch.tensor([1.0, -1.0] * (C // 2))
+    t = torch.stack([pat, pat, -pat, pat * 0 + pat, -pat, -pat], dim=1).view(1, C, 2, 3)            # pixels 0, 1, 3 of class +p; 2, 4, 5 of class -p: mean 0, variance 1
+    r = 1.0 / (1.0 + 1e-6) ** 0.5
+    out = a(t)                                                                                       # q = k = 0: uniform attention -> every pixel gets the MEAN value = 0
+    assert torch.allclose(out, t, atol=1e-6)
+    with torch.no_grad():                                                                            # q = k = alpha * GN(x): scores +-alpha^2 r^2 C / sqrt(C); large alpha -> a pixel
+        a.to_q.weight.copy_(torch.eye(C) * 3.0)                                                      # attends to its own class only, uniformly -> value = its own GN(x)
+        a.to_k.weight.copy_(torch.eye(C) * 3.0)
+    out = a(t)
+    assert torch.allclose(out, t * (1.0 + r), atol=1e-5)                                             # residual + attended value
+    s_same, s_other = 9.0 * r * r * C / C ** 0.5, -9.0 * r * r * C / C ** 0.5                        # and with a finite alpha the softmax weights are the hand-computed ones:
+    with torch.no_grad():
+        a.to_q.weight.copy_(torch.eye(C) * 0.3)
+        a.to_k.weight.copy_(torch.eye(C) * 0.3)
+    import math
+    e_same, e_other = math.exp(s_same / 100.0), math.exp(s_other / 100.0)                            # 0.3^2 = 9 / 100
+    w_same = 3 * e_same / (3 * e_same + 3 * e_other)                                                 # three pixels per class; softmax over the KEY axis
+    assert torch.allclose(a(t), t * (1.0 + r * (2 * w_same - 1.0)), atol=1e-5)
+
+
 def test_product_module_has_diffusers_state_dict_and_config():
     vae, ref = AutoencoderKL(), AutoencoderKLRef()
     a, b = vae.state_dict(), ref.state_dict()
