@@ -81,6 +81,15 @@ def test_dpm_solver_20_steps_runs_and_is_finite():
     z = torch.randn(2, 4, 8, 8, generator=torch.Generator().manual_seed(0))
     s = DPMS(model, condition=torch.ones(2, 1), uncondition=torch.zeros(2, 1), cfg_scale=4.5).sample(z, steps=20, order=2)
     assert torch.isfinite(s).all()
+    # return_intermediate (reference model/dpm_solver.py:1175-1176, 1207-1234): (x0, [initial latent, x_t after every solver step]); the oracle's solver, stopped
+    # after k steps of the same 20-step schedule, gives the same x_t
+    from oracle import pixart_oracle as po
+    s2, inter = DPMS(model, condition=torch.ones(2, 1), uncondition=torch.zeros(2, 1), cfg_scale=4.5).sample(z, steps=20, order=2, return_intermediate=True)
+    assert torch.equal(s2, s) and len(inter) == 21 and torch.equal(inter[0], z) and torch.equal(inter[-1], s)
+    eps_model = lambda x, t_in, c: 0.1 * x + 0.01 * c.mean()          # noqa: E731 - the same toy denoiser behind the oracle's (x, t, cond) interface
+    for k in (1, 2, 7, 20):
+        xk = po.dpm_solver_sample(eps_model, z, torch.ones(2, 1), torch.zeros(2, 1), 4.5, steps=20, order=2, stop_after=k)
+        assert rel_l2(inter[k], xk) < 2e-5, k
 
 
 def test_pos_table_matches_reference(golden):
