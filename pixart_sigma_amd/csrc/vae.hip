@@ -104,7 +104,13 @@ struct Norm {
 // ---- y[b, yo, xo] = act(norm(x[b, yo / up, xo / up])): writes the interior of y (the zero border of a padded grid is the caller's)
 // A thread handles one 16-byte chunk column of GA_ROWS consecutive output rows: the loads are issued before any arithmetic, so a
 // wave keeps GA_ROWS KiB in flight (one chunk per thread left this kernel latency-bound at ~2.4 TB/s).
-constexpr int GA_ROWS = 4;
+#ifndef PXA_GA_ROWS
+#define PXA_GA_ROWS 4       // rows per thread (A/B builds: tools/build_variant.py ... -DPXA_GA_ROWS=8)
+#endif
+#ifndef PXA_GA_NT
+#define PXA_GA_NT 0         // 1 = non-temporal loads of x (read once), 2 = also non-temporal stores (A/B builds)
+#endif
+constexpr int GA_ROWS = PXA_GA_ROWS;
 __global__ __launch_bounds__(256) void gn_apply_kernel(Grid x, Norm nm, int up, Grid y) {
   const int CV = x.C / 8, i = blockIdx.x * 256 + threadIdx.x;   // grid: (chunks of one output row, group of output rows, sample)
   if (i >= y.W * CV) return;
@@ -113,7 +119,9 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(Grid x, Norm nm, int up, 
 #pragma unroll
   for (int r = 0; r < GA_ROWS; r++) {
     const int yo = min(y0 + r, y.H - 1);
-    v[r] = *reinterpret_cast<const uint4*>(x.at(b, yo >> (up - 1), xo >> (up - 1)) + cv * 8);
+    const uint4* src = reinterpret_cast<const uint4*>(x.at(b, yo >> (up - 1), xo >> (up - 1)) + cv * 8);
+    if (PXA_GA_NT) { const nt_u4 t = __builtin_nontemporal_load(reinterpret_cast<const nt_u4*>(src)); v[r] = make_uint4(t[0], t[1], t[2], t[3]); }
+    else v[r] = *src;
   }
 #pragma unroll
   for (int r = 0; r < GA_ROWS; r++) {
@@ -121,7 +129,9 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(Grid x, Norm nm, int up, 
     float f[8];
     unpack_bf16x8(v[r], f);
     nm.apply(f, b, cv * 8);
-    *reinterpret_cast<uint4*>(y.at(b, y0 + r, xo) + cv * 8) = pack8(f);
+    const uint4 o4 = pack8(f);
+    if (PXA_GA_NT == 2) __builtin_nontemporal_store(nt_u4{o4.x, o4.y, o4.z, o4.w}, reinterpret_cast<nt_u4*>(y.at(b, y0 + r, xo) + cv * 8));
+    else *reinterpret_cast<uint4*>(y.at(b, y0 + r, xo) + cv * 8) = o4;
   }
 }
 

@@ -18,8 +18,8 @@ stored branch activations are bf16 (DESIGN.md "Numerics").  Backward is hand-seq
 gradients are accumulated straight into the flat fp32 gradient buffer (ParamStore.grad).
 """
 import math
-
 import os
+import weakref
 
 import numpy as np
 import torch
@@ -131,8 +131,12 @@ class ParamStore:
         """The shadow weights changed (a re-cast, a fused optimizer step): new generation, and every buffer derived from the weights is rewritten IN PLACE now -
         so whatever holds its address (a captured HIP graph) keeps reading current values, exactly as it does for the shadow itself."""
         self.generation += 1
-        for fn in self._on_change:
-            fn()
+        for ref in list(self._on_change):            # weak references: a store must not keep a discarded engine (and its buffers) alive
+            fn = ref()
+            if fn is None:
+                self._on_change.remove(ref)
+            else:
+                fn()
 
     def refresh_shadow(self, force=False):
         """Re-cast master -> bf16 shadow if any parameter was modified by torch ops since the last cast (the fused AdamW
@@ -197,7 +201,7 @@ class Engine:
         if self.prescale:
             D, depth = cfg["hidden_size"], cfg["depth"]
             self._qs = (torch.empty((depth, 3 * D, D), dtype=BF16, device=store.device), torch.empty((depth, 3 * D), dtype=F32, device=store.device))
-            store._on_change.append(self._refresh_qs)
+            store._on_change.append(weakref.WeakMethod(self._refresh_qs))
 
     # ------------------------------------------------------------------ helpers
     def pos_table(self, h, w):
