@@ -5,7 +5,7 @@
 tag=${1:?tag}
 cd "$(dirname "$0")/.." || exit 1
 for f in gpurun_out/${tag}_*; do
-  case "$f" in *.log|*.err|*_trace.csv) continue;; esac
+  case "$f" in *.log|*.err|*_trace.csv|*_pmc_step_[0-9].csv) continue;; esac
   [ -f "$f" ] && [ "$(stat -c %s "$f")" -lt 2000000 ] && cp "$f" profiles/
 done
 for op in f16 bf16; do
