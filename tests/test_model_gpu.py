@@ -336,6 +336,9 @@ def test_dpm_solver_chain_at_configured_steps_full_depth(golden, name):
     record_parity(f"{name}: {g['steps']}-step DPM-Solver++ sample (depth 28)", e, tol)
     record_parity(f"{name}: worst x_t over the chain (step {max(range(len(errs)), key=errs.__getitem__)})", max(errs), tol)
     assert torch.isfinite(s).all() and max(errs) < tol, errs
+    if name == "dpms_xl2_512_s20":          # ... and the same 20-step loop captured as ONE HIP graph (20 x ~700 launches) reproduces the eager sample bit for bit
+        sg = solver.sample_graphed(inp["x"].cuda(), steps=g["steps"], order=2, skip_type="time_uniform", method="multistep")
+        assert torch.equal(sg, s)
 
 
 def test_dmd_one_step_generator_matches_reference(golden):

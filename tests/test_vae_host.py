@@ -171,3 +171,19 @@ def test_conv_weight_packing_follows_the_abi_k_order():
     assert torch.equal(w[:, 128 * 5 + 7].float(), down.weight.detach()[:, 7, 1, 2].to(w.dtype).float())
     qkv = vae._packed[("qkv", id(vae.decoder.mid_block.attentions[0]))]
     assert qkv[0].shape == (3 * 256, 256) and qkv[2] == 3 * 256
+
+
+def test_analytic_decoder_flop_count_equals_the_hooked_count():
+    """tools/vae_layer_table.py:decode_schedule (what tools/bench_vae.py, tools/bench_dmd.py and bench.py's `configs` leg price the decoder with, so that no
+    product-side measurement imports oracle/) counts exactly the 2 m n k that forward hooks on the restated decoder count; the phase-decomposed upsampling
+    convolutions keep the reference's algorithmic count."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    from bench_vae import conv_flops
+    from vae_layer_table import decode_schedule
+    for px in (256, 512):
+        hooked = conv_flops(AutoencoderKLRef().to("meta"), px)
+        assert sum(e[2] for e in decode_schedule(1, px)) == hooked
+        assert abs(sum(e[2] for e in decode_schedule(1, px, phases=True)) - hooked) < 1e-6 * hooked
+        assert sum(e[2] for e in decode_schedule(3, px)) == 3 * hooked
