@@ -90,12 +90,19 @@ def test_bench_under_torchrun_with_a_real_rccl_group_matches_plain_run():
     noise of the fp32 atomics in the reductions (measured 1e-5 relative between two identical runs)."""
     plain = _bench({}, [sys.executable])
     port = str(29500 + os.getpid() % 2000)
-    pg = _bench({"PXA_DP_FORCE_COLLECTIVES": "1"}, [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
+    pg = _bench({"PXA_DP_FORCE_COLLECTIVES": "1", "PXA_DP_TRACE": "1", "PXA_DP_TRACE_PRINT": "0"}, [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
                                                     "--master-addr", "127.0.0.1", "--master-port", port])
     print("\nfinal_loss plain", plain["final_loss"], "rccl world-1", pg["final_loss"])
     assert pg["process_group"] == "nccl" and plain["process_group"] is None
     assert abs(pg["final_loss"] - plain["final_loss"]) < 1e-4 * abs(plain["final_loss"])
     assert pg["n_gpus"] == 1 and pg["config"]["parallelism"] == "dp1"
+    # round 6: the per-bucket trace of the last step rides in the bench line (PXA_DP_TRACE=1): final, blocks 27 .. 0, then 'cond' - every one of them launched
+    # from a hook (the last from autograd's end-of-backward callback), none from finish()
+    tr = pg["dp_trace"]
+    names = [b["bucket"] for b in tr["buckets"]]
+    assert names == ["final"] + [f"blocks.{i}" for i in reversed(range(28))] + ["cond"], names
+    assert all(b["launched_from"] == "hook" for b in tr["buckets"]) and tr["exposed_ms"] >= 0.0 and tr["world"] == 1
+    assert all(b["passed_ms"] >= b["ready_ms"] for b in tr["buckets"]) and "dp_trace" not in plain
 
 
 def test_train_entry_point_fp16_accumulation_schedule(tmp_path):
