@@ -108,7 +108,8 @@ struct Norm {
 #define PXA_GA_ROWS 4       // rows per thread (A/B builds: tools/build_variant.py ... -DPXA_GA_ROWS=8)
 #endif
 #ifndef PXA_GA_NT
-#define PXA_GA_NT 0         // 1 = non-temporal loads of x (read once), 2 = also non-temporal stores (A/B builds)
+#define PXA_GA_NT 2         // 0 = plain, 1 = non-temporal loads of x (read once), 2 = also non-temporal stores.  Two alternating rounds of the 64 x 512px decode
+                            // (profiles/r6_09_run.txt): 0: 169.3 / 168.1 ms, 1: 168.7 / 168.1, 2: 167.9 / 167.2 - small, but of one sign: the default since round 6
 #endif
 constexpr int GA_ROWS = PXA_GA_ROWS;
 __global__ __launch_bounds__(256) void gn_apply_kernel(Grid x, Norm nm, int up, Grid y) {

@@ -359,13 +359,38 @@ class AutoencoderKL(nn.Module):
         t = ops.vae_gn_apply(x, Grid.compact(B, x.H, x.W, C, dev), self._norm(x, at.group_norm))
         qkv = self._conv1(t, None, key=("qkv", id(at))).buf      # (B*HW, 3C)
         o = torch.empty(B * HW, C, dtype=BF16, device=dev)
-        for i in range(B):                                       # scores of one image at a time: HW x HW fp32
-            r = slice(i * HW, (i + 1) * HW)
-            s = ops.gemm(qkv[r, :C], qkv[r, C:2 * C], ops.NT, out_dtype=F32)
-            p = ops.vae_softmax_rows(s, C ** -0.5)
-            ops.gemm(p, qkv[r, 2 * C:], ops.NN, out=o[r])
+        # scores of one image at a time (HW x HW fp32).  Round 6: the images alternate over PXA_VAE_ATTN_STREAMS (default 2) HIP streams - the P V product of one
+        # image (an NN GEMM of 128 workgroups: half the CUs, 66 us) runs beside the next image's score GEMM and softmax instead of in front of them.  Every
+        # buffer is allocated here, on the caller's stream; the side streams start behind the qkv projection and the caller's stream waits for all of them.
+        ns = max(1, min(int(os.environ.get("PXA_VAE_ATTN_STREAMS", "2")), B))
+        sbuf = [torch.empty(HW, HW, dtype=F32, device=dev) for _ in range(ns)]
+        pbuf = [torch.empty(HW, HW, dtype=BF16, device=dev) for _ in range(ns)]
+        main = torch.cuda.current_stream(dev)
+        side = [main] if ns == 1 else self._side_streams(dev, ns)
+        if ns > 1:
+            ready = torch.cuda.Event()
+            ready.record(main)
+            for st in side:
+                st.wait_event(ready)
+        for i in range(B):
+            r, k = slice(i * HW, (i + 1) * HW), i % ns
+            with torch.cuda.stream(side[k]):
+                ops.gemm(qkv[r, :C], qkv[r, C:2 * C], ops.NT, out_f32=sbuf[k])
+                ops.vae_softmax_rows(sbuf[k], C ** -0.5, out=pbuf[k])
+                ops.gemm(pbuf[k], qkv[r, 2 * C:], ops.NN, out=o[r])
+        if ns > 1:
+            for st in side:
+                done = torch.cuda.Event()
+                done.record(st)
+                main.wait_event(done)
         o = self._conv1(Grid(o, B, x.H, x.W, C), at.to_out[0])
         return ops.vae_add(o, x, o)
+
+    def _side_streams(self, dev, n):
+        key = (str(dev), n)
+        if getattr(self, "_streams", None) is None or self._streams[0] != key:
+            self._streams = (key, [torch.cuda.Stream(device=dev) for _ in range(n)])
+        return self._streams[1]
 
     def _mid(self, x, mid):
         return self._resnet(self._attention(self._resnet(x, mid.resnets[0]), mid.attentions[0]), mid.resnets[1])
