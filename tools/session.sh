@@ -97,6 +97,18 @@ print(round(d["ms_per_step"],2), "ms/step; process_group", d["process_group"], "
   done
   cat $O/${tag}_dp_ab.txt
 }
+r_pmc_vae() {    # fabric-traffic and matrix-pipe counters of the VAE decode kernels (separate --pmc passes, as the microarch guide prescribes), fp16 build
+  export PXA_OPERAND_DTYPE=f16
+  b=${1:-16}
+  echo "$hdr operand build f16; python tools/bench_vae.py --px 512 --batch $b --iters 1 under rocprofv3 --pmc; FETCH_SIZE / WRITE_SIZE in KB per launch (FETCH_SIZE x 2 on gfx950), means over the launches of one (kernel, grid)" > $O/${tag}_pmc_vae.txt
+  for ctr in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum" "GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES"; do
+    n=$(echo $ctr | tr ' ' '_')
+    timeout 400 rocprofv3 --kernel-trace --pmc $ctr -d $O/pmc_${tag}_v$n -o r -- python tools/bench_vae.py --px 512 --batch $b --iters 1 > /dev/null 2>&1
+    { echo "== $ctr"; python tools/pmc_query.py $O/pmc_${tag}_v$n/r_results.db "gemm_pers|gn_apply|conv3x3_small|softmax_rows|gemm_glds"; } >> $O/${tag}_pmc_vae.txt 2>&1
+    rm -rf $O/pmc_${tag}_v$n
+  done
+  head -60 $O/${tag}_pmc_vae.txt | cut -c1-200
+}
 r_run() {        # anything else, logged under the tag:  run:python:tools/kbench.py:attn
   echo "$hdr operand build ${PXA_OPERAND_DTYPE:-bf16}: $*" >> $O/${tag}_run.txt
   timeout ${RUN_TIMEOUT:-600} "$@" >> $O/${tag}_run.txt 2>&1; echo "rc=$?" >> $O/${tag}_run.txt
