@@ -64,11 +64,11 @@ def test_groupnorm_stats_and_apply(ops, B, C, H, W, groups):
     assert torch.equal(from_grid(y), F.interpolate(x, scale_factor=2.0, mode="nearest"))
 
 
-@pytest.mark.parametrize("B,H,W,chans", [(2, 24, 20, (128, 256)), (1, 33, 47, (128, 512)), (3, 16, 16, (256, 256))])
+@pytest.mark.parametrize("B,H,W,chans", [(2, 24, 20, (128, 256)), (1, 33, 47, (128, 512)), (3, 16, 16, (256, 256)), (2, 30, 22, (128, 128))])
 def test_upsample_conv_as_four_phase_convolutions(ops, B, H, W, chans):
     """Round 6: Upsample2D (nearest 2x, then Conv2d 3x3 pad 1) as four 2 x 2 phase convolutions on the LOW-RES grid whose epilogues scatter into the high-res
     padded grid (pxa_gemm_args.up_*, AutoencoderKL._conv3_up2): equals conv2d(interpolate(x)) up to the ONE rounding of the summed taps, and the GroupNorm partial
-    sums its epilogues accumulate over the four launches equal the statistics of the stored result.  Odd sizes, batch > 1, 256 / 512 channels."""
+    sums its epilogues accumulate over the four launches equal the statistics of the stored result.  Odd sizes, batch > 1, 128 (paired items) / 256 / 512 channels."""
     from pixart_sigma_amd.vae import AutoencoderKL
     torch.manual_seed(3)
     vae = AutoencoderKL(block_out_channels=chans, layers_per_block=1).cuda()
